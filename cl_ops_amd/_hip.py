@@ -1,0 +1,86 @@
+"""ctypes view of the thin C-ABI HIP layer (include/clo_hip.h).
+
+Loads cl_ops_amd/lib/libcl_ops_hip.so — the only implementation there is. If
+the library is missing or does not load, importing this module raises: there
+is no CPU or PyTorch fallback for the sort/scan path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcl_ops_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "cl_ops_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C cl_ops_amd/csrc` (needs hipcc). There is no fallback path." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+
+
+class DeviceProps(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("compute_units", ci), ("max_threads_per_block", ci),
+                ("wavefront_size", ci), ("lds_bytes_per_block", sz), ("global_mem_bytes", sz),
+                ("gcn_arch", C.c_char * 64)]
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_sig("clo_hip_device_count", ci, C.POINTER(ci))
+_sig("clo_hip_set_device", ci, ci)
+_sig("clo_hip_get_device", ci, C.POINTER(ci))
+_sig("clo_hip_get_device_props", ci, ci, C.POINTER(DeviceProps))
+_sig("clo_hip_stream_create", ci, C.POINTER(vp))
+_sig("clo_hip_stream_destroy", ci, vp)
+_sig("clo_hip_stream_synchronize", ci, vp)
+_sig("clo_hip_malloc", ci, C.POINTER(vp), sz)
+_sig("clo_hip_free", ci, vp)
+_sig("clo_hip_memcpy_h2d_async", ci, vp, vp, sz, vp)
+_sig("clo_hip_memcpy_d2h_async", ci, vp, vp, sz, vp)
+_sig("clo_hip_memcpy_d2d_async", ci, vp, vp, sz, vp)
+_sig("clo_hip_memset_async", ci, vp, ci, sz, vp)
+_sig("clo_hip_event_create", ci, C.POINTER(vp))
+_sig("clo_hip_event_destroy", ci, vp)
+_sig("clo_hip_event_record", ci, vp, vp)
+_sig("clo_hip_event_synchronize", ci, vp)
+_sig("clo_hip_event_elapsed_ms", ci, vp, vp, C.POINTER(C.c_float))
+_sig("clo_hip_stream_wait_event", ci, vp, vp)
+_sig("clo_hip_error_string", C.c_char_p, ci)
+_sig("clo_hip_scan_workspace_bytes", sz, sz, ci, ci)
+_sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
+_sig("clo_hip_radix_workspace_bytes", sz, sz, ci, ci, ci)
+_sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, vp, sz, vp)
+_sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)
+_sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, sz, vp)
+_sig("clo_hip_msd_workspace_bytes", sz, sz, ci, ci)
+_sig("clo_hip_bitonic_padded_numel", sz, sz)
+_sig("clo_hip_bitonic_simple", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
+_sig("clo_hip_bitonic_tiled", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
+_sig("clo_hip_kernel_lds_bytes", sz, C.c_char_p, ci, ci)
+_sig("clo_hip_check_status", ci, vp, vp)
+_sig("clo_hip_radix_set_variant", ci, ci)
+
+
+class HipError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = lib.clo_hip_error_string(status)
+        super().__init__("%s: %s (status %d)" % (what or "clo_hip", msg.decode() if msg else "?", status))
+
+
+def check(status, what=""):
+    if status != 0:
+        raise HipError(status, what)
+
+
+def device_count():
+    n = ci(0)
+    st = lib.clo_hip_device_count(C.byref(n))
+    return n.value if st == 0 else 0

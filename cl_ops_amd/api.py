@@ -1,0 +1,422 @@
+"""Python view of the cl_ops sort/scan C API exported by libcl_ops_hip.so.
+
+This is a thin ctypes wrapper — every call goes through the C-ABI
+(include/clo_sort.h, clo_scan.h, clo_ccl.h), i.e. through the same entry
+points a C program written against the reference's headers would use:
+``clo_sort_new`` / ``clo_sort_with_device_data`` / ``clo_sort_with_host_data``
+(reference: src/cl_ops/sort/clo_sort_abstract.in.h:116-170) and the
+``clo_scan_*`` twins (src/cl_ops/scan/clo_scan_abstract.in.h:109-162).
+There is no computation in Python and no fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+from ._hip import lib, vp, sz, ci
+
+# CloType numbering: src/cl_ops/common/clo_common.in.h:108-120
+CLO_TYPES = {"char": 0, "uchar": 1, "short": 2, "ushort": 3, "int": 4, "uint": 5,
+             "long": 6, "ulong": 7, "half": 8, "float": 9, "double": 10}
+_NP_TO_CLO = {np.dtype(np.int8): "char", np.dtype(np.uint8): "uchar", np.dtype(np.int16): "short",
+              np.dtype(np.uint16): "ushort", np.dtype(np.int32): "int", np.dtype(np.uint32): "uint",
+              np.dtype(np.int64): "long", np.dtype(np.uint64): "ulong", np.dtype(np.float32): "float",
+              np.dtype(np.float64): "double"}
+CLO_TYPE_NP = {v: k for k, v in _NP_TO_CLO.items()}
+
+CL_QUEUE_PROFILING_ENABLE = 1 << 1
+
+# clo_error_codes: clo_common.in.h:80-95
+CLO_SUCCESS, CLO_ERROR_ARGS, CLO_ERROR_IMPL_NOT_FOUND, CLO_ERROR_UNKNOWN_TYPE, CLO_ERROR_LIBRARY = 0, 2, 5, 6, 7
+
+
+class GError(C.Structure):
+    _fields_ = [("domain", C.c_uint32), ("code", C.c_int), ("message", C.c_char_p)]
+
+
+GErrorP = C.POINTER(GError)
+_u32 = C.c_uint32
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_E = C.POINTER(GErrorP)
+_sig("clo_gerror_free", None, GErrorP)
+_sig("clo_quark_to_string", C.c_char_p, _u32)
+_sig("clo_error_quark", _u32)
+_sig("ccl_hip_error_quark", _u32)
+_sig("clo_type_get_name", C.c_char_p, ci)
+_sig("clo_type_sizeof", sz, ci)
+_sig("clo_type_by_name", ci, C.c_char_p, _E)
+_sig("clo_nlpo2", C.c_uint, C.c_uint)
+_sig("clo_ones32", C.c_uint, C.c_uint)
+_sig("clo_tzc", C.c_uint, ci)
+_sig("clo_sum", C.c_uint, C.c_uint)
+
+_sig("ccl_context_new_from_device_index", vp, ci, _E)
+_sig("ccl_context_new_gpu", vp, _E)
+_sig("ccl_context_destroy", None, vp)
+_sig("ccl_context_get_device", vp, vp, _u32, _E)
+_sig("ccl_device_get_index", ci, vp)
+_sig("ccl_device_get_max_work_group_size", sz, vp)
+_sig("ccl_device_get_name", C.c_char_p, vp)
+_sig("ccl_queue_new", vp, vp, vp, C.c_uint64, _E)
+_sig("ccl_queue_new_from_stream", vp, vp, vp, C.c_uint64, _E)
+_sig("ccl_queue_destroy", None, vp)
+_sig("ccl_queue_finish", _u32, vp, _E)
+_sig("ccl_queue_gc", None, vp)
+_sig("ccl_queue_get_stream", vp, vp)
+_sig("ccl_buffer_new", vp, vp, C.c_uint64, sz, vp, _E)
+_sig("ccl_buffer_new_from_device_ptr", vp, vp, vp, sz, _E)
+_sig("ccl_buffer_destroy", None, vp)
+_sig("ccl_buffer_get_size", sz, vp)
+_sig("ccl_buffer_get_device_ptr", vp, vp)
+_sig("ccl_buffer_enqueue_write", vp, vp, vp, _u32, sz, sz, vp, vp, _E)
+_sig("ccl_buffer_enqueue_read", vp, vp, vp, _u32, sz, sz, vp, vp, _E)
+_sig("ccl_buffer_enqueue_copy", vp, vp, vp, vp, sz, sz, sz, vp, _E)
+_sig("ccl_event_get_name", C.c_char_p, vp)
+_sig("ccl_prof_new", vp)
+_sig("ccl_prof_destroy", None, vp)
+_sig("ccl_prof_add_queue", None, vp, C.c_char_p, vp)
+_sig("ccl_prof_calc", _u32, vp, _E)
+_sig("ccl_prof_get_duration", C.c_uint64, vp)
+
+_sig("clo_sort_new", vp, C.c_char_p, C.c_char_p, vp, C.POINTER(ci), C.POINTER(ci), C.c_char_p, C.c_char_p,
+     C.c_char_p, _E)
+_sig("clo_sort_destroy", None, vp)
+_sig("clo_sort_with_device_data", vp, vp, vp, vp, vp, vp, sz, sz, _E)
+_sig("clo_sort_with_host_data", _u32, vp, vp, vp, vp, vp, sz, sz, _E)
+_sig("clo_sort_get_context", vp, vp)
+_sig("clo_sort_get_program", vp, vp)
+_sig("clo_sort_get_element_type", ci, vp)
+_sig("clo_sort_get_element_size", sz, vp)
+_sig("clo_sort_get_key_type", ci, vp)
+_sig("clo_sort_get_key_size", sz, vp)
+_sig("clo_sort_get_data", vp, vp)
+_sig("clo_sort_set_data", None, vp, vp)
+_sig("clo_sort_get_num_kernels", _u32, vp, _E)
+_sig("clo_sort_get_kernel_name", C.c_char_p, vp, _u32, _E)
+_sig("clo_sort_get_localmem_usage", sz, vp, _u32, sz, sz, _E)
+
+_sig("clo_scan_new", vp, C.c_char_p, C.c_char_p, vp, ci, ci, C.c_char_p, _E)
+_sig("clo_scan_destroy", None, vp)
+_sig("clo_scan_with_device_data", vp, vp, vp, vp, vp, vp, sz, sz, _E)
+_sig("clo_scan_with_host_data", _u32, vp, vp, vp, vp, vp, sz, sz, _E)
+_sig("clo_scan_get_context", vp, vp)
+_sig("clo_scan_get_program", vp, vp)
+_sig("clo_scan_get_elem_type", ci, vp)
+_sig("clo_scan_get_element_size", sz, vp)
+_sig("clo_scan_get_sum_type", ci, vp)
+_sig("clo_scan_get_sum_size", sz, vp)
+_sig("clo_scan_get_data", vp, vp)
+_sig("clo_scan_set_data", None, vp, vp)
+_sig("clo_scan_get_num_kernels", _u32, vp, _E)
+_sig("clo_scan_get_kernel_name", C.c_char_p, vp, _u32, _E)
+_sig("clo_scan_get_localmem_usage", sz, vp, _u32, sz, sz, _E)
+
+
+class CloError(RuntimeError):
+    """A GError reported by the library: .domain (string), .code, .message."""
+
+    def __init__(self, domain, code, message):
+        self.domain, self.code, self.message = domain, code, message
+        super().__init__("[%s:%d] %s" % (domain, code, message))
+
+
+class _Err:
+    """GError** out-parameter holder."""
+
+    def __init__(self):
+        self.p = GErrorP()
+
+    @property
+    def ref(self):
+        return C.byref(self.p)
+
+    def raise_if_set(self):
+        if self.p:
+            e = self.p.contents
+            dom = lib.clo_quark_to_string(e.domain)
+            exc = CloError(dom.decode() if dom else str(e.domain), e.code,
+                           e.message.decode() if e.message else "")
+            lib.clo_gerror_free(self.p)
+            self.p = GErrorP()
+            raise exc
+
+
+def _b(s):
+    return None if s is None else s.encode()
+
+
+def clo_type(t):
+    """CloType constant from a name ('uint'), a numpy dtype, or an int."""
+    if isinstance(t, int):
+        return t
+    if isinstance(t, str):
+        return CLO_TYPES[t]
+    return CLO_TYPES[_NP_TO_CLO[np.dtype(t)]]
+
+
+class Context:
+    """CCLContext over one HIP device."""
+
+    def __init__(self, device_index=0):
+        err = _Err()
+        self.h = lib.ccl_context_new_from_device_index(device_index, err.ref)
+        err.raise_if_set()
+        if not self.h:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "could not create context")
+        self.device_index = device_index
+
+    @property
+    def device(self):
+        return lib.ccl_context_get_device(self.h, 0, None)
+
+    @property
+    def device_name(self):
+        n = lib.ccl_device_get_name(self.device)
+        return n.decode() if n else ""
+
+    def close(self):
+        if self.h:
+            lib.ccl_context_destroy(self.h)
+            self.h = None
+
+
+class Queue:
+    """CCLQueue = one HIP stream (own, or adopted from e.g. torch)."""
+
+    def __init__(self, ctx, profiling=False, stream=None):
+        err = _Err()
+        props = CL_QUEUE_PROFILING_ENABLE if profiling else 0
+        if stream is None:
+            self.h = lib.ccl_queue_new(ctx.h, None, props, err.ref)
+        else:
+            self.h = lib.ccl_queue_new_from_stream(ctx.h, vp(stream), props, err.ref)
+        err.raise_if_set()
+        self.ctx = ctx
+
+    @property
+    def stream(self):
+        return lib.ccl_queue_get_stream(self.h)
+
+    def finish(self):
+        err = _Err()
+        lib.ccl_queue_finish(self.h, err.ref)
+        err.raise_if_set()
+
+    def gc(self):
+        lib.ccl_queue_gc(self.h)
+
+    def close(self):
+        if self.h:
+            lib.ccl_queue_destroy(self.h)
+            self.h = None
+
+
+class Buffer:
+    """CCLBuffer: device memory (owned, or wrapping an external device pointer)."""
+
+    def __init__(self, ctx, nbytes=None, device_ptr=None):
+        err = _Err()
+        if device_ptr is None:
+            self.h = lib.ccl_buffer_new(ctx.h, 1, nbytes, None, err.ref)
+        else:
+            self.h = lib.ccl_buffer_new_from_device_ptr(ctx.h, vp(device_ptr), nbytes, err.ref)
+        err.raise_if_set()
+        self.ctx = ctx
+        self.nbytes = nbytes
+
+    @property
+    def ptr(self):
+        return lib.ccl_buffer_get_device_ptr(self.h)
+
+    def write(self, queue, array, offset=0):
+        a = np.ascontiguousarray(array)
+        err = _Err()
+        lib.ccl_buffer_enqueue_write(self.h, queue.h, 1, offset, a.nbytes, a.ctypes.data_as(vp), None, err.ref)
+        err.raise_if_set()
+
+    def read(self, queue, dtype, count, offset=0):
+        out = np.empty(count, dtype=dtype)
+        err = _Err()
+        lib.ccl_buffer_enqueue_read(self.h, queue.h, 1, offset, out.nbytes, out.ctypes.data_as(vp), None, err.ref)
+        err.raise_if_set()
+        return out
+
+    def close(self):
+        if self.h:
+            lib.ccl_buffer_destroy(self.h)
+            self.h = None
+
+
+class Sorter:
+    """CloSort. Arguments as clo_sort_new (clo_sort_abstract.in.h:116-120)."""
+
+    def __init__(self, algorithm, ctx, elem_type, key_type=None, options=None, compare=None, get_key=None,
+                 compiler_opts=None):
+        et = ci(clo_type(elem_type))
+        kt = ci(clo_type(key_type)) if key_type is not None else None
+        err = _Err()
+        self.h = lib.clo_sort_new(_b(algorithm), _b(options), ctx.h, C.byref(et),
+                                  C.byref(kt) if kt is not None else None, _b(compare), _b(get_key),
+                                  _b(compiler_opts), err.ref)
+        err.raise_if_set()
+        if not self.h:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_sort_new returned NULL")
+        self.ctx = ctx
+
+    def with_device_data(self, q_exec, data_in, data_out, numel, lws_max=0, q_comm=None):
+        err = _Err()
+        evt = lib.clo_sort_with_device_data(self.h, q_exec.h, q_comm.h if q_comm else None, data_in.h,
+                                            data_out.h if data_out is not None else None, numel, lws_max, err.ref)
+        err.raise_if_set()
+        return evt
+
+    def with_host_data(self, array, q_exec=None, q_comm=None, lws_max=0):
+        a = np.ascontiguousarray(array)
+        out = np.empty_like(a)
+        err = _Err()
+        ok = lib.clo_sort_with_host_data(self.h, q_exec.h if q_exec else None, q_comm.h if q_comm else None,
+                                         a.ctypes.data_as(vp), out.ctypes.data_as(vp), a.size, lws_max, err.ref)
+        err.raise_if_set()
+        if not ok:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_sort_with_host_data failed")
+        return out
+
+    @property
+    def element_size(self):
+        return lib.clo_sort_get_element_size(self.h)
+
+    @property
+    def key_size(self):
+        return lib.clo_sort_get_key_size(self.h)
+
+    @property
+    def element_type(self):
+        return lib.clo_sort_get_element_type(self.h)
+
+    @property
+    def key_type(self):
+        return lib.clo_sort_get_key_type(self.h)
+
+    def num_kernels(self):
+        err = _Err()
+        n = lib.clo_sort_get_num_kernels(self.h, err.ref)
+        err.raise_if_set()
+        return n
+
+    def kernel_name(self, i):
+        err = _Err()
+        n = lib.clo_sort_get_kernel_name(self.h, i, err.ref)
+        err.raise_if_set()
+        return n.decode() if n else None
+
+    def localmem_usage(self, i, lws_max=0, numel=1 << 20):
+        err = _Err()
+        n = lib.clo_sort_get_localmem_usage(self.h, i, lws_max, numel, err.ref)
+        err.raise_if_set()
+        return n
+
+    def close(self):
+        if self.h:
+            lib.clo_sort_destroy(self.h)
+            self.h = None
+
+
+class Scanner:
+    """CloScan. Arguments as clo_scan_new (clo_scan_abstract.in.h:109-112)."""
+
+    def __init__(self, algorithm, ctx, elem_type, sum_type, options=None, compiler_opts=None):
+        err = _Err()
+        self.h = lib.clo_scan_new(_b(algorithm), _b(options), ctx.h, clo_type(elem_type), clo_type(sum_type),
+                                  _b(compiler_opts), err.ref)
+        err.raise_if_set()
+        if not self.h:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_scan_new returned NULL")
+        self.ctx = ctx
+        self.sum_np = CLO_TYPE_NP[[k for k, v in CLO_TYPES.items() if v == clo_type(sum_type)][0]]
+
+    def with_device_data(self, q_exec, data_in, data_out, numel, lws_max=0, q_comm=None):
+        err = _Err()
+        evt = lib.clo_scan_with_device_data(self.h, q_exec.h, q_comm.h if q_comm else None, data_in.h,
+                                            data_out.h, numel, lws_max, err.ref)
+        err.raise_if_set()
+        return evt
+
+    def with_host_data(self, array, q_exec=None, q_comm=None, lws_max=0):
+        a = np.ascontiguousarray(array)
+        out = np.empty(a.size, dtype=self.sum_np)
+        err = _Err()
+        ok = lib.clo_scan_with_host_data(self.h, q_exec.h if q_exec else None, q_comm.h if q_comm else None,
+                                         a.ctypes.data_as(vp), out.ctypes.data_as(vp), a.size, lws_max, err.ref)
+        err.raise_if_set()
+        if not ok:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_scan_with_host_data failed")
+        return out
+
+    def num_kernels(self):
+        return lib.clo_scan_get_num_kernels(self.h, None)
+
+    def kernel_name(self, i):
+        n = lib.clo_scan_get_kernel_name(self.h, i, None)
+        return n.decode() if n else None
+
+    def localmem_usage(self, i, lws_max=0, numel=1 << 20):
+        return lib.clo_scan_get_localmem_usage(self.h, i, lws_max, numel, None)
+
+    def close(self):
+        if self.h:
+            lib.clo_scan_destroy(self.h)
+            self.h = None
+
+
+class Profiler:
+    """CCLProf over queues created with profiling=True (clo_sort_bench.c:201-208)."""
+
+    def __init__(self, *queues):
+        self.h = lib.ccl_prof_new()
+        for q in queues:
+            lib.ccl_prof_add_queue(self.h, b"q", q.h)
+
+    def duration_ns(self):
+        err = _Err()
+        lib.ccl_prof_calc(self.h, err.ref)
+        err.raise_if_set()
+        return lib.ccl_prof_get_duration(self.h)
+
+    def close(self):
+        if self.h:
+            lib.ccl_prof_destroy(self.h)
+            self.h = None
+
+
+class HipEventTimer:
+    """Pair of HIP events on a queue's stream (the stream the kernels run on)."""
+
+    def __init__(self, queue):
+        self.q = queue
+        self.e0, self.e1 = vp(), vp()
+        _hip.check(lib.clo_hip_event_create(C.byref(self.e0)))
+        _hip.check(lib.clo_hip_event_create(C.byref(self.e1)))
+
+    def start(self):
+        _hip.check(lib.clo_hip_event_record(self.e0, self.q.stream))
+
+    def stop(self):
+        _hip.check(lib.clo_hip_event_record(self.e1, self.q.stream))
+
+    def elapsed_ms(self):
+        _hip.check(lib.clo_hip_event_synchronize(self.e1))
+        ms = C.c_float()
+        _hip.check(lib.clo_hip_event_elapsed_ms(self.e0, self.e1, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        lib.clo_hip_event_destroy(self.e0)
+        lib.clo_hip_event_destroy(self.e1)

@@ -1,0 +1,434 @@
+/*
+ * clo_ccl.c — the cf4ocl2 object subset of include/clo_ccl.h over the thin HIP
+ * C-ABI (clo_hip.h). Plain C; no OpenCL anywhere.
+ */
+#include "clo_ccl.h"
+#include "clo_common.h"
+#include "clo_hip.h"
+
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef CLO_USE_GLIB
+#define clo_gerror_set g_set_error
+#define CLO_QUARK(s) g_quark_from_static_string(s)
+#else
+#define CLO_QUARK(s) clo_quark_from_string(s)
+#endif
+
+struct ccl_device {
+	int index;
+	clo_hip_device_props props;
+};
+
+struct ccl_context {
+	int refcount;
+	struct ccl_device dev;
+};
+
+struct ccl_event {
+	struct ccl_event* next;  /* queue-owned list */
+	char name[48];
+	void* start;             /* hip events; start only when profiling */
+	void* end;
+};
+
+struct ccl_queue {
+	CCLContext* ctx;
+	void* stream;
+	int owns_stream;
+	int profiling;
+	struct ccl_event* events;  /* most recent first */
+	struct ccl_event* first;   /* oldest since last gc */
+};
+
+struct ccl_buffer {
+	CCLContext* ctx;
+	void* dptr;
+	size_t size;
+	int owns;
+};
+
+struct ccl_program {
+	char* what;
+	char* options;
+};
+
+struct ccl_event_wait_list {
+	size_t n, cap;
+	CCLEvent** evts;
+};
+
+#define CCL_PROF_MAX_QUEUES 8
+struct ccl_prof {
+	CCLQueue* queues[CCL_PROF_MAX_QUEUES];
+	int nqueues;
+	cl_ulong duration_ns;
+};
+
+GQuark ccl_hip_error_quark(void) { return CLO_QUARK("ccl-hip-error-quark"); }
+
+/* Returns 1 (and sets err) when a clo_hip_* status is a failure. */
+static int hip_failed(int st, GError** err, const char* what) {
+	if (st == 0) return 0;
+	clo_gerror_set(err, CCL_HIP_ERROR, st, "%s: %s", what, clo_hip_error_string(st));
+	return 1;
+}
+
+static int use_device(CCLContext* ctx, GError** err) {
+	return !hip_failed(clo_hip_set_device(ctx->dev.index), err, "hipSetDevice");
+}
+
+/* ---------------- context / device ---------------- */
+
+CCLContext* ccl_context_new_from_device_index(int device_index, GError** err) {
+	int count = 0;
+	int st = clo_hip_device_count(&count);
+	if (st != 0 || count <= 0) {
+		clo_gerror_set(err, CCL_HIP_ERROR, st ? st : 100,
+			"No HIP device available (%s); cl_ops_amd has no CPU path", clo_hip_error_string(st ? st : 100));
+		return NULL;
+	}
+	if (device_index < 0) device_index = 0;
+	if (device_index >= count) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Device index %d out of range (%d devices)", device_index, count);
+		return NULL;
+	}
+	CCLContext* ctx = (CCLContext*) calloc(1, sizeof(*ctx));
+	if (!ctx) return NULL;
+	ctx->refcount = 1;
+	ctx->dev.index = device_index;
+	if (hip_failed(clo_hip_get_device_props(device_index, &ctx->dev.props), err, "hipGetDeviceProperties")) {
+		free(ctx);
+		return NULL;
+	}
+	if (!use_device(ctx, err)) { free(ctx); return NULL; }
+	return ctx;
+}
+
+CCLContext* ccl_context_new_gpu(GError** err) {
+	return ccl_context_new_from_device_index(0, err);
+}
+
+CCLContext* ccl_context_new_from_menu_full(void* dev_idx_ptr, GError** err) {
+	int idx = dev_idx_ptr ? *(int*) dev_idx_ptr : -1;
+	return ccl_context_new_from_device_index(idx, err);
+}
+
+void ccl_context_ref(CCLContext* ctx) { if (ctx) ++ctx->refcount; }
+
+void ccl_context_unref(CCLContext* ctx) {
+	if (ctx && --ctx->refcount == 0) free(ctx);
+}
+
+void ccl_context_destroy(CCLContext* ctx) { ccl_context_unref(ctx); }
+
+CCLDevice* ccl_context_get_device(CCLContext* ctx, cl_uint index, GError** err) {
+	if (!ctx || index != 0) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Context holds exactly one device (index 0)");
+		return NULL;
+	}
+	return &ctx->dev;
+}
+
+int ccl_device_get_index(CCLDevice* dev) { return dev ? dev->index : -1; }
+size_t ccl_device_get_max_work_group_size(CCLDevice* dev) { return dev ? (size_t) dev->props.max_threads_per_block : 0; }
+const char* ccl_device_get_name(CCLDevice* dev) { return dev ? dev->props.name : NULL; }
+
+/* ---------------- queue ---------------- */
+
+static CCLQueue* queue_alloc(CCLContext* ctx, void* stream, int owns, cl_ulong properties) {
+	CCLQueue* cq = (CCLQueue*) calloc(1, sizeof(*cq));
+	if (!cq) return NULL;
+	ccl_context_ref(ctx);
+	cq->ctx = ctx;
+	cq->stream = stream;
+	cq->owns_stream = owns;
+	cq->profiling = (properties & CL_QUEUE_PROFILING_ENABLE) != 0;
+	return cq;
+}
+
+CCLQueue* ccl_queue_new(CCLContext* ctx, CCLDevice* dev, cl_ulong properties, GError** err) {
+	(void) dev;
+	if (!ctx) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL context"); return NULL; }
+	if (!use_device(ctx, err)) return NULL;
+	void* stream = NULL;
+	if (hip_failed(clo_hip_stream_create(&stream), err, "hipStreamCreate")) return NULL;
+	return queue_alloc(ctx, stream, 1, properties);
+}
+
+CCLQueue* ccl_queue_new_from_stream(CCLContext* ctx, void* hip_stream, cl_ulong properties, GError** err) {
+	if (!ctx) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL context"); return NULL; }
+	return queue_alloc(ctx, hip_stream, 0, properties);
+}
+
+void ccl_queue_gc(CCLQueue* cq) {
+	if (!cq) return;
+	struct ccl_event* e = cq->events;
+	while (e) {
+		struct ccl_event* next = e->next;
+		clo_hip_event_destroy(e->start);
+		clo_hip_event_destroy(e->end);
+		free(e);
+		e = next;
+	}
+	cq->events = NULL;
+	cq->first = NULL;
+}
+
+void ccl_queue_destroy(CCLQueue* cq) {
+	if (!cq) return;
+	clo_hip_set_device(cq->ctx->dev.index);
+	clo_hip_stream_synchronize(cq->stream);
+	ccl_queue_gc(cq);
+	if (cq->owns_stream) clo_hip_stream_destroy(cq->stream);
+	ccl_context_unref(cq->ctx);
+	free(cq);
+}
+
+CCLDevice* ccl_queue_get_device(CCLQueue* cq, GError** err) {
+	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }
+	return &cq->ctx->dev;
+}
+
+CCLContext* ccl_queue_get_context(CCLQueue* cq, GError** err) {
+	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }
+	return cq->ctx;
+}
+
+cl_bool ccl_queue_finish(CCLQueue* cq, GError** err) {
+	if (!cq) return CL_FALSE;
+	return hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize") ? CL_FALSE : CL_TRUE;
+}
+
+void* ccl_queue_get_stream(CCLQueue* cq) { return cq ? cq->stream : NULL; }
+
+CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err) {
+	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }
+	if (!use_device(cq->ctx, err)) return NULL;
+	struct ccl_event* e = (struct ccl_event*) calloc(1, sizeof(*e));
+	if (!e) return NULL;
+	ccl_event_set_name(e, name);
+	if (hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) { free(e); return NULL; }
+	if (cq->profiling) {
+		if (hip_failed(clo_hip_event_create(&e->start), err, "hipEventCreate")
+			|| hip_failed(clo_hip_event_record(e->start, cq->stream), err, "hipEventRecord")) {
+			clo_hip_event_destroy(e->start);
+			clo_hip_event_destroy(e->end);
+			free(e);
+			return NULL;
+		}
+	}
+	e->next = cq->events;
+	cq->events = e;
+	if (!cq->first) cq->first = e;
+	return e;
+}
+
+cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err) {
+	if (!cq || !evt) return CL_FALSE;
+	return hip_failed(clo_hip_event_record(evt->end, cq->stream), err, "hipEventRecord") ? CL_FALSE : CL_TRUE;
+}
+
+cl_bool ccl_queue_wait_for(CCLQueue* cq, CCLEventWaitList* ewl, GError** err) {
+	if (!cq) return CL_FALSE;
+	if (!ewl || !*ewl) return CL_TRUE;
+	for (size_t i = 0; i < (*ewl)->n; ++i)
+		if (hip_failed(clo_hip_stream_wait_event(cq->stream, (*ewl)->evts[i]->end), err, "hipStreamWaitEvent"))
+			return CL_FALSE;
+	return CL_TRUE;
+}
+
+/* ---------------- buffer ---------------- */
+
+CCLBuffer* ccl_buffer_new(CCLContext* ctx, cl_ulong flags, size_t size, void* host_ptr, GError** err) {
+	(void) flags;
+	if (!ctx) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL context"); return NULL; }
+	if (host_ptr) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "host_ptr buffers are not supported"); return NULL; }
+	if (!use_device(ctx, err)) return NULL;
+	CCLBuffer* b = (CCLBuffer*) calloc(1, sizeof(*b));
+	if (!b) return NULL;
+	if (hip_failed(clo_hip_malloc(&b->dptr, size), err, "hipMalloc")) { free(b); return NULL; }
+	ccl_context_ref(ctx);
+	b->ctx = ctx;
+	b->size = size;
+	b->owns = 1;
+	return b;
+}
+
+CCLBuffer* ccl_buffer_new_from_device_ptr(CCLContext* ctx, void* device_ptr, size_t size, GError** err) {
+	if (!ctx || !device_ptr) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL context or pointer"); return NULL; }
+	CCLBuffer* b = (CCLBuffer*) calloc(1, sizeof(*b));
+	if (!b) return NULL;
+	ccl_context_ref(ctx);
+	b->ctx = ctx;
+	b->dptr = device_ptr;
+	b->size = size;
+	b->owns = 0;
+	return b;
+}
+
+void ccl_buffer_destroy(CCLBuffer* buf) {
+	if (!buf) return;
+	if (buf->owns) {
+		clo_hip_set_device(buf->ctx->dev.index);
+		clo_hip_free(buf->dptr);  /* hipFree waits for work using the memory */
+	}
+	ccl_context_unref(buf->ctx);
+	free(buf);
+}
+
+size_t ccl_buffer_get_size(CCLBuffer* buf) { return buf ? buf->size : 0; }
+void* ccl_buffer_get_device_ptr(CCLBuffer* buf) { return buf ? buf->dptr : NULL; }
+
+typedef int (*copy_fn)(void*, const void*, size_t, void*);
+
+static CCLEvent* enqueue_copy(CCLQueue* cq, const char* name, copy_fn fn, void* dst, const void* src,
+	size_t size, cl_bool blocking, CCLEventWaitList* ewl, GError** err) {
+	if (!ccl_queue_wait_for(cq, ewl, err)) return NULL;
+	if (ewl) ccl_event_wait_list_clear(ewl);
+	CCLEvent* e = ccl_queue_begin_command(cq, name, err);
+	if (!e) return NULL;
+	if (hip_failed(fn(dst, src, size, cq->stream), err, name)) return NULL;
+	if (!ccl_queue_end_command(cq, e, err)) return NULL;
+	if (blocking && hip_failed(clo_hip_event_synchronize(e->end), err, "hipEventSynchronize")) return NULL;
+	return e;
+}
+
+static int range_ok(CCLBuffer* b, size_t off, size_t size, GError** err) {
+	if (!b || off > b->size || size > b->size - off) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Buffer range out of bounds");
+		return 0;
+	}
+	return 1;
+}
+
+CCLEvent* ccl_buffer_enqueue_write(CCLBuffer* buf, CCLQueue* cq, cl_bool blocking, size_t offset,
+	size_t size, void* ptr, CCLEventWaitList* ewl, GError** err) {
+	if (!cq || !range_ok(buf, offset, size, err)) return NULL;
+	return enqueue_copy(cq, "write_buffer", clo_hip_memcpy_h2d_async, (char*) buf->dptr + offset, ptr, size, blocking, ewl, err);
+}
+
+CCLEvent* ccl_buffer_enqueue_read(CCLBuffer* buf, CCLQueue* cq, cl_bool blocking, size_t offset,
+	size_t size, void* ptr, CCLEventWaitList* ewl, GError** err) {
+	if (!cq || !range_ok(buf, offset, size, err)) return NULL;
+	return enqueue_copy(cq, "read_buffer", clo_hip_memcpy_d2h_async, ptr, (char*) buf->dptr + offset, size, blocking, ewl, err);
+}
+
+CCLEvent* ccl_buffer_enqueue_copy(CCLBuffer* src, CCLBuffer* dst, CCLQueue* cq, size_t src_offset,
+	size_t dst_offset, size_t size, CCLEventWaitList* ewl, GError** err) {
+	if (!cq || !range_ok(src, src_offset, size, err) || !range_ok(dst, dst_offset, size, err)) return NULL;
+	return enqueue_copy(cq, "copy_buffer", clo_hip_memcpy_d2d_async, (char*) dst->dptr + dst_offset,
+		(char*) src->dptr + src_offset, size, CL_FALSE, ewl, err);
+}
+
+/* ---------------- events ---------------- */
+
+void ccl_event_set_name(CCLEvent* evt, const char* name) {
+	if (!evt) return;
+	strncpy(evt->name, name ? name : "", sizeof(evt->name) - 1);
+	evt->name[sizeof(evt->name) - 1] = '\0';
+}
+
+const char* ccl_event_get_name(CCLEvent* evt) { return evt ? evt->name : NULL; }
+
+static void ewl_push(CCLEventWaitList* ewl, CCLEvent* e) {
+	if (!ewl || !e) return;
+	if (!*ewl) *ewl = (CCLEventWaitList) calloc(1, sizeof(**ewl));
+	if (!*ewl) return;
+	if ((*ewl)->n == (*ewl)->cap) {
+		size_t cap = (*ewl)->cap ? (*ewl)->cap * 2 : 4;
+		CCLEvent** p = (CCLEvent**) realloc((*ewl)->evts, cap * sizeof(CCLEvent*));
+		if (!p) return;
+		(*ewl)->evts = p;
+		(*ewl)->cap = cap;
+	}
+	(*ewl)->evts[(*ewl)->n++] = e;
+}
+
+CCLEventWaitList* ccl_ewl(CCLEventWaitList* ewl, ...) {
+	va_list ap;
+	va_start(ap, ewl);
+	for (CCLEvent* e = va_arg(ap, CCLEvent*); e != NULL; e = va_arg(ap, CCLEvent*)) ewl_push(ewl, e);
+	va_end(ap);
+	return ewl;
+}
+
+void ccl_event_wait_list_add(CCLEventWaitList* ewl, ...) {
+	va_list ap;
+	va_start(ap, ewl);
+	for (CCLEvent* e = va_arg(ap, CCLEvent*); e != NULL; e = va_arg(ap, CCLEvent*)) ewl_push(ewl, e);
+	va_end(ap);
+}
+
+void ccl_event_wait_list_clear(CCLEventWaitList* ewl) {
+	if (ewl && *ewl) {
+		free((*ewl)->evts);
+		free(*ewl);
+		*ewl = NULL;
+	}
+}
+
+cl_bool ccl_event_wait(CCLEventWaitList* ewl, GError** err) {
+	cl_bool ok = CL_TRUE;
+	if (ewl && *ewl) {
+		for (size_t i = 0; i < (*ewl)->n && ok; ++i)
+			if (hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) ok = CL_FALSE;
+		ccl_event_wait_list_clear(ewl);
+	}
+	return ok;
+}
+
+/* ---------------- program token ---------------- */
+
+CCLProgram* ccl_program_new_token(CCLContext* ctx, const char* what, const char* build_options) {
+	(void) ctx;
+	CCLProgram* p = (CCLProgram*) calloc(1, sizeof(*p));
+	if (!p) return NULL;
+	p->what = strdup(what ? what : "");
+	p->options = strdup(build_options ? build_options : "");
+	return p;
+}
+
+void ccl_program_destroy(CCLProgram* prg) {
+	if (!prg) return;
+	free(prg->what);
+	free(prg->options);
+	free(prg);
+}
+
+const char* ccl_program_get_build_options(CCLProgram* prg) { return prg ? prg->options : NULL; }
+
+/* ---------------- profiling ---------------- */
+
+CCLProf* ccl_prof_new(void) { return (CCLProf*) calloc(1, sizeof(CCLProf)); }
+void ccl_prof_destroy(CCLProf* prof) { free(prof); }
+
+void ccl_prof_add_queue(CCLProf* prof, const char* name, CCLQueue* cq) {
+	(void) name;
+	if (prof && cq && prof->nqueues < CCL_PROF_MAX_QUEUES) prof->queues[prof->nqueues++] = cq;
+}
+
+cl_bool ccl_prof_calc(CCLProf* prof, GError** err) {
+	if (!prof) return CL_FALSE;
+	prof->duration_ns = 0;
+	for (int q = 0; q < prof->nqueues; ++q) {
+		CCLQueue* cq = prof->queues[q];
+		if (!cq->profiling) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Queue was not created with CL_QUEUE_PROFILING_ENABLE");
+			return CL_FALSE;
+		}
+		if (!cq->events) continue;
+		if (hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize")) return CL_FALSE;
+		float ms = 0.f;
+		if (hip_failed(clo_hip_event_elapsed_ms(cq->first->start, cq->events->end, &ms), err, "hipEventElapsedTime"))
+			return CL_FALSE;
+		prof->duration_ns += (cl_ulong) ((double) ms * 1e6);
+		/* cf4ocl2 releases the queue's events once profiled. */
+		ccl_queue_gc(cq);
+	}
+	return CL_TRUE;
+}
+
+cl_ulong ccl_prof_get_duration(CCLProf* prof) { return prof ? prof->duration_ns : 0; }

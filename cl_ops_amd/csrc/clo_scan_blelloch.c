@@ -1,0 +1,118 @@
+/*
+ * clo_scan_blelloch.c — host driver of the "blelloch" scanner over HIP.
+ *
+ * Mirrors src/cl_ops/scan/clo_scan_blelloch.c of the reference: any option is
+ * an error (:43-45), three kernel names (:251-279), exclusive scan
+ * data_in[elem] -> data_out[sum]. The three launches of :146-195 (workgroupScan,
+ * workgroupSumsScan, addWorkgroupSums) are replaced by one call into the C-ABI,
+ * clo_hip_scan_exclusive: a single-pass chained scan that reads and writes
+ * every element once. The whole array is scanned (upstream leaves the tail
+ * numel % (2*lws) unscanned, clo_scan_blelloch.cl:70).
+ */
+#include "clo_scan.h"
+#include "clo_internal.h"
+
+#include <string.h>
+
+typedef struct {
+	clo_devbuf workspace;
+	void* last_stream;
+} clo_scan_blelloch_data;
+
+static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec,
+	CCLQueue* cq_comm, CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max,
+	GError** err) {
+
+	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
+	clo_return_val_if_fail(cq_exec != NULL, NULL);
+	clo_return_val_if_fail(data_in != NULL && data_out != NULL, NULL);
+	(void) cq_comm;
+	(void) lws_max;
+
+	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scanner);
+	const int es = (int) clo_scan_get_element_size(scanner);
+	const int ss = (int) clo_scan_get_sum_size(scanner);
+	void* stream = ccl_queue_get_stream(cq_exec);
+
+	if (numel * (size_t) es > ccl_buffer_get_size(data_in) || numel * (size_t) ss > ccl_buffer_get_size(data_out)) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "numel (%zu) exceeds the size of the device buffers", numel);
+		return NULL;
+	}
+
+	CCLEvent* evt = ccl_queue_begin_command(cq_exec, "clo_scan_blelloch_wgscan", err);
+	if (!evt) return NULL;
+
+	if (numel > 0) {
+		if (data->last_stream && data->last_stream != stream)
+			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
+		data->last_stream = stream;
+		const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
+		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return NULL;
+		clo_debug("BLELLOCH: N=%zu elem=%dB sum=%dB workspace=%zuB", numel, es, ss, ws);
+		int st = clo_hip_scan_exclusive(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out),
+			numel, es, clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
+			data->workspace.ptr, data->workspace.bytes, stream);
+		if (clo_hip_failed(st, err, "clo_hip_scan_exclusive")) return NULL;
+	}
+
+	if (!ccl_queue_end_command(cq_exec, evt, err)) return NULL;
+	return evt;
+}
+
+/* ref: clo_scan_blelloch.c:219-249 — options must be empty. */
+static const char* clo_scan_blelloch_init(CloScan* scanner, const char* options, GError** err) {
+	if (options != NULL && strlen(options) > 0) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Invalid options for blelloch scan.");
+		return NULL;
+	}
+	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) calloc(1, sizeof(*data));
+	if (!data) return NULL;
+	clo_scan_set_data(scanner, data);
+	return "blelloch:hip";
+}
+
+static void clo_scan_blelloch_finalize(CloScan* scan) {
+	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scan);
+	if (data) {
+		clo_devbuf_release(&data->workspace);
+		free(data);
+	}
+	clo_scan_set_data(scan, NULL);
+}
+
+static cl_uint clo_scan_blelloch_get_num_kernels(CloScan* scanner, GError** err) {
+	(void) scanner; (void) err;
+	return CLO_SCAN_BLELLOCH_NUM_KERNELS;
+}
+
+/* ref: clo_scan_blelloch.c:251-279 */
+static const char* clo_scan_blelloch_get_kernel_name(CloScan* scanner, cl_uint i, GError** err) {
+	clo_return_val_if_fail(i < CLO_SCAN_BLELLOCH_NUM_KERNELS, NULL);
+	(void) scanner; (void) err;
+	switch (i) {
+		case 0: return CLO_SCAN_BLELLOCH_KNAME_WGSCAN;
+		case 1: return CLO_SCAN_BLELLOCH_KNAME_WGSUMSSCAN;
+		default: return CLO_SCAN_BLELLOCH_KNAME_ADDWGSUMS;
+	}
+}
+
+/* ref: clo_scan_blelloch.c:286-331. Only "workgroupScan" exists as a HIP
+ * kernel (the other two jobs are done inside it by look-back). */
+static size_t clo_scan_blelloch_get_localmem_usage(CloScan* scanner, cl_uint i, size_t lws_max,
+	size_t numel, GError** err) {
+	clo_return_val_if_fail(i < CLO_SCAN_BLELLOCH_NUM_KERNELS, 0);
+	(void) lws_max; (void) numel; (void) err;
+	if (i != 0) return 0;
+	return clo_hip_kernel_lds_bytes("scan", (int) clo_scan_get_element_size(scanner), (int) clo_scan_get_sum_size(scanner));
+}
+
+/* ref: clo_scan_blelloch.c:335-343 */
+const CloScanImplDef clo_scan_blelloch_def = {
+	"blelloch",
+	clo_scan_blelloch_init,
+	clo_scan_blelloch_finalize,
+	clo_scan_blelloch_scan_with_device_data,
+	clo_scan_blelloch_get_num_kernels,
+	clo_scan_blelloch_get_kernel_name,
+	clo_scan_blelloch_get_localmem_usage
+};

@@ -1,0 +1,400 @@
+/*
+ * clo_sort_abstract.c — the CloSort object and its name->implementation
+ * dispatch. Follows the behaviour of the reference's
+ * src/cl_ops/sort/clo_sort_abstract.c:91-629 (constructor, destructor,
+ * device-data and host-data entry points, getters); the JIT step
+ * (:144-179) is replaced by parsing `compare` / `get_key` into a CloSortKeySpec
+ * that selects ahead-of-time HIP kernels.
+ */
+#include "clo_sort.h"
+#include "clo_internal.h"
+
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct clo_sort {
+	CloSortImplDef impl_def;
+	CCLContext* ctx;
+	CCLProgram* prg;
+	CloType elem_type;
+	CloType key_type;
+	void* data;
+	CloSortKeySpec spec;
+};
+
+/* ------------------------------------------------------------------ */
+/* get_key / compare parsing                                           */
+/* ------------------------------------------------------------------ */
+
+/* f(x) = (x >> shift) & mask */
+typedef struct { int shift; unsigned long long mask; int ok; } keyfn;
+
+typedef struct { const char* p; } cursor;
+
+static void skip_ws(cursor* c) { while (isspace((unsigned char) *c->p)) ++c->p; }
+
+static int accept(cursor* c, const char* tok) {
+	skip_ws(c);
+	size_t n = strlen(tok);
+	if (strncmp(c->p, tok, n) == 0) { c->p += n; return 1; }
+	return 0;
+}
+
+/* A cast "(type)": returns the type size or 0 if the text is not a cast. */
+static int parse_cast(cursor* c) {
+	static const struct { const char* name; int size; } names[] = {
+		{"unsigned long", 8}, {"unsigned int", 4}, {"unsigned short", 2}, {"unsigned char", 1},
+		{"uchar", 1}, {"char", 1}, {"ushort", 2}, {"short", 2}, {"uint", 4}, {"int", 4},
+		{"ulong", 8}, {"long", 8}
+	};
+	cursor save = *c;
+	if (!accept(c, "(")) return 0;
+	skip_ws(c);
+	for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) {
+		size_t n = strlen(names[i].name);
+		if (strncmp(c->p, names[i].name, n) == 0 && !isalnum((unsigned char) c->p[n]) && c->p[n] != '_') {
+			cursor t = *c;
+			t.p += n;
+			if (accept(&t, ")")) { *c = t; return names[i].size; }
+		}
+	}
+	*c = save;
+	return 0;
+}
+
+static int parse_number(cursor* c, unsigned long long* out) {
+	skip_ws(c);
+	if (!isdigit((unsigned char) *c->p)) return 0;
+	char* end = NULL;
+	*out = strtoull(c->p, &end, 0);
+	while (*end == 'u' || *end == 'U' || *end == 'l' || *end == 'L') ++end;
+	c->p = end;
+	return 1;
+}
+
+static keyfn parse_and(cursor* c);
+
+/* primary := cast primary | '(' and ')' | 'x' */
+static keyfn parse_primary(cursor* c) {
+	keyfn f = {0, ~0ull, 0};
+	int cast = parse_cast(c);
+	if (cast) {
+		f = parse_primary(c);
+		if (f.ok && cast < 8) f.mask &= (1ull << (8 * cast)) - 1ull;
+		return f;
+	}
+	if (accept(c, "(")) {
+		f = parse_and(c);
+		if (!accept(c, ")")) f.ok = 0;
+		return f;
+	}
+	skip_ws(c);
+	if (*c->p == 'x' && !isalnum((unsigned char) c->p[1]) && c->p[1] != '_') {
+		++c->p;
+		f.ok = 1;
+	}
+	return f;
+}
+
+/* shift := primary ('>>' number)* */
+static keyfn parse_shift(cursor* c) {
+	keyfn f = parse_primary(c);
+	unsigned long long n;
+	while (f.ok && accept(c, ">>")) {
+		if (!parse_number(c, &n) || n > 63) { f.ok = 0; break; }
+		f.shift += (int) n;
+		f.mask >>= n;
+	}
+	return f;
+}
+
+/* and := shift ('&' number)* */
+static keyfn parse_and(cursor* c) {
+	keyfn f = parse_shift(c);
+	unsigned long long n;
+	while (f.ok && accept(c, "&")) {
+		if (!parse_number(c, &n)) { f.ok = 0; break; }
+		f.mask &= n;
+	}
+	return f;
+}
+
+static int parse_get_key(const char* text, int elem_size, int key_size, int* shift, int* bits) {
+	keyfn f = {0, ~0ull, 1};
+	if (text) {
+		cursor c = { text };
+		f = parse_and(&c);
+		skip_ws(&c);
+		if (*c.p != '\0') f.ok = 0;
+	}
+	if (!f.ok) return 0;
+	/* x has elem_size bytes; the result is converted to the key type. */
+	if (elem_size < 8) {
+		unsigned long long em = (1ull << (8 * elem_size)) - 1ull;
+		f.mask &= f.shift >= 8 * elem_size ? 0ull : (em >> f.shift);
+	} else if (f.shift > 0) {
+		f.mask &= ~0ull >> f.shift;
+	}
+	if (key_size < 8) f.mask &= (1ull << (8 * key_size)) - 1ull;
+	/* only contiguous low masks (2^k - 1) are built */
+	if (f.mask == 0 || (f.mask & (f.mask + 1ull)) != 0ull) return 0;
+	*shift = f.shift;
+	*bits = f.mask == ~0ull ? 64 : (int) clo_ones32((unsigned int) f.mask) + (int) clo_ones32((unsigned int) (f.mask >> 32));
+	return 1;
+}
+
+/* compare: "a > b" (ascending, default) or "a < b" with any parenthesisation. */
+static int parse_compare(const char* text, int* descending) {
+	if (!text) { *descending = 0; return 1; }
+	char buf[64];
+	size_t n = 0;
+	for (const char* p = text; *p; ++p) {
+		if (isspace((unsigned char) *p) || *p == '(' || *p == ')') continue;
+		if (n + 1 >= sizeof(buf)) return 0;
+		buf[n++] = *p;
+	}
+	buf[n] = '\0';
+	if (strcmp(buf, "a>b") == 0) { *descending = 0; return 1; }
+	if (strcmp(buf, "a<b") == 0) { *descending = 1; return 1; }
+	return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* object                                                              */
+/* ------------------------------------------------------------------ */
+
+CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
+	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
+	const char* compiler_opts, GError** err) {
+
+	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
+	clo_return_val_if_fail(ctx != NULL, NULL);
+	clo_return_val_if_fail(elem_type != NULL, NULL);
+
+	/* ref: clo_sort_abstract.c:111-117 (gselect is outside this build). */
+	const CloSortImplDef* impls[] = {
+		&clo_sort_sbitonic_def, &clo_sort_abitonic_def, &clo_sort_satradix_def, NULL
+	};
+
+	CloSort* sorter = NULL;
+	GError* err_internal = NULL;
+
+	for (unsigned i = 0; impls[i] != NULL; ++i) {
+		if (type == NULL || strcmp(type, impls[i]->name) != 0) continue;
+
+		sorter = (CloSort*) calloc(1, sizeof(CloSort));
+		if (!sorter) break;
+		sorter->impl_def = *impls[i];
+		ccl_context_ref(ctx);
+		sorter->ctx = ctx;
+		sorter->elem_type = *elem_type;
+		sorter->key_type = key_type ? *key_type : *elem_type;
+
+		/* what upstream expresses as CLO_SORT_ELEM_TYPE / KEY_TYPE / COMPARE /
+		 * KEY_GET macros (:144-168) */
+		CloSortKeySpec* ks = &sorter->spec;
+		ks->elem_size = (int) clo_type_sizeof(sorter->elem_type);
+		ks->key_size = (int) clo_type_sizeof(sorter->key_type);
+		ks->key_kind = clo_type_is_float(sorter->key_type) ? 2 : (clo_type_is_signed(sorter->key_type) ? 1 : 0);
+		if (ks->elem_size == 0 || ks->key_size == 0) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_UNKNOWN_TYPE, "Unknown element or key type");
+			goto error_handler;
+		}
+		if (sorter->elem_type == CLO_HALF || sorter->key_type == CLO_HALF) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Type 'half' is not supported by the HIP build");
+			goto error_handler;
+		}
+		if (!parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
+				"Unsupported get_key expression '%s' (supported: x, shifts, low-bit masks, integer casts)",
+				get_key ? get_key : "(x)");
+			goto error_handler;
+		}
+		if (ks->key_kind == 2 && (ks->key_shift != 0 || ks->key_bits != 8 * ks->key_size || ks->elem_size != ks->key_size)) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Floating point keys must be the whole element");
+			goto error_handler;
+		}
+		if (!parse_compare(compare, &ks->descending)) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
+				"Unsupported compare expression '%s' (supported: ((a) > (b)), ((a) < (b)))", compare);
+			goto error_handler;
+		}
+
+		const char* token = sorter->impl_def.init(sorter, options, &err_internal);
+		if (err_internal) { clo_gerror_propagate(err, err_internal); goto error_handler; }
+		if (!token) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "Sort implementation '%s' failed to initialise", type);
+			goto error_handler;
+		}
+		/* No JIT: the "program" is a token naming the ahead-of-time kernels. */
+		sorter->prg = ccl_program_new_token(ctx, token, compiler_opts);
+		break;
+	}
+
+	if (sorter == NULL) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_IMPL_NOT_FOUND,
+			"The requested sort implementation, '%s', was not found.", type ? type : "(null)");
+	}
+	return sorter;
+
+error_handler:
+	if (sorter) {
+		/* finalize only what init created */
+		if (sorter->data) sorter->impl_def.finalize(sorter);
+		ccl_context_unref(sorter->ctx);
+		ccl_program_destroy(sorter->prg);
+		free(sorter);
+	}
+	return NULL;
+}
+
+void clo_sort_destroy(CloSort* sorter) {
+	clo_return_if_fail(sorter != NULL);
+	sorter->impl_def.finalize(sorter);
+	if (sorter->ctx) ccl_context_unref(sorter->ctx);
+	if (sorter->prg) ccl_program_destroy(sorter->prg);
+	free(sorter);
+}
+
+CCLEvent* clo_sort_with_device_data(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm,
+	CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max, GError** err) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
+	clo_return_val_if_fail(cq_exec != NULL, NULL);
+	return sorter->impl_def.sort_with_device_data(sorter, cq_exec, cq_comm, data_in, data_out, numel, lws_max, err);
+}
+
+/* ref: clo_sort_abstract.c:296-418 — buffers, blocking H2D on cq_comm, sort on
+ * cq_exec, blocking D2H of the result. */
+cl_bool clo_sort_with_host_data(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm,
+	void* data_in, void* data_out, size_t numel, size_t lws_max, GError** err) {
+
+	clo_return_val_if_fail(sorter != NULL, CL_FALSE);
+	clo_return_val_if_fail(err == NULL || *err == NULL, CL_FALSE);
+
+	cl_bool status = CL_FALSE;
+	CCLBuffer* data_in_dev = NULL;
+	CCLBuffer* data_aux_dev = NULL;
+	CCLBuffer* data_out_dev = NULL;
+	CCLBuffer* data_read_dev = NULL;
+	CCLQueue* intern_queue = NULL;
+	CCLEvent* evt = NULL;
+	CCLEventWaitList ewl = NULL;
+	GError* err_internal = NULL;
+	const size_t data_size = numel * clo_type_sizeof(sorter->elem_type);
+	CCLContext* ctx = sorter->ctx;
+
+	if (cq_exec == NULL) {
+		CCLDevice* dev = ccl_context_get_device(ctx, 0, &err_internal);
+		if (err_internal) goto error_handler;
+		intern_queue = ccl_queue_new(ctx, dev, 0, &err_internal);
+		if (err_internal) goto error_handler;
+		cq_exec = intern_queue;
+	}
+	if (cq_comm == NULL) cq_comm = cq_exec;
+
+	data_in_dev = ccl_buffer_new(ctx, CL_MEM_READ_ONLY, data_size, NULL, &err_internal);
+	if (err_internal) goto error_handler;
+	if (!sorter->impl_def.in_place) {
+		data_aux_dev = ccl_buffer_new(ctx, CL_MEM_WRITE_ONLY, data_size, NULL, &err_internal);
+		if (err_internal) goto error_handler;
+		data_out_dev = data_aux_dev;
+		data_read_dev = data_aux_dev;
+	} else {
+		data_read_dev = data_in_dev;
+	}
+
+	evt = ccl_buffer_enqueue_write(data_in_dev, cq_comm, CL_FALSE, 0, data_size, data_in, NULL, &err_internal);
+	if (err_internal) goto error_handler;
+	ccl_event_set_name(evt, "clo_sort_write");
+	ccl_event_wait(ccl_ewl(&ewl, evt, NULL), &err_internal);
+	if (err_internal) goto error_handler;
+
+	evt = sorter->impl_def.sort_with_device_data(sorter, cq_exec, cq_comm, data_in_dev, data_out_dev,
+		numel, lws_max, &err_internal);
+	if (err_internal) goto error_handler;
+
+	evt = ccl_buffer_enqueue_read(data_read_dev, cq_comm, CL_FALSE, 0, data_size, data_out,
+		evt ? ccl_ewl(&ewl, evt, NULL) : NULL, &err_internal);
+	if (err_internal) goto error_handler;
+	ccl_event_set_name(evt, "clo_sort_read");
+	ccl_event_wait(ccl_ewl(&ewl, evt, NULL), &err_internal);
+	if (err_internal) goto error_handler;
+
+	status = CL_TRUE;
+	goto finish;
+
+error_handler:
+	clo_gerror_propagate(err, err_internal);
+	status = CL_FALSE;
+
+finish:
+	ccl_event_wait_list_clear(&ewl);
+	if (data_in_dev) ccl_buffer_destroy(data_in_dev);
+	if (data_aux_dev) ccl_buffer_destroy(data_aux_dev);
+	if (intern_queue) ccl_queue_destroy(intern_queue);
+	return status;
+}
+
+/* ---- getters, ref: clo_sort_abstract.c:428-629 ---- */
+
+CCLContext* clo_sort_get_context(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	return sorter->ctx;
+}
+
+CCLProgram* clo_sort_get_program(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	return sorter->prg;
+}
+
+CloType clo_sort_get_element_type(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, (CloType) -1);
+	return sorter->elem_type;
+}
+
+size_t clo_sort_get_element_size(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, 0);
+	return clo_type_sizeof(sorter->elem_type);
+}
+
+CloType clo_sort_get_key_type(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, (CloType) -1);
+	return sorter->key_type;
+}
+
+size_t clo_sort_get_key_size(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, 0);
+	return clo_type_sizeof(sorter->key_type);
+}
+
+void* clo_sort_get_data(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	return sorter->data;
+}
+
+void clo_sort_set_data(CloSort* sorter, void* data) {
+	clo_return_if_fail(sorter != NULL);
+	sorter->data = data;
+}
+
+cl_uint clo_sort_get_num_kernels(CloSort* sorter, GError** err) {
+	clo_return_val_if_fail(sorter != NULL, 0);
+	return sorter->impl_def.get_num_kernels(sorter, err);
+}
+
+const char* clo_sort_get_kernel_name(CloSort* sorter, cl_uint i, GError** err) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	return sorter->impl_def.get_kernel_name(sorter, i, err);
+}
+
+size_t clo_sort_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max, size_t numel, GError** err) {
+	clo_return_val_if_fail(sorter != NULL, 0);
+	return sorter->impl_def.get_localmem_usage(sorter, i, lws_max, numel, err);
+}
+
+const CloSortKeySpec* clo_sort_get_key_spec(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	return &sorter->spec;
+}

@@ -1,0 +1,82 @@
+/*
+ * clo_sort_bitonic_common.c — what the two bitonic drivers share: buffer
+ * choice (in place / copy first, as src/cl_ops/sort/clo_sort_sbitonic.c:83-97
+ * and clo_sort_abitonic.c:359-375 upstream), power-of-two padding, and the call
+ * into the C-ABI (clo_hip_bitonic_simple / clo_hip_bitonic_tiled).
+ */
+#include "clo_sort_bitonic_common.h"
+
+CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, const char* evt_name,
+	const char* copy_evt_name, CCLQueue* cq_exec, CCLQueue* cq_comm, CCLBuffer* data_in,
+	CCLBuffer* data_out, size_t numel, GError** err) {
+
+	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
+	clo_return_val_if_fail(cq_exec != NULL, NULL);
+	clo_return_val_if_fail(data_in != NULL, NULL);
+
+	const CloSortKeySpec* ks = clo_sort_get_key_spec(sorter);
+	const size_t bytes = numel * (size_t) ks->elem_size;
+	void* stream = ccl_queue_get_stream(cq_exec);
+	CCLEventWaitList ewl = NULL;
+	CCLEvent* evt = NULL;
+
+	if (cq_comm == NULL) cq_comm = cq_exec;
+	if (bytes > ccl_buffer_get_size(data_in) || (data_out && bytes > ccl_buffer_get_size(data_out))) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "numel (%zu) exceeds the size of the device buffers", numel);
+		return NULL;
+	}
+	if (numel > 0x80000000ull) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "numel must not exceed 2^31");
+		return NULL;
+	}
+
+	/* Sort in data_out after copying data_in into it, or directly in data_in
+	 * (ref: clo_sort_sbitonic.c:83-97). The copy travels on cq_comm and the
+	 * kernels wait for it. */
+	CCLBuffer* target = data_in;
+	if (data_out != NULL && data_out != data_in) {
+		evt = ccl_buffer_enqueue_copy(data_in, data_out, cq_comm, 0, 0, bytes, NULL, err);
+		if (!evt) return NULL;
+		ccl_event_set_name(evt, copy_evt_name);
+		ccl_event_wait_list_add(&ewl, evt, NULL);
+		target = data_out;
+	}
+	if (!ccl_queue_wait_for(cq_exec, &ewl, err)) { ccl_event_wait_list_clear(&ewl); return NULL; }
+	ccl_event_wait_list_clear(&ewl);
+
+	evt = ccl_queue_begin_command(cq_exec, evt_name, err);
+	if (!evt) return NULL;
+
+	if (numel > 1) {
+		const size_t padded = clo_hip_bitonic_padded_numel(numel);
+		void* work = ccl_buffer_get_device_ptr(target);
+		int use_pad = 0;
+		if (padded != numel) {
+			/* Upstream handles powers of two only (its kernels have no bounds).
+			 * Padding is safe when ties are invisible, i.e. identity keys. */
+			if (ks->key_shift != 0 || ks->key_bits != 8 * ks->elem_size) {
+				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
+					"bitonic sorts of a non-power-of-two numel need the key to be the whole element");
+				return NULL;
+			}
+			if (state->last_stream && state->last_stream != stream)
+				if (clo_hip_failed(clo_hip_stream_synchronize(state->last_stream), err, "hipStreamSynchronize")) return NULL;
+			state->last_stream = stream;
+			if (clo_hip_failed(clo_devbuf_reserve(&state->padded, padded * (size_t) ks->elem_size), err, "hipMalloc(bitonic pad)")) return NULL;
+			if (clo_hip_failed(clo_hip_memcpy_d2d_async(state->padded.ptr, work, bytes, stream), err, "hipMemcpyAsync")) return NULL;
+			work = state->padded.ptr;
+			use_pad = 1;
+		}
+		int launches = 0;
+		int st = tiled
+			? clo_hip_bitonic_tiled(work, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, &launches, stream)
+			: clo_hip_bitonic_simple(work, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, &launches, stream);
+		if (clo_hip_failed(st, err, tiled ? "clo_hip_bitonic_tiled" : "clo_hip_bitonic_simple")) return NULL;
+		clo_debug("%s: numel=%zu padded=%zu launches=%d", evt_name, numel, padded, launches);
+		if (use_pad)
+			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) return NULL;
+	}
+
+	if (!ccl_queue_end_command(cq_exec, evt, err)) return NULL;
+	return evt;
+}

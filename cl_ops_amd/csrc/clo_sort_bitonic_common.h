@@ -1,0 +1,20 @@
+/* clo_sort_bitonic_common.h — shared by the sbitonic and abitonic drivers. */
+#ifndef CLO_SORT_BITONIC_COMMON_H
+#define CLO_SORT_BITONIC_COMMON_H
+
+#include "clo_sort.h"
+#include "clo_internal.h"
+
+typedef struct {
+	clo_devbuf padded;   /* used only when numel is not a power of two */
+	void* last_stream;
+} clo_bitonic_state;
+
+/* Runs one of the two HIP schedules on (data_in -> data_out | in place).
+ * tiled = 0: one launch per step (sbitonic); 1: LDS/register tiles (abitonic).
+ * Returns the event closing the command, or NULL with *err set. */
+CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, const char* evt_name,
+	const char* copy_evt_name, CCLQueue* cq_exec, CCLQueue* cq_comm, CCLBuffer* data_in,
+	CCLBuffer* data_out, size_t numel, GError** err);
+
+#endif

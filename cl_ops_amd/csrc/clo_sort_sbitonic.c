@@ -1,0 +1,64 @@
+/*
+ * clo_sort_sbitonic.c — host driver of the "sbitonic" sorter over HIP.
+ * Mirrors src/cl_ops/sort/clo_sort_sbitonic.c:31-233 of the reference: no
+ * options, one kernel ("sbitonic"), no local memory, in place, one launch per
+ * (stage, step) (:102-118) — done by clo_hip_bitonic_simple.
+ */
+#include "clo_sort_bitonic_common.h"
+
+static CCLEvent* clo_sort_sbitonic_sort_with_device_data(CloSort* sorter, CCLQueue* cq_exec,
+	CCLQueue* cq_comm, CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max,
+	GError** err) {
+	(void) lws_max;
+	return clo_bitonic_run(sorter, (clo_bitonic_state*) clo_sort_get_data(sorter), 0,
+		"sbitonic_ndrange", "sbitonic_copy", cq_exec, cq_comm, data_in, data_out, numel, err);
+}
+
+/* ref: clo_sort_sbitonic.c:140-155 — options are ignored. */
+static const char* clo_sort_sbitonic_init(CloSort* sorter, const char* options, GError** err) {
+	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
+	(void) options;
+	clo_bitonic_state* state = (clo_bitonic_state*) calloc(1, sizeof(*state));
+	if (!state) return NULL;
+	clo_sort_set_data(sorter, state);
+	return "sbitonic:hip";
+}
+
+static void clo_sort_sbitonic_finalize(CloSort* sorter) {
+	clo_bitonic_state* state = (clo_bitonic_state*) clo_sort_get_data(sorter);
+	if (state) {
+		clo_devbuf_release(&state->padded);
+		free(state);
+	}
+	clo_sort_set_data(sorter, NULL);
+}
+
+static cl_uint clo_sort_sbitonic_get_num_kernels(CloSort* sorter, GError** err) {
+	(void) sorter; (void) err;
+	return 1;
+}
+
+static const char* clo_sort_sbitonic_get_kernel_name(CloSort* sorter, cl_uint i, GError** err) {
+	clo_return_val_if_fail(i == 0, NULL);
+	(void) sorter; (void) err;
+	return CLO_SORT_SBITONIC_KNAME;
+}
+
+static size_t clo_sort_sbitonic_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max,
+	size_t numel, GError** err) {
+	clo_return_val_if_fail(i == 0, 0);
+	(void) sorter; (void) lws_max; (void) numel; (void) err;
+	return 0;
+}
+
+/* ref: clo_sort_sbitonic.c:224-233 */
+const CloSortImplDef clo_sort_sbitonic_def = {
+	"sbitonic",
+	CL_TRUE,
+	clo_sort_sbitonic_init,
+	clo_sort_sbitonic_finalize,
+	clo_sort_sbitonic_sort_with_device_data,
+	clo_sort_sbitonic_get_num_kernels,
+	clo_sort_sbitonic_get_kernel_name,
+	clo_sort_sbitonic_get_localmem_usage
+};

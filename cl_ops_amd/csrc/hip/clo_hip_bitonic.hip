@@ -1,0 +1,360 @@
+// clo_hip_bitonic.hip — bitonic sorting networks for gfx950 ("sbitonic" and
+// "abitonic" replacements).
+//
+// The network is the reference's: stage S = 1..T, step p = S..1, pair (i1,i2)
+// with i2 = i1 + 2^(p-1), direction bit dir = (i1 >> S) & 1, and
+//     swap <=> COMPARE(key[i1], key[i2]) XOR dir
+// (sort/clo_sort_sbitonic.cl:45-67, sort/clo_sort_abitonic.cl:31-38,585-601;
+// dir is the reference's (gid >> (stage-1)) & 1 expressed on the element index).
+// Layers are applied in the same order with the same rule, so the result is
+// bit-identical to the reference for any schedule, ties included.
+//
+// Schedules:
+//  * clo_hip_bitonic_simple — one launch per (stage, step), global memory only:
+//    what sort/clo_sort_sbitonic.c:102-118 does.
+//  * clo_hip_bitonic_tiled  — replaces the 26-kernel strategy of
+//    sort/clo_sort_abitonic.c:58-313. Two kernels:
+//      - bitonic_tile: a work-group owns 2^KL consecutive elements in LDS and
+//        runs every step p <= KL of a stage (or all of stages 1..KL) there.
+//        Each thread keeps 2^Q elements in VGPRs and runs up to Q consecutive
+//        steps on them between two LDS exchanges; the LDS image is padded by
+//        one slot per 32 so that every exchange pattern is bank-conflict free.
+//      - bitonic_strided: steps p > KL; each thread loads 2^NS elements
+//        2^(p-NS) apart (adjacent lanes = adjacent addresses, so every access
+//        is a full coalesced row), runs NS steps in VGPRs, stores them back.
+//    For 2^26 keys that is 38 passes over the array instead of the reference's
+//    58-62.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+namespace {
+
+struct key_desc {
+	unsigned shift;
+	unsigned kind;        // 0 unsigned, 1 signed, 2 float
+	unsigned descending;  // CLO_SORT_COMPARE "((a) < (b))"
+	unsigned long long mask, signbit;
+};
+
+// Key as an unsigned integer whose order is the typed order of the key.
+template <typename E>
+__device__ __forceinline__ unsigned long long okey(E e, const key_desc& kd) {
+	unsigned long long k = ((unsigned long long) e >> kd.shift) & kd.mask;
+	if (kd.kind == 1) k ^= kd.signbit;
+	else if (kd.kind == 2) k = (k & kd.signbit) ? (~k & kd.mask) : (k | kd.signbit);
+	return k;
+}
+
+// Compare-exchange with the reference's rule (abitonic.cl:31-38).
+template <typename E>
+__device__ __forceinline__ void cmpxch(E& a, E& b, unsigned dir, const key_desc& kd) {
+	const unsigned long long ka = okey<E>(a, kd), kb = okey<E>(b, kd);
+	const bool cmp = kd.descending ? (ka < kb) : (ka > kb);
+	if (cmp != (bool) dir) { const E t = a; a = b; b = t; }
+}
+
+// Up to log2(V) steps on the V values of one thread: strides 2^(nsteps-1) .. 1
+// (the register networks of abitonic.cl:163-224, any size). Value j sits at
+// element index idx0 | (j << b0); its direction bit is bit S of that index.
+template <typename E, int V>
+__device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, unsigned b0, unsigned S,
+	const key_desc& kd) {
+	const unsigned dbase = (unsigned) ((idx0 >> S) & 1);
+	// non-zero iff the direction bit is one of this thread's register bits
+	const unsigned dsel = (S >= b0 && S - b0 < 31u) ? ((1u << (S - b0)) & (unsigned) (V - 1)) : 0u;
+	#pragma unroll
+	for (int half = V / 2; half >= 1; half /= 2) {
+		if (half < (1 << nsteps)) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j)
+				if ((j & half) == 0) {
+					const unsigned dir = dsel ? (((unsigned) j & dsel) ? 1u : 0u) : dbase;
+					cmpxch<E>(v[j], v[j + half], dir, kd);
+				}
+		}
+	}
+}
+
+// ---- one launch per step (sbitonic.cl:38-69 / abit_any) ----
+template <typename E>
+__global__ __launch_bounds__(256)
+void clo_bitonic_step_kernel(E* __restrict__ data, size_t npairs, unsigned stage, unsigned step, key_desc kd) {
+	const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (gid >= npairs) return;
+	const unsigned sh = step - 1;
+	const size_t i1 = ((gid >> sh) << (sh + 1)) | (gid & (((size_t) 1 << sh) - 1));
+	const size_t i2 = i1 + ((size_t) 1 << sh);
+	E a = data[i1], b = data[i2];
+	const E a0 = a, b0 = b;
+	cmpxch<E>(a, b, (unsigned) ((i1 >> stage) & 1), kd);
+	if (a != a0 || b != b0) { data[i1] = a; data[i2] = b; }
+}
+
+// ---- strided register kernel: steps p .. p-NS+1 of stage S, p-NS >= 6 ----
+template <typename E, int NS>
+__global__ __launch_bounds__(256)
+void clo_bitonic_strided_kernel(E* __restrict__ data, size_t n, unsigned stage, unsigned p, key_desc kd) {
+	constexpr int V = 1 << NS;
+	const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (t >= (n >> NS)) return;
+	const unsigned b0 = p - NS;  // lowest index bit handled in registers
+	const size_t base = ((t >> b0) << (b0 + NS)) | (t & (((size_t) 1 << b0) - 1));
+	E v[V];
+	#pragma unroll
+	for (int j = 0; j < V; ++j) v[j] = data[base + ((size_t) j << b0)];
+	reg_network<E, V>(v, NS, base, b0, stage, kd);
+	#pragma unroll
+	for (int j = 0; j < V; ++j) data[base + ((size_t) j << b0)] = v[j];
+}
+
+// ---- LDS tile kernel ----
+// Q register bits, 256 threads, tile = 2^(8+Q) elements max; kl = log2 of the
+// tile actually used (Q <= kl <= 8+Q). mode 0: run steps p_hi..1 of `stage`;
+// mode 1: run all of stages 1..stage (stage <= kl).
+template <typename E, int Q>
+__global__ __launch_bounds__(256)
+void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, int mode, key_desc kd) {
+	constexpr int V = 1 << Q;
+	constexpr int TILE_MAX = 256 * V;
+	__shared__ E s[TILE_MAX + TILE_MAX / 32];
+
+	const unsigned tid = threadIdx.x;
+	const unsigned tile = 1u << kl;
+	const unsigned nthr = tile >> Q;  // active threads
+	const size_t gbase = (size_t) blockIdx.x << kl;
+	auto phys = [](unsigned i) { return i + (i >> 5); };
+
+	// global -> LDS, coalesced
+	for (unsigned i = tid; i < tile; i += 256) s[phys(i)] = data[gbase + i];
+	__syncthreads();
+
+	// The thread's V values stay in VGPRs across consecutive step groups that
+	// use the same register bits (all of stages 1..Q, for one).
+	E v[V];
+	int cur_b0 = -1;
+	unsigned base = 0;
+	const unsigned s_first = mode ? 1u : stage;
+	for (unsigned S = s_first; S <= stage; ++S) {
+		unsigned p = mode ? S : p_hi;
+		while (p >= 1) {
+			// register bits [b0, b0+Q) of the tile index; steps p .. b0+1
+			const unsigned b0 = p > (unsigned) Q ? p - Q : 0u;
+			const int nsteps = (int) (p - b0);
+			if (cur_b0 != (int) b0) {
+				if (cur_b0 >= 0) {
+					if (tid < nthr) {
+						#pragma unroll
+						for (int j = 0; j < V; ++j) s[phys(base + ((unsigned) j << cur_b0))] = v[j];
+					}
+					__syncthreads();
+				}
+				base = ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u));
+				if (tid < nthr) {
+					#pragma unroll
+					for (int j = 0; j < V; ++j) v[j] = s[phys(base + ((unsigned) j << b0))];
+				}
+				cur_b0 = (int) b0;
+			}
+			if (tid < nthr) reg_network<E, V>(v, nsteps, gbase + base, b0, S, kd);
+			p = b0;
+		}
+	}
+	if (cur_b0 >= 0) {
+		if (tid < nthr) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j) s[phys(base + ((unsigned) j << cur_b0))] = v[j];
+		}
+	}
+	__syncthreads();
+
+	for (unsigned i = tid; i < tile; i += 256) data[gbase + i] = s[phys(i)];
+}
+
+// ---- pad the tail [numel, padded) with elements that sort last ----
+template <typename E>
+__global__ void clo_bitonic_pad_kernel(E* data, size_t numel, size_t padded, E pad) {
+	const size_t i = numel + (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (i < padded) data[i] = pad;
+}
+
+size_t nlpo2(size_t x) {
+	size_t p = 1;
+	while (p < x) p <<= 1;
+	return p;
+}
+
+unsigned log2u(size_t x) {
+	unsigned l = 0;
+	while (((size_t) 1 << l) < x) ++l;
+	return l;
+}
+
+template <typename E>
+int make_desc(int key_shift, int key_bits, int key_size, int key_kind, int descending, key_desc* kd, E* pad) {
+	if (key_size != 1 && key_size != 2 && key_size != 4 && key_size != 8) return CLO_HIP_EARGS;
+	if (key_bits < 1 || key_bits > 8 * key_size) return CLO_HIP_EARGS;
+	if (key_shift < 0 || key_shift + key_bits > 8 * (int) sizeof(E)) return CLO_HIP_EARGS;
+	if (key_kind < 0 || key_kind > 2) return CLO_HIP_EARGS;
+	if (key_kind == 2 && ((key_size != 4 && key_size != 8) || key_bits != 8 * key_size)) return CLO_HIP_EUNSUPPORTED;
+	kd->shift = (unsigned) key_shift;
+	kd->kind = (unsigned) key_kind;
+	kd->descending = descending ? 1u : 0u;
+	kd->mask = key_bits == 64 ? ~0ull : ((1ull << key_bits) - 1ull);
+	kd->signbit = 1ull << (8 * key_size - 1);
+	if (key_kind == 1 && key_bits < 8 * key_size) kd->kind = 0;  // sign bit masked off: plain unsigned order
+	// Element whose key is the last one in the requested order.
+	unsigned long long last_ordered = descending ? 0ull : kd->mask;  // in okey space
+	unsigned long long k = last_ordered;
+	if (key_kind == 1) k ^= kd->signbit;
+	else if (key_kind == 2) k = (k & kd->signbit) ? (k & ~kd->signbit) : (~k & kd->mask);
+	// all other bits of the element: ones (any value would do)
+	unsigned long long e = ~0ull;
+	e &= ~(kd->mask << key_shift);
+	e |= (k & kd->mask) << key_shift;
+	*pad = (E) e;
+	return 0;
+}
+
+template <typename E>
+int pad_tail(E* data, size_t numel, size_t padded, E pad, hipStream_t s) {
+	if (padded > numel) {
+		const size_t cnt = padded - numel;
+		hipLaunchKernelGGL((clo_bitonic_pad_kernel<E>), dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s,
+			data, numel, padded, pad);
+	}
+	return 0;
+}
+
+template <typename E>
+int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, hipStream_t s) {
+	E* data = (E*) vdata;
+	key_desc kd; E pad;
+	int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
+	if (st) return st;
+	const size_t n = nlpo2(numel);
+	const unsigned T = log2u(n);
+	pad_tail<E>(data, numel, n, pad, s);
+	int count = 0;
+	const size_t npairs = n / 2;
+	const unsigned blocks = (unsigned) ((npairs + 255) / 256);
+	for (unsigned stage = 1; stage <= T; ++stage)
+		for (unsigned step = stage; step >= 1; --step) {
+			hipLaunchKernelGGL((clo_bitonic_step_kernel<E>), dim3(blocks), dim3(256), 0, s, data, npairs, stage, step, kd);
+			++count;
+		}
+	if (launches) *launches = count;
+	return (int) hipGetLastError();
+}
+
+template <typename E, int NS>
+void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_desc& kd, hipStream_t s) {
+	const size_t threads = n >> NS;
+	hipLaunchKernelGGL((clo_bitonic_strided_kernel<E, NS>), dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, s,
+		data, n, stage, p, kd);
+}
+
+template <typename E>
+int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, hipStream_t s) {
+	// register bits per thread: 32 values of <= 4 bytes, 16 values of 8 bytes
+	constexpr int Q = sizeof(E) == 8 ? 4 : 5;
+	constexpr unsigned KL_MAX = 8 + Q;
+	// strided passes need p - NS >= 6 so that a wave's 64 lanes read one
+	// contiguous row; KL_MAX >= 12 guarantees it for every p > KL_MAX.
+	E* data = (E*) vdata;
+	key_desc kd; E pad;
+	int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
+	if (st) return st;
+	const size_t n = nlpo2(numel);
+	const unsigned T = log2u(n);
+	if (T < (unsigned) Q) return simple_impl<E>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+	pad_tail<E>(data, numel, n, pad, s);
+	const unsigned kl = T < KL_MAX ? T : KL_MAX;
+	const unsigned tiles = (unsigned) (n >> kl);
+	int count = 0;
+	// stages 1..kl inside the tiles
+	hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
+	++count;
+	for (unsigned stage = kl + 1; stage <= T; ++stage) {
+		unsigned p = stage;
+		while (p > kl) {
+			unsigned ns = p - kl;
+			if (ns > (unsigned) Q) ns = Q;
+			switch (ns) {
+				case 1: launch_strided<E, 1>(data, n, stage, p, kd, s); break;
+				case 2: launch_strided<E, 2>(data, n, stage, p, kd, s); break;
+				case 3: launch_strided<E, 3>(data, n, stage, p, kd, s); break;
+				case 4: launch_strided<E, 4>(data, n, stage, p, kd, s); break;
+				default:
+					if constexpr (Q >= 5) launch_strided<E, 5>(data, n, stage, p, kd, s);
+					break;
+			}
+			++count;
+			p -= ns;
+		}
+		hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, stage, kl, 0, kd);
+		++count;
+	}
+	if (launches) *launches = count;
+	return (int) hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t clo_hip_bitonic_padded_numel(size_t numel) { return nlpo2(numel ? numel : 1); }
+
+int clo_hip_bitonic_simple(void* data, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, void* stream) {
+	if (launches) *launches = 0;
+	if (numel <= 1) return 0;
+	if (!data) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	switch (elem_size) {
+		case 1: return simple_impl<uint8_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 2: return simple_impl<uint16_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 4: return simple_impl<uint32_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 8: return simple_impl<uint64_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, void* stream) {
+	if (launches) *launches = 0;
+	if (numel <= 1) return 0;
+	if (!data) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	switch (elem_size) {
+		case 1: return tiled_impl<uint8_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 2: return tiled_impl<uint16_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 4: return tiled_impl<uint32_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 8: return tiled_impl<uint64_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
+	if (!family) return 0;
+	const std::string f(family);
+	if (f == "bitonic_tile") {
+		const size_t v = elem_size == 8 ? 16 : 32;
+		return (256 * v + 256 * v / 32) * (size_t) elem_size;
+	}
+	if (f == "radix_hist") return 4 * 256 * sizeof(unsigned);
+	if (f == "radix_pass") {
+		const size_t R = (size_t) 1 << (param < 1 ? 1 : (param > 8 ? 8 : param));
+		const size_t tile = 512u * (elem_size == 8 ? 8 : 16);
+		return tile * (size_t) elem_size + (2 * 8 * R + 2 * R + 5) * sizeof(unsigned);
+	}
+	if (f == "scan") return ((param > 4 ? 8 : 16) * 4 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;
+	return 0;  // bitonic_strided, bitonic_step: registers only
+}
+
+}  // extern "C"

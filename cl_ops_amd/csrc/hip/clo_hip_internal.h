@@ -1,0 +1,79 @@
+// clo_hip_internal.h — shared device-side helpers for the HIP kernels
+// (not part of the C-ABI). gfx950 / wave64 only.
+#ifndef CLO_HIP_INTERNAL_H
+#define CLO_HIP_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+// ---- workspace header (first CLO_WS_HEADER_BYTES of every workspace) ----
+// word 0: status (non-zero = a bounded spin gave up)
+// words 16..79: work-queue tickets, one per pass
+#define CLO_WS_STATUS_OFFSET 0
+#define CLO_WS_TICKET_WORD   16
+#define CLO_WS_MAX_PASSES    64
+#define CLO_WS_HEADER_BYTES  512
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+
+typedef unsigned long long clo_u64;
+
+// Look-back granule: one naturally aligned 8-byte word written by ONE store:
+//   bits 63..34 epoch (pass + 1; 0 = never written this call)
+//   bits 33..32 state (1 = tile aggregate, 2 = inclusive prefix)
+//   bits 31..0  value
+// The data is the flag (cdna_hip_programming.md G16 R2): relaxed agent-scope
+// (sc1) store on the producer, relaxed agent-scope load polls on the consumer,
+// no fences, no separate flag word.
+#define CLO_LB_AGG    1u
+#define CLO_LB_PREFIX 2u
+
+__device__ __forceinline__ clo_u64 clo_lb_pack(unsigned epoch, unsigned state, unsigned value) {
+	return ((clo_u64) ((epoch << 2) | state) << 32) | value;
+}
+__device__ __forceinline__ unsigned clo_lb_tag(clo_u64 g) { return (unsigned) (g >> 32); }
+__device__ __forceinline__ unsigned clo_lb_val(clo_u64 g) { return (unsigned) g; }
+
+__device__ __forceinline__ clo_u64 clo_ld_agent(const clo_u64* p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void clo_st_agent(clo_u64* p, clo_u64 v) {
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every poll loop is bounded: after this many failed polls the wave records
+// the failure in the workspace status word and carries on (wrong output, but
+// the grid drains). ~1 us per poll under load => seconds before giving up.
+#define CLO_MAX_SPINS (1u << 22)
+
+__device__ __forceinline__ unsigned clo_lane_id() {
+	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Number of set bits of `mask` strictly below the calling lane.
+__device__ __forceinline__ unsigned clo_mbcnt(clo_u64 mask) {
+	return __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32),
+		__builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
+}
+
+template <typename T>
+__device__ __forceinline__ T clo_wave_reduce_sum(T x) {
+	#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+	return x;
+}
+
+// Inclusive scan across the 64 lanes of a wave.
+template <typename T>
+__device__ __forceinline__ T clo_wave_scan_inclusive(T x, unsigned lane) {
+	#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		T y = __shfl_up(x, off, 64);
+		if (lane >= (unsigned) off) x += y;
+	}
+	return x;
+}
+
+#endif  // __HIPCC__
+#endif

@@ -1,0 +1,531 @@
+// clo_hip_radix.hip — stable LSD radix sort for gfx950 ("satradix" replacement).
+//
+// Upstream, every digit pass is four launches over four buffers
+// (sort/clo_sort_satradix.c:264-313): satradix_localsort (b one-bit splits, each a
+// full LDS Blelloch scan over the tile), satradix_histogram, a 3-kernel scan of
+// num_wgs*radix counters, satradix_scatter (sort/clo_sort_satradix.cl:34-258) —
+// about 5 element streams plus 6 counter streams through HBM per digit.
+//
+// Here a digit pass is ONE kernel that reads every element once and writes it
+// once (chained-scan "onesweep" structure):
+//   1. a work-group draws a ticket = tile id, loads its tile wave-striped
+//      (lane l of wave w holds element w*64*ITEMS + i*64 + l of the tile);
+//   2. ranks each element among equal digits of the tile, stably: per item one
+//      __ballot per digit bit gives the lanes holding the same digit (match-any),
+//      v_mbcnt gives the rank inside the wave item, a per-wave LDS counter row
+//      carries the count across items; a small cross-wave pass makes the tile
+//      histogram and per-wave offsets (this is the job of upstream's localsort +
+//      histogram kernels, with no one-bit split loop and no barriers inside it);
+//   3. publishes the tile histogram and resolves its global offsets per digit
+//      by decoupled look-back over earlier tiles (8-byte {tag,count} granules,
+//      agent-scope relaxed accesses) — upstream's counters scan;
+//   4. scatters the tile into digit order through an LDS stage so that HBM
+//      writes are contiguous runs per digit (upstream's scatter kernel);
+//   5. while the keys are in registers, counts the NEXT pass's digit so no
+//      separate histogram read is needed except before the first pass.
+// Stability per pass + LSD order give exactly the order the reference produces
+// (stable ascending by key), for any digit width.
+#include <hip/hip_runtime.h>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// first-pass digit histogram
+// ---------------------------------------------------------------------------
+
+constexpr int HIST_THREADS = 256;
+constexpr int HIST_ITEMS = 16;  // elements per thread per block-iteration
+
+template <typename E>
+__global__ __launch_bounds__(HIST_THREADS)
+void clo_radix_hist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
+	unsigned* __restrict__ ghist32, unsigned long long* __restrict__ ghist64) {
+
+	__shared__ unsigned h[HIST_THREADS / 64][256];
+	const unsigned tid = threadIdx.x, wave = tid >> 6;
+	for (unsigned i = tid; i < (HIST_THREADS / 64) * 256; i += HIST_THREADS) (&h[0][0])[i] = 0;
+	__syncthreads();
+
+	const size_t chunk = (size_t) HIST_THREADS * HIST_ITEMS;
+	for (size_t base = (size_t) blockIdx.x * chunk; base < n; base += (size_t) gridDim.x * chunk) {
+		#pragma unroll
+		for (int i = 0; i < HIST_ITEMS; ++i) {
+			const size_t idx = base + (size_t) i * HIST_THREADS + tid;
+			if (idx < n) {
+				const unsigned d = (unsigned) (in[idx] >> shift) & mask;
+				atomicAdd(&h[wave][d], 1u);
+			}
+		}
+	}
+	__syncthreads();
+	if (tid <= mask) {
+		unsigned s = 0;
+		#pragma unroll
+		for (int w = 0; w < HIST_THREADS / 64; ++w) s += h[w][tid];
+		if (s) {
+			if (ghist32) atomicAdd(&ghist32[tid], s);
+			if (ghist64) atomicAdd(&ghist64[tid], (unsigned long long) s);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// one digit pass
+// ---------------------------------------------------------------------------
+
+// Exclusive scan over the R (<= 256) values held by threads 0..R-1 (others pass
+// 0). Every thread of the block must call it.
+template <int THREADS>
+__device__ __forceinline__ unsigned block_excl_scan(unsigned x, unsigned tid, unsigned* s_tmp) {
+	const unsigned lane = tid & 63u, wave = tid >> 6;
+	const unsigned incl = clo_wave_scan_inclusive<unsigned>(x, lane);
+	if (lane == 63 && wave < 4) s_tmp[wave] = incl;
+	__syncthreads();
+	unsigned add = 0;
+	#pragma unroll
+	for (unsigned w = 0; w < 4; ++w) if (w < wave) add += s_tmp[w];
+	return incl - x + add;
+}
+
+template <typename E, int BITS, int THREADS, int ITEMS, int ROUNDS>
+__global__ __launch_bounds__(THREADS)
+void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
+	unsigned shift, unsigned mask,
+	int has_next, unsigned next_shift, unsigned next_mask,
+	unsigned* hdr, unsigned ticket_word,
+	const unsigned* __restrict__ ghist_cur, unsigned* __restrict__ ghist_next,
+	clo_u64* state, unsigned epoch) {
+
+	constexpr int R = 1 << BITS;
+	constexpr int WAVES = THREADS / 64;
+	constexpr int TILE = THREADS * ITEMS;
+	constexpr int STAGE = TILE / ROUNDS;
+	static_assert(R <= THREADS, "one thread per digit");
+	static_assert(STAGE % THREADS == 0, "stage is read back in whole rows");
+
+	__shared__ E s_stage[STAGE];
+	__shared__ unsigned s_wcnt[WAVES][R];   // per-wave running digit counts -> offsets
+	__shared__ unsigned s_next[WAVES][R];   // next pass's digit counts
+	__shared__ unsigned s_dstart[R];        // first tile-local position of each digit
+	__shared__ unsigned s_delta[R];         // global index = tile-local position + delta
+	__shared__ unsigned s_tmp[4];
+	__shared__ unsigned s_tile;
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+	if (tid == 0) s_tile = atomicAdd(&hdr[ticket_word], 1u);
+	for (unsigned i = tid; i < WAVES * R; i += THREADS) {
+		(&s_wcnt[0][0])[i] = 0;
+		(&s_next[0][0])[i] = 0;
+	}
+	__syncthreads();
+	const unsigned tile = s_tile;
+	const size_t base = (size_t) tile * TILE;
+	if (base >= n) return;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+
+	// global base of each digit = exclusive scan of this pass's histogram
+	const unsigned gcount = tid < (unsigned) R ? ghist_cur[tid] : 0u;
+	const unsigned gbase = block_excl_scan<THREADS>(gcount, tid, s_tmp);
+
+	// ---- 1. load, wave-striped ----
+	E key[ITEMS];
+	const unsigned wbase = wave * 64u * ITEMS + lane;
+	if (count == (unsigned) TILE) {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = in[base + wbase + i * 64];
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			const unsigned li = wbase + i * 64;
+			key[i] = li < count ? in[base + li] : (E) 0;
+		}
+	}
+
+	// ---- 5. next pass's digit counts (order-independent, so done early) ----
+	if (has_next) {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			if (wbase + i * 64 < count)
+				atomicAdd(&s_next[wave][(unsigned) (key[i] >> next_shift) & next_mask], 1u);
+		}
+	}
+
+	// ---- 2. stable rank of every element among equal digits of its wave ----
+	unsigned rank[ITEMS];
+	volatile unsigned* wrow = &s_wcnt[wave][0];
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const bool valid = wbase + i * 64 < count;
+		const unsigned d = (unsigned) (key[i] >> shift) & mask;
+		clo_u64 peers = __ballot(valid);
+		#pragma unroll
+		for (int k = 0; k < BITS; ++k) {
+			const bool bit = (d >> k) & 1u;
+			const clo_u64 b = __ballot(bit);
+			peers &= bit ? b : ~b;
+		}
+		const unsigned r = clo_mbcnt(peers);
+		const unsigned c = (unsigned) __popcll(peers);
+		const unsigned prior = wrow[d];
+		if (valid && r == 0) wrow[d] = prior + c;
+		rank[i] = prior + r;
+	}
+	__syncthreads();
+
+	// ---- tile histogram, per-wave offsets, digit starts ----
+	unsigned hist = 0;
+	if (tid < (unsigned) R) {
+		#pragma unroll
+		for (int w = 0; w < WAVES; ++w) {
+			const unsigned c = s_wcnt[w][tid];
+			s_wcnt[w][tid] = hist;
+			hist += c;
+		}
+	}
+	const unsigned dstart = block_excl_scan<THREADS>(hist, tid, s_tmp);
+
+	// ---- 3. decoupled look-back, one thread per digit ----
+	if (tid < (unsigned) R) {
+		clo_u64* my = state + (size_t) tile * R + tid;
+		unsigned excl = 0;
+		if (tile == 0) {
+			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_PREFIX, hist));
+		} else {
+			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_AGG, hist));
+			long j = (long) tile - 1;
+			unsigned spins = 0;
+			bool done = false;
+			while (!done) {
+				// up to 4 predecessors in flight per poll
+				clo_u64 g[4];
+				#pragma unroll
+				for (int k = 0; k < 4; ++k)
+					g[k] = (j - k >= 0) ? clo_ld_agent(state + (size_t) (j - k) * R + tid) : 0ull;
+				bool stalled = false;
+				#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					if (done || stalled) continue;
+					if (j - k < 0) { done = true; continue; }
+					const unsigned tag = clo_lb_tag(g[k]);
+					const unsigned st = tag & 3u;
+					if ((tag >> 2) != epoch || st == 0u) {
+						j -= k;
+						stalled = true;
+					} else {
+						excl += clo_lb_val(g[k]);
+						if (st == CLO_LB_PREFIX) done = true;
+					}
+				}
+				if (!done && !stalled) j -= 4;
+				if (stalled) {
+					if (++spins > CLO_MAX_SPINS) {
+						atomicExch(&hdr[0], 1u);
+						done = true;
+					}
+					__builtin_amdgcn_s_sleep(2);
+				}
+			}
+			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_PREFIX, excl + hist));
+		}
+		s_dstart[tid] = dstart;
+		s_delta[tid] = gbase + excl - dstart;
+	}
+	__syncthreads();
+
+	// ---- 4. scatter through the LDS stage, then contiguous runs to HBM ----
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const unsigned d = (unsigned) (key[i] >> shift) & mask;
+		rank[i] += s_dstart[d] + s_wcnt[wave][d];  // tile-local position
+	}
+	#pragma unroll
+	for (int round = 0; round < ROUNDS; ++round) {
+		const unsigned lo = (unsigned) round * STAGE;
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			const bool valid = wbase + i * 64 < count;
+			const unsigned p = rank[i] - lo;
+			if (valid && p < (unsigned) STAGE) s_stage[p] = key[i];
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int j = 0; j < STAGE / THREADS; ++j) {
+			const unsigned p = lo + j * THREADS + tid;
+			if (p < count) {
+				const E e = s_stage[p - lo];
+				const unsigned d = (unsigned) (e >> shift) & mask;
+				out[(size_t) (unsigned) (p + s_delta[d])] = e;
+			}
+		}
+		if (round + 1 < ROUNDS) __syncthreads();
+	}
+
+	// ---- 5b. hand the next pass its global histogram ----
+	if (has_next && tid <= next_mask) {
+		unsigned s = 0;
+		#pragma unroll
+		for (int w = 0; w < WAVES; ++w) s += s_next[w][tid];
+		if (s) atomicAdd(&ghist_next[tid], s);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+int g_variant = 0;
+
+struct tile_cfg { int threads, items, rounds; };
+
+// Tile shapes (threads, items per thread, LDS stage rounds). The LDS stage is
+// 32 KiB for 4/8-byte elements in every shape.
+template <typename E> struct shape0 { static constexpr int T = 512, I = (sizeof(E) == 8 ? 8 : 16), RD = 1; };
+template <typename E> struct shape1 { static constexpr int T = 512, I = (sizeof(E) == 8 ? 16 : 32), RD = 2; };
+template <typename E> struct shape2 { static constexpr int T = 1024, I = (sizeof(E) == 8 ? 8 : 16), RD = 2; };
+
+size_t tile_elems(int elem_size, int variant) {
+	const bool wide = elem_size == 8;
+	switch (variant) {
+		case 1: return 512u * (wide ? 16 : 32);
+		case 2: return 1024u * (wide ? 8 : 16);
+		default: return 512u * (wide ? 8 : 16);
+	}
+}
+
+struct ws_layout { size_t ghist, state, total, tiles; };
+
+ws_layout radix_layout(size_t n, int elem_size, int passes, int digit_bits, int variant) {
+	ws_layout L;
+	const size_t R = (size_t) 1 << digit_bits;
+	const size_t tile = tile_elems(elem_size, variant);
+	L.tiles = (n + tile - 1) / tile;
+	if (L.tiles == 0) L.tiles = 1;
+	L.ghist = CLO_WS_HEADER_BYTES;
+	size_t gh = (size_t) (passes + 1) * R * sizeof(unsigned);
+	gh = (gh + 255) & ~(size_t) 255;
+	L.state = L.ghist + gh;
+	L.total = L.state + L.tiles * R * sizeof(clo_u64);
+	return L;
+}
+
+template <typename E, int BITS, typename S>
+void launch_pass(const E* in, E* out, size_t n, unsigned shift, unsigned mask,
+	int has_next, unsigned nshift, unsigned nmask, unsigned* hdr, unsigned ticket_word,
+	const unsigned* gh_cur, unsigned* gh_next, clo_u64* state, unsigned epoch,
+	size_t tiles, hipStream_t s) {
+	hipLaunchKernelGGL((clo_radix_pass_kernel<E, BITS, S::T, S::I, S::RD>),
+		dim3((unsigned) tiles), dim3(S::T), 0, s,
+		in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word,
+		gh_cur, gh_next, state, epoch);
+}
+
+template <typename E, int BITS>
+void launch_pass_variant(int variant, const E* in, E* out, size_t n, unsigned shift, unsigned mask,
+	int has_next, unsigned nshift, unsigned nmask, unsigned* hdr, unsigned ticket_word,
+	const unsigned* gh_cur, unsigned* gh_next, clo_u64* state, unsigned epoch,
+	size_t tiles, hipStream_t s) {
+	if constexpr (BITS == 4 && sizeof(E) >= 4) {
+		if (variant == 1) {
+			launch_pass<E, BITS, shape1<E>>(in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word, gh_cur, gh_next, state, epoch, tiles, s);
+			return;
+		}
+		if (variant == 2) {
+			launch_pass<E, BITS, shape2<E>>(in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word, gh_cur, gh_next, state, epoch, tiles, s);
+			return;
+		}
+	}
+	launch_pass<E, BITS, shape0<E>>(in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word, gh_cur, gh_next, state, epoch, tiles, s);
+}
+
+// Variants other than 0 exist only for 4-bit digits on 4/8-byte elements.
+int effective_variant(int elem_size, int digit_bits) {
+	return (digit_bits == 4 && elem_size >= 4) ? g_variant : 0;
+}
+
+template <typename E, int BITS>
+int radix_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits,
+	void* ws, hipStream_t s) {
+
+	const int passes = (key_bits + BITS - 1) / BITS;
+	const int variant = effective_variant((int) sizeof(E), BITS);
+	const ws_layout L = radix_layout(n, (int) sizeof(E), passes, BITS, variant);
+	unsigned* hdr = (unsigned*) ws;
+	unsigned* ghist = (unsigned*) ((char*) ws + L.ghist);
+	clo_u64* state = (clo_u64*) ((char*) ws + L.state);
+	constexpr unsigned R = 1u << BITS;
+
+	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
+	if (e != hipSuccess) return (int) e;
+
+	const unsigned bits0 = key_bits < BITS ? key_bits : BITS;
+	unsigned hist_blocks = (unsigned) ((n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
+	if (hist_blocks > 2048) hist_blocks = 2048;
+	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(hist_blocks), dim3(HIST_THREADS), 0, s,
+		src, n, (unsigned) key_shift, (1u << bits0) - 1u, ghist, (unsigned long long*) nullptr);
+
+	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
+	const E* cur_in = src;
+	for (int p = 0; p < passes; ++p) {
+		E* cur_out;
+		if (inplace_odd) cur_out = (p % 2 == 0) ? tmp : dst;
+		else cur_out = ((passes - 1 - p) % 2 == 0) ? dst : tmp;
+		const int rem = key_bits - p * BITS;
+		const unsigned bits = rem < BITS ? rem : BITS;
+		const int has_next = p + 1 < passes;
+		const int nrem = key_bits - (p + 1) * BITS;
+		const unsigned nbits = has_next ? (nrem < BITS ? nrem : BITS) : 1;
+		launch_pass_variant<E, BITS>(variant, cur_in, cur_out, n,
+			(unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
+			has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
+			hdr, (unsigned) (CLO_WS_TICKET_WORD + p),
+			ghist + (size_t) p * R, ghist + (size_t) (p + 1) * R, state, (unsigned) (p + 1),
+			L.tiles, s);
+		cur_in = cur_out;
+	}
+	e = hipGetLastError();
+	if (e != hipSuccess) return (int) e;
+	if (inplace_odd) {
+		e = hipMemcpyAsync(dst, tmp, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+		if (e != hipSuccess) return (int) e;
+	}
+	return 0;
+}
+
+template <typename E>
+int radix_dispatch_bits(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits,
+	int digit_bits, void* ws, hipStream_t s) {
+	switch (digit_bits) {
+		case 1: return radix_sort_impl<E, 1>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 2: return radix_sort_impl<E, 2>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 3: return radix_sort_impl<E, 3>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 4: return radix_sort_impl<E, 4>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 5: return radix_sort_impl<E, 5>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 6: return radix_sort_impl<E, 6>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 7: return radix_sort_impl<E, 7>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 8: return radix_sort_impl<E, 8>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+// ---- MSD bucket split = one histogram + one stable pass on the top bits ----
+
+template <typename E>
+int msd_hist_impl(const void* src, size_t n, unsigned shift, unsigned mask, uint64_t* counts, hipStream_t s) {
+	unsigned blocks = (unsigned) ((n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
+	if (blocks > 2048) blocks = 2048;
+	if (blocks == 0) blocks = 1;
+	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(blocks), dim3(HIST_THREADS), 0, s,
+		(const E*) src, n, shift, mask, (unsigned*) nullptr, (unsigned long long*) counts);
+	return (int) hipGetLastError();
+}
+
+template <typename E, int BITS>
+int msd_partition_impl(const E* src, E* dst, size_t n, unsigned shift, void* ws, hipStream_t s) {
+	const ws_layout L = radix_layout(n, (int) sizeof(E), 1, BITS, 0);
+	unsigned* hdr = (unsigned*) ws;
+	unsigned* ghist = (unsigned*) ((char*) ws + L.ghist);
+	clo_u64* state = (clo_u64*) ((char*) ws + L.state);
+	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
+	if (e != hipSuccess) return (int) e;
+	unsigned blocks = (unsigned) ((n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(blocks), dim3(HIST_THREADS), 0, s,
+		src, n, shift, (1u << BITS) - 1u, ghist, (unsigned long long*) nullptr);
+	launch_pass<E, BITS, shape0<E>>(src, dst, n, shift, (1u << BITS) - 1u, 0, 0u, 0u,
+		hdr, (unsigned) CLO_WS_TICKET_WORD, ghist, ghist + (1u << BITS), state, 1u, L.tiles, s);
+	return (int) hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int clo_hip_radix_set_variant(int variant) {
+	if (variant < 0 || variant > 2) return CLO_HIP_EARGS;
+	g_variant = variant;
+	return 0;
+}
+
+size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits) {
+	if (digit_bits < 1 || digit_bits > 8 || key_bits < 1) return 0;
+	const int passes = (key_bits + digit_bits - 1) / digit_bits;
+	// sized for the smallest tile of any variant so the knob can change later
+	size_t worst = 0;
+	for (int v = 0; v < 3; ++v) {
+		const size_t t = radix_layout(numel, elem_size, passes, digit_bits, v).total;
+		if (t > worst) worst = t;
+	}
+	return worst;
+}
+
+int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
+	int elem_size, int key_shift, int key_bits, int digit_bits,
+	void* workspace, size_t workspace_bytes, void* stream) {
+
+	if (numel == 0) return 0;
+	if (!src || !dst || !tmp || !workspace || tmp == src || tmp == dst) return CLO_HIP_EARGS;
+	if (key_bits < 1 || key_shift < 0 || key_shift + key_bits > 8 * elem_size) return CLO_HIP_EARGS;
+	if (digit_bits < 1 || digit_bits > 8) return CLO_HIP_EUNSUPPORTED;
+	if (numel > 0xffffffffull) return CLO_HIP_EARGS;  // 32-bit positions, as upstream's uint indices
+	if ((key_bits + digit_bits - 1) / digit_bits > CLO_WS_MAX_PASSES) return CLO_HIP_EARGS;
+	if (workspace_bytes < clo_hip_radix_workspace_bytes(numel, elem_size, key_bits, digit_bits)) return CLO_HIP_EWORKSPACE;
+	hipStream_t s = (hipStream_t) stream;
+	switch (elem_size) {
+		case 1: return radix_dispatch_bits<uint8_t>(src, dst, tmp, numel, key_shift, key_bits, digit_bits, workspace, s);
+		case 2: return radix_dispatch_bits<uint16_t>(src, dst, tmp, numel, key_shift, key_bits, digit_bits, workspace, s);
+		case 4: return radix_dispatch_bits<uint32_t>(src, dst, tmp, numel, key_shift, key_bits, digit_bits, workspace, s);
+		case 8: return radix_dispatch_bits<uint64_t>(src, dst, tmp, numel, key_shift, key_bits, digit_bits, workspace, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {
+	if (bucket_bits < 1 || bucket_bits > 3) return 0;
+	return radix_layout(numel, elem_size, 1, bucket_bits, 0).total;
+}
+
+int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
+	int key_shift, int key_bits, int bucket_bits, uint64_t* counts_dev, void* stream) {
+	if (!counts_dev || bucket_bits < 1 || bucket_bits > 3 || bucket_bits > key_bits) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	hipError_t e = hipMemsetAsync(counts_dev, 0, sizeof(uint64_t) << bucket_bits, s);
+	if (e != hipSuccess) return (int) e;
+	if (numel == 0) return 0;
+	if (!src) return CLO_HIP_EARGS;
+	const unsigned shift = (unsigned) (key_shift + key_bits - bucket_bits), mask = (1u << bucket_bits) - 1u;
+	switch (elem_size) {
+		case 4: return msd_hist_impl<uint32_t>(src, numel, shift, mask, counts_dev, s);
+		case 8: return msd_hist_impl<uint64_t>(src, numel, shift, mask, counts_dev, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_size,
+	int key_shift, int key_bits, int bucket_bits,
+	void* workspace, size_t workspace_bytes, void* stream) {
+	if (numel == 0) return 0;
+	if (!src || !dst || src == dst || !workspace) return CLO_HIP_EARGS;
+	if (bucket_bits < 1 || bucket_bits > 3 || bucket_bits > key_bits) return CLO_HIP_EARGS;
+	if (numel > 0xffffffffull) return CLO_HIP_EARGS;
+	if (workspace_bytes < clo_hip_msd_workspace_bytes(numel, elem_size, bucket_bits)) return CLO_HIP_EWORKSPACE;
+	hipStream_t s = (hipStream_t) stream;
+	const unsigned shift = (unsigned) (key_shift + key_bits - bucket_bits);
+	#define CLO_MSD_CASE(E, B) return msd_partition_impl<E, B>((const E*) src, (E*) dst, numel, shift, workspace, s)
+	if (elem_size == 4) {
+		if (bucket_bits == 1) CLO_MSD_CASE(uint32_t, 1);
+		if (bucket_bits == 2) CLO_MSD_CASE(uint32_t, 2);
+		CLO_MSD_CASE(uint32_t, 3);
+	} else if (elem_size == 8) {
+		if (bucket_bits == 1) CLO_MSD_CASE(uint64_t, 1);
+		if (bucket_bits == 2) CLO_MSD_CASE(uint64_t, 2);
+		CLO_MSD_CASE(uint64_t, 3);
+	}
+	#undef CLO_MSD_CASE
+	return CLO_HIP_EUNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// clo_hip_runtime.hip — device/stream/memory/event part of the thin C-ABI over
+// HIP (include/clo_hip.h). Stands where cf4ocl2's context/queue/buffer/event
+// wrappers stood upstream; no kernels here.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+extern "C" {
+
+int clo_hip_device_count(int* count) {
+	if (!count) return CLO_HIP_EARGS;
+	hipError_t e = hipGetDeviceCount(count);
+	if (e != hipSuccess) { *count = 0; }
+	return (int) e;
+}
+
+int clo_hip_set_device(int device) { return (int) hipSetDevice(device); }
+int clo_hip_get_device(int* device) { return device ? (int) hipGetDevice(device) : CLO_HIP_EARGS; }
+
+int clo_hip_get_device_props(int device, clo_hip_device_props* props) {
+	if (!props) return CLO_HIP_EARGS;
+	hipDeviceProp_t p;
+	hipError_t e = hipGetDeviceProperties(&p, device);
+	if (e != hipSuccess) return (int) e;
+	memset(props, 0, sizeof(*props));
+	snprintf(props->name, sizeof(props->name), "%s", p.name);
+	snprintf(props->gcn_arch, sizeof(props->gcn_arch), "%s", p.gcnArchName);
+	props->compute_units = p.multiProcessorCount;
+	props->max_threads_per_block = p.maxThreadsPerBlock;
+	props->wavefront_size = p.warpSize;
+	props->lds_bytes_per_block = p.sharedMemPerBlock;
+	props->global_mem_bytes = p.totalGlobalMem;
+	return 0;
+}
+
+int clo_hip_stream_create(void** stream) {
+	if (!stream) return CLO_HIP_EARGS;
+	hipStream_t s;
+	hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+	*stream = (e == hipSuccess) ? (void*) s : nullptr;
+	return (int) e;
+}
+int clo_hip_stream_destroy(void* stream) { return (int) hipStreamDestroy((hipStream_t) stream); }
+int clo_hip_stream_synchronize(void* stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
+
+int clo_hip_malloc(void** dptr, size_t bytes) {
+	if (!dptr) return CLO_HIP_EARGS;
+	*dptr = nullptr;
+	if (bytes == 0) bytes = 4;
+	return (int) hipMalloc(dptr, bytes);
+}
+int clo_hip_free(void* dptr) { return dptr ? (int) hipFree(dptr) : 0; }
+
+int clo_hip_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream) {
+	return (int) hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t) stream);
+}
+int clo_hip_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream) {
+	return (int) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream);
+}
+int clo_hip_memcpy_d2d_async(void* dst, const void* src, size_t bytes, void* stream) {
+	return (int) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream);
+}
+int clo_hip_memset_async(void* dst, int value, size_t bytes, void* stream) {
+	return (int) hipMemsetAsync(dst, value, bytes, (hipStream_t) stream);
+}
+
+int clo_hip_event_create(void** event) {
+	if (!event) return CLO_HIP_EARGS;
+	hipEvent_t ev;
+	hipError_t e = hipEventCreate(&ev);
+	*event = (e == hipSuccess) ? (void*) ev : nullptr;
+	return (int) e;
+}
+int clo_hip_event_destroy(void* event) { return event ? (int) hipEventDestroy((hipEvent_t) event) : 0; }
+int clo_hip_event_record(void* event, void* stream) {
+	return (int) hipEventRecord((hipEvent_t) event, (hipStream_t) stream);
+}
+int clo_hip_event_synchronize(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }
+int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
+	return ms ? (int) hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop) : CLO_HIP_EARGS;
+}
+int clo_hip_stream_wait_event(void* stream, void* event) {
+	return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0);
+}
+
+const char* clo_hip_error_string(int status) {
+	switch (status) {
+		case 0: return "success";
+		case CLO_HIP_EARGS: return "clo_hip: invalid arguments";
+		case CLO_HIP_EUNSUPPORTED: return "clo_hip: unsupported type or option";
+		case CLO_HIP_EWORKSPACE: return "clo_hip: workspace too small";
+		case CLO_HIP_ETIMEOUT: return "clo_hip: in-kernel look-back spin timed out";
+		default: return status > 0 ? hipGetErrorString((hipError_t) status) : "clo_hip: unknown error";
+	}
+}
+
+int clo_hip_check_status(void* workspace, void* stream) {
+	if (!workspace) return CLO_HIP_EARGS;
+	unsigned int word = 0;
+	hipError_t e = hipMemcpyAsync(&word, (char*) workspace + CLO_WS_STATUS_OFFSET, sizeof(word),
+		hipMemcpyDeviceToHost, (hipStream_t) stream);
+	if (e != hipSuccess) return (int) e;
+	e = hipStreamSynchronize((hipStream_t) stream);
+	if (e != hipSuccess) return (int) e;
+	return word ? CLO_HIP_ETIMEOUT : 0;
+}
+
+}  // extern "C"

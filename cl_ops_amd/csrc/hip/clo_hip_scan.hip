@@ -1,0 +1,277 @@
+// clo_hip_scan.hip — exclusive prefix sum for gfx950.
+//
+// Replaces the three launches of the reference Blelloch scan
+// (scan/clo_scan_blelloch.c:146-195 -> workgroupScan / workgroupSumsScan /
+// addWorkgroupSums, scan/clo_scan_blelloch.cl:49-211), which move 16 B per
+// 4-byte element through HBM and run on at most lws work-groups. Here: ONE
+// launch, each element read once and written once (8 B per u32->u32 element):
+//
+//   * a tile = 256 threads x 4 consecutive elements x ROWS rows, loaded with
+//     one 16-byte (u32) coalesced vector load per lane and row, kept in VGPRs;
+//   * in-lane prefix of the 4 elements, wave64 shuffle scan of the lane sums,
+//     cross-wave/row offsets through 1 KiB of LDS;
+//   * tiles are handed out by a ticket (atomicAdd) so tile ids follow dispatch
+//     order; the running prefix travels tile to tile by decoupled look-back on
+//     8-byte {tag,value} granules with agent-scope relaxed loads/stores
+//     (per-XCD L2s are not coherent: clo_hip_internal.h).
+//
+// Arithmetic is modular in the sum type, exactly as the reference's
+// CLO_SCAN_SUM_TYPE additions (blelloch.cl:79-124).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_VEC = 4;
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+
+template <typename T, int N> struct vec_of { T v[N]; };
+
+// 4 consecutive elements as one aligned vector access where possible.
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, T (&v)[4]) {
+	typedef T vec4 __attribute__((ext_vector_type(4)));
+	vec4 x = *reinterpret_cast<const vec4*>(p);
+	v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const T (&v)[4]) {
+	typedef T vec4 __attribute__((ext_vector_type(4)));
+	vec4 x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3];
+	*reinterpret_cast<vec4*>(p) = x;
+}
+
+// Look-back over predecessor tiles, run by wave 0 (all 64 lanes): lane l
+// inspects tile (idx - l). NG granules per tile carry the sum in 32-bit pieces.
+template <typename TSum, int NG>
+__device__ TSum scan_lookback(const clo_u64* state, unsigned tile, unsigned lane, unsigned* status) {
+	TSum excl = 0;
+	long idx = (long) tile - 1;
+	unsigned spins = 0;
+	while (true) {
+		long j = idx - (long) lane;
+		unsigned tag = (1u << 2) | CLO_LB_PREFIX;  // tiles before 0: prefix 0
+		TSum val = 0;
+		if (j >= 0) {
+			clo_u64 g0 = clo_ld_agent(&state[(size_t) j * 2]);
+			tag = clo_lb_tag(g0);
+			val = (TSum) clo_lb_val(g0);
+			if (NG == 2) {
+				clo_u64 g1 = clo_ld_agent(&state[(size_t) j * 2 + 1]);
+				if (clo_lb_tag(g1) != tag) tag = 0;  // mid-update: poll again
+				val = (TSum) (((clo_u64) clo_lb_val(g1) << 32) | clo_lb_val(g0));
+			}
+		}
+		const unsigned st = tag & 3u;
+		const bool valid = (tag >> 2) == 1u && st != 0u;
+		const clo_u64 pmask = __ballot(valid && st == CLO_LB_PREFIX);
+		const clo_u64 imask = __ballot(!valid);
+		if (pmask) {
+			const unsigned first = (unsigned) __ffsll((long long) pmask) - 1u;
+			const clo_u64 below = (first == 0) ? 0ull : ((~0ull) >> (64 - first));
+			if ((imask & below) == 0) {
+				excl += clo_wave_reduce_sum<TSum>(lane <= first ? val : (TSum) 0);
+				break;
+			}
+		} else if (imask == 0) {
+			excl += clo_wave_reduce_sum<TSum>(val);
+			idx -= 64;
+			continue;
+		}
+		if (++spins > CLO_MAX_SPINS) {
+			if (lane == 0) atomicExch(status, 1u);
+			break;
+		}
+		__builtin_amdgcn_s_sleep(4);
+	}
+	return excl;
+}
+
+template <typename TSum, int NG>
+__device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsigned st, TSum v) {
+	const clo_u64 x = (clo_u64) v;
+	clo_st_agent(&state[(size_t) tile * 2], clo_lb_pack(1u, st, (unsigned) x));
+	if (NG == 2) clo_st_agent(&state[(size_t) tile * 2 + 1], clo_lb_pack(1u, st, (unsigned) (x >> 32)));
+}
+
+// TIn/TOut: memory types; TSum: 32- or 64-bit accumulator (sums narrower than
+// 32 bits are computed mod 2^32 and truncated on store, which is the same
+// residue).
+template <typename TIn, typename TOut, typename TSum, int ROWS>
+__global__ __launch_bounds__(SCAN_THREADS)
+void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n,
+	unsigned* hdr, clo_u64* state, int aligned) {
+
+	constexpr int ROW_ELEMS = SCAN_THREADS * SCAN_VEC;
+	constexpr int TILE = ROW_ELEMS * ROWS;
+	constexpr int NG = sizeof(TSum) > 4 ? 2 : 1;
+
+	__shared__ unsigned s_tile;
+	__shared__ TSum s_part[ROWS][SCAN_WAVES];
+	__shared__ TSum s_excl;
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+	if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
+	__syncthreads();
+	const unsigned tile = s_tile;
+	const size_t base = (size_t) tile * TILE;
+	if (base >= n) return;
+	const bool full = (base + TILE <= n) && aligned;
+
+	// ---- load (elem -> sum type conversion on load, blelloch.cl:79-80) ----
+	TSum v[ROWS][SCAN_VEC];
+	if (full) {
+		#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			TIn t[4];
+			load4<TIn>(in + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) v[r][c] = (TSum) t[c];
+		}
+	} else {
+		#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const size_t i = base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC + c;
+				v[r][c] = i < n ? (TSum) in[i] : (TSum) 0;
+			}
+		}
+	}
+
+	// ---- in-lane inclusive prefix, wave scan of lane totals per row ----
+	TSum lane_excl[ROWS];
+	#pragma unroll
+	for (int r = 0; r < ROWS; ++r) {
+		v[r][1] += v[r][0]; v[r][2] += v[r][1]; v[r][3] += v[r][2];
+		const TSum incl = clo_wave_scan_inclusive<TSum>(v[r][3], lane);
+		lane_excl[r] = incl - v[r][3];
+		if (lane == 63) s_part[r][wave] = incl;
+	}
+	__syncthreads();
+
+	// ---- offsets of (row, wave) pieces inside the tile; tile aggregate ----
+	TSum run = 0;
+	#pragma unroll
+	for (int r = 0; r < ROWS; ++r) {
+		TSum mine = 0;
+		#pragma unroll
+		for (int w = 0; w < SCAN_WAVES; ++w) {
+			const TSum t = s_part[r][w];
+			if ((unsigned) w == wave) mine = run;
+			run += t;
+		}
+		lane_excl[r] += mine;
+	}
+	const TSum aggregate = run;
+
+	// ---- chained prefix across tiles (wave 0) ----
+	if (wave == 0) {
+		TSum excl = 0;
+		if (tile == 0) {
+			if (lane == 0) scan_publish<TSum, NG>(state, 0, CLO_LB_PREFIX, aggregate);
+		} else {
+			if (lane == 0) scan_publish<TSum, NG>(state, tile, CLO_LB_AGG, aggregate);
+			excl = scan_lookback<TSum, NG>(state, tile, lane, &hdr[0]);
+			if (lane == 0) scan_publish<TSum, NG>(state, tile, CLO_LB_PREFIX, (TSum) (excl + aggregate));
+		}
+		if (lane == 0) s_excl = excl;
+	}
+	__syncthreads();
+	const TSum tile_excl = s_excl;
+
+	// ---- store: exclusive value of element c = offset + inclusive(c-1) ----
+	if (full) {
+		#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const TSum o = tile_excl + lane_excl[r];
+			TOut t[4] = { (TOut) o, (TOut) (o + v[r][0]), (TOut) (o + v[r][1]), (TOut) (o + v[r][2]) };
+			store4<TOut>(out + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+		}
+	} else {
+		#pragma unroll
+		for (int r = 0; r < ROWS; ++r) {
+			const TSum o = tile_excl + lane_excl[r];
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const size_t i = base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC + c;
+				if (i < n) out[i] = (TOut) (c == 0 ? o : (TSum) (o + v[r][c - 1]));
+			}
+		}
+	}
+}
+
+constexpr size_t scan_tile_elems(int sum_size) {
+	return (size_t) SCAN_THREADS * SCAN_VEC * (sum_size > 4 ? 8 : 16);
+}
+
+template <typename TIn, typename TOut>
+int launch_scan(const void* in, void* out, size_t n, void* ws, hipStream_t s) {
+	if constexpr (sizeof(TIn) > sizeof(TOut)) {
+		return CLO_HIP_EUNSUPPORTED;
+	} else {
+		typedef typename std::conditional<(sizeof(TOut) > 4), uint64_t, uint32_t>::type TSum;
+		constexpr int ROWS = sizeof(TOut) > 4 ? 8 : 16;
+		const size_t tile = scan_tile_elems((int) sizeof(TOut));
+		const size_t tiles = (n + tile - 1) / tile;
+		unsigned* hdr = (unsigned*) ws;
+		clo_u64* state = (clo_u64*) ((char*) ws + CLO_WS_HEADER_BYTES);
+		const int aligned = ((uintptr_t) in % (4 * sizeof(TIn)) == 0) && ((uintptr_t) out % (4 * sizeof(TOut)) == 0);
+		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16, s);
+		if (e != hipSuccess) return (int) e;
+		hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS>), dim3((unsigned) tiles), dim3(SCAN_THREADS), 0, s,
+			(const TIn*) in, (TOut*) out, n, hdr, state, aligned);
+		return (int) hipGetLastError();
+	}
+}
+
+template <typename TOut>
+int dispatch_in(const void* in, void* out, size_t n, int es, int sgn, void* ws, hipStream_t s) {
+	switch (es) {
+		case 1: return sgn ? launch_scan<int8_t, TOut>(in, out, n, ws, s) : launch_scan<uint8_t, TOut>(in, out, n, ws, s);
+		case 2: return sgn ? launch_scan<int16_t, TOut>(in, out, n, ws, s) : launch_scan<uint16_t, TOut>(in, out, n, ws, s);
+		case 4: return sgn ? launch_scan<int32_t, TOut>(in, out, n, ws, s) : launch_scan<uint32_t, TOut>(in, out, n, ws, s);
+		case 8: return launch_scan<uint64_t, TOut>(in, out, n, ws, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
+	(void) elem_size;
+	const size_t tile = scan_tile_elems(sum_size);
+	const size_t tiles = (numel + tile - 1) / tile;
+	return CLO_WS_HEADER_BYTES + (tiles ? tiles : 1) * 16;
+}
+
+int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
+	int elem_size, int elem_signed, int sum_size,
+	void* workspace, size_t workspace_bytes, void* stream) {
+
+	if (numel == 0) return 0;
+	if (!data_in || !data_out || !workspace) return CLO_HIP_EARGS;
+	if (sum_size < elem_size) return CLO_HIP_EUNSUPPORTED;
+	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
+	if (numel / scan_tile_elems(sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	// The sum type only matters by width: two's complement addition is the
+	// same for signed and unsigned sums.
+	switch (sum_size) {
+		case 1: return dispatch_in<uint8_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
+		case 2: return dispatch_in<uint16_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
+		case 4: return dispatch_in<uint32_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
+		case 8: return dispatch_in<uint64_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+}  // extern "C"

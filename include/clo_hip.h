@@ -1,0 +1,150 @@
+/*
+ * clo_hip.h — the thin C-ABI layer over HIP that replaces the cf4ocl2/OpenCL
+ * dispatch of cl_ops for the sort/scan hot path.
+ *
+ * Plain C, plain pointers and sizes; no C++/torch/HIP types in any signature
+ * (streams and events travel as void*). The host drivers in
+ * cl_ops_amd/csrc (clo_sort_*.c, clo_scan_*.c; plain C, built with gcc) call ONLY this header; the
+ * implementations live in the .hip files of cl_ops_amd/csrc/hip (built with hipcc for
+ * gfx950). Everything returns 0 on success or a non-zero status that
+ * clo_hip_error_string() decodes (positive = hipError_t, negative = CLO_HIP_E*).
+ *
+ * What each entry point stands in for upstream is cited as file:line relative
+ * to the reference tree's src/cl_ops/.
+ */
+#ifndef CLO_HIP_H
+#define CLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLO_HIP_EARGS      (-1)  /* invalid argument combination */
+#define CLO_HIP_EUNSUPPORTED (-2)  /* type/option not built into this library */
+#define CLO_HIP_EWORKSPACE (-3)  /* workspace too small */
+#define CLO_HIP_ETIMEOUT   (-4)  /* an in-kernel bounded spin gave up (see clo_hip_check_status) */
+
+/* ---- device / runtime (replaces ccl_context_*, ccl_queue_*, ccl_buffer_*,
+ *      ccl_event_*, ccl_prof_* as used at sort/clo_sort_abstract.c:335-395,
+ *      scan/clo_scan_abstract.c:290-339, benchmarks/clo_sort_bench.c:148-208) ---- */
+
+typedef struct {
+	char name[128];
+	int compute_units;
+	int max_threads_per_block;  /* CL_DEVICE_MAX_WORK_GROUP_SIZE stand-in */
+	int wavefront_size;
+	size_t lds_bytes_per_block;
+	size_t global_mem_bytes;
+	char gcn_arch[64];
+} clo_hip_device_props;
+
+int clo_hip_device_count(int* count);
+int clo_hip_set_device(int device);
+int clo_hip_get_device(int* device);
+int clo_hip_get_device_props(int device, clo_hip_device_props* props);
+
+int clo_hip_stream_create(void** stream);
+int clo_hip_stream_destroy(void* stream);
+int clo_hip_stream_synchronize(void* stream);
+
+int clo_hip_malloc(void** dptr, size_t bytes);
+int clo_hip_free(void* dptr);
+int clo_hip_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream);
+int clo_hip_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream);
+int clo_hip_memcpy_d2d_async(void* dst, const void* src, size_t bytes, void* stream);
+int clo_hip_memset_async(void* dst, int value, size_t bytes, void* stream);
+
+int clo_hip_event_create(void** event);
+int clo_hip_event_destroy(void* event);
+int clo_hip_event_record(void* event, void* stream);
+int clo_hip_event_synchronize(void* event);
+int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms);
+/* Make `stream` wait for `event` (cq_exec waiting on a cq_comm copy,
+ * sort/clo_sort_sbitonic.c:86-95). */
+int clo_hip_stream_wait_event(void* stream, void* event);
+
+const char* clo_hip_error_string(int status);
+
+/* ---- exclusive prefix sum (replaces the three launches of
+ *      scan/clo_scan_blelloch.c:146-195: workgroupScan, workgroupSumsScan,
+ *      addWorkgroupSums — scan/clo_scan_blelloch.cl:49-211) ----
+ * data_out[i] = sum_{j<i} (sum_t) data_in[j], wrap-around in the sum type.
+ * elem_size, sum_size in {1,2,4,8} bytes with sum_size >= elem_size (unsigned
+ * widening; signed inputs: pass elem_signed=1 for sign extension).
+ * workspace: clo_hip_scan_workspace_bytes() bytes of device memory, contents
+ * don't-care; the call zeroes what it polls. Asynchronous on `stream`. */
+size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size);
+int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
+	int elem_size, int elem_signed, int sum_size,
+	void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LSD radix sort (replaces the per-digit loop of
+ *      sort/clo_sort_satradix.c:264-313: satradix_localsort, satradix_histogram,
+ *      clo_scan_with_device_data, satradix_scatter — sort/clo_sort_satradix.cl:34-258) ----
+ * Stable ascending sort of `numel` elements of elem_size bytes by the unsigned
+ * key field  key = (elem >> key_shift) & ((1<<key_bits)-1), digits of
+ * `digit_bits` bits (1..8; radix = 1<<digit_bits), least significant first.
+ * src is read, the sorted result is written to dst; tmp is scratch of the same
+ * size. dst may equal src (in place); tmp must be distinct from both. src is
+ * left untouched when dst != src. Asynchronous on `stream`. */
+size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits);
+int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
+	int elem_size, int key_shift, int key_bits, int digit_bits,
+	void* workspace, size_t workspace_bytes, void* stream);
+
+/* MSD bucket partition used by the multi-GPU exchange (new
+ * functionality): stable split of src into 1<<bucket_bits buckets by the top
+ * bucket_bits of the key field. counts (device, 1<<bucket_bits uint64) receives
+ * the bucket sizes; dst gets the buckets back to back in bucket order.
+ * Two steps so the caller can exchange counts between them. */
+int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
+	int key_shift, int key_bits, int bucket_bits,
+	uint64_t* counts_dev, void* stream);
+int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_size,
+	int key_shift, int key_bits, int bucket_bits,
+	void* workspace, size_t workspace_bytes, void* stream);
+size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits);
+
+/* ---- bitonic sorts (replace the launch loops of
+ *      sort/clo_sort_sbitonic.c:102-118 / sort/clo_sort_sbitonic.cl:38-69 and
+ *      sort/clo_sort_abitonic.c:401-432 / sort/clo_sort_abitonic.cl:234-1067) ----
+ * In-place bitonic network over nlpo2(numel) slots (numel need not be a power
+ * of two: the caller provides a buffer of clo_hip_bitonic_padded_numel(numel)
+ * elements and the call pads the tail so that it sorts to the end, i.e.
+ * data[0..numel) comes out sorted). The key is the low key_bits bits of
+ * (KEY_TYPE)(elem >> key_shift), KEY_TYPE being key_size bytes wide;
+ * key_kind: 0 unsigned, 1 signed, 2 float (then key_bits = 8*key_size).
+ * descending: CLO_SORT_COMPARE "((a) < (b))".
+ * clo_hip_bitonic_simple: one launch per (stage, step) — the sbitonic schedule.
+ * clo_hip_bitonic_tiled: LDS/register-tiled schedule — the abitonic replacement.
+ * *launches (may be NULL) receives the number of kernel launches made. */
+size_t clo_hip_bitonic_padded_numel(size_t numel);
+int clo_hip_bitonic_simple(void* data, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, void* stream);
+int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, void* stream);
+
+/* ---- status word of the bounded spins (decoupled look-back) ----
+ * Every kernel that polls another work-group's state bounds its spin; on
+ * give-up it sets a word in the workspace and finishes. This reads it back
+ * (synchronises `stream`). Returns 0, CLO_HIP_ETIMEOUT or a hip error. */
+int clo_hip_check_status(void* workspace, void* stream);
+
+/* Static LDS bytes per work-group of the kernel families, for the
+ * get_localmem_usage introspection calls (sort/clo_sort_satradix.c:626-658,
+ * scan/clo_scan_blelloch.c:307-319). family: "radix_hist", "radix_pass",
+ * "scan", "bitonic_tile", "bitonic_strided", "bitonic_step". */
+size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param);
+
+/* Tuning knob (benchmark/tests only): radix tile variant, 0 = default. */
+int clo_hip_radix_set_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

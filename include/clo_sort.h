@@ -1,0 +1,95 @@
+/*
+ * clo_sort.h — the CloSort plugin API, as exported by the reference's
+ * src/cl_ops/sort/clo_sort_abstract.in.h:43-170 (same names, argument order,
+ * ownership and error behaviour), implemented over HIP.
+ *
+ * Algorithms registered: "sbitonic", "abitonic", "satradix"
+ * (clo_sort_sbitonic.in.h:36, clo_sort_abitonic.in.h:116, clo_sort_satradix.in.h:55).
+ * "gselect" is outside this build's scope: clo_sort_new reports
+ * CLO_ERROR_IMPL_NOT_FOUND for it.
+ *
+ * Divergences from upstream, all deliberate:
+ *  - `compare` / `get_key` are OpenCL C macro bodies upstream (JIT). Here they
+ *    are parsed into a fixed family: get_key = x, (x) >> N, ((x) >> N) & MASK,
+ *    optional casts; compare = ((a) > (b)) or ((a) < (b)). Anything else:
+ *    CLO_ERROR_ARGS.
+ *  - data_out != NULL works (upstream sorts data_in regardless,
+ *    clo_sort_satradix.c:276,305 / clo_sort_abitonic.c:388) and leaves data_in
+ *    untouched; numel need not be a power of two.
+ *  - `compiler_opts` is accepted and ignored (kernels are built ahead of time).
+ */
+#ifndef CLO_SORT_H
+#define CLO_SORT_H
+
+#include "clo_common.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLO_SORT_IMPLS "sbitonic, abitonic, satradix"
+
+/* clo_sort_abstract.in.h:43-110 */
+typedef struct clo_sort_impl_def {
+	const char* name;
+	cl_bool in_place;
+	/* Returns a non-NULL token on success (upstream: the kernel source text). */
+	const char* (*init)(CloSort* sorter, const char* options, GError** err);
+	void (*finalize)(CloSort* sorter);
+	CCLEvent* (*sort_with_device_data)(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm,
+		CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max, GError** err);
+	cl_uint (*get_num_kernels)(CloSort* sorter, GError** err);
+	const char* (*get_kernel_name)(CloSort* sorter, cl_uint i, GError** err);
+	size_t (*get_localmem_usage)(CloSort* sorter, cl_uint i, size_t lws_max, size_t numel, GError** err);
+} CloSortImplDef;
+
+/* clo_sort_abstract.in.h:116-170 */
+CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
+	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
+	const char* compiler_opts, GError** err);
+void clo_sort_destroy(CloSort* sorter);
+CCLEvent* clo_sort_with_device_data(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm,
+	CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max, GError** err);
+cl_bool clo_sort_with_host_data(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm,
+	void* data_in, void* data_out, size_t numel, size_t lws_max, GError** err);
+CCLContext* clo_sort_get_context(CloSort* sorter);
+CCLProgram* clo_sort_get_program(CloSort* sorter);
+CloType clo_sort_get_element_type(CloSort* sorter);
+size_t clo_sort_get_element_size(CloSort* sorter);
+CloType clo_sort_get_key_type(CloSort* sorter);
+size_t clo_sort_get_key_size(CloSort* sorter);
+void* clo_sort_get_data(CloSort* sorter);
+void clo_sort_set_data(CloSort* sorter, void* data);
+cl_uint clo_sort_get_num_kernels(CloSort* sorter, GError** err);
+const char* clo_sort_get_kernel_name(CloSort* sorter, cl_uint i, GError** err);
+size_t clo_sort_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max, size_t numel, GError** err);
+
+extern const CloSortImplDef clo_sort_sbitonic_def;  /* clo_sort_sbitonic.in.h:36 */
+extern const CloSortImplDef clo_sort_abitonic_def;  /* clo_sort_abitonic.in.h:116 */
+extern const CloSortImplDef clo_sort_satradix_def;  /* clo_sort_satradix.in.h:55 */
+
+/* Kernel-name strings reported by get_kernel_name — part of the observable API
+ * (clo_sort_sbitonic.in.h:33, clo_sort_satradix.in.h:42-52, clo_sort_abitonic.in.h:64-106). */
+#define CLO_SORT_SBITONIC_KNAME "sbitonic"
+#define CLO_SORT_SATRADIX_NUM_KERNELS 3
+#define CLO_SORT_SATRADIX_KNAME_LOCALSORT "satradix_localsort"
+#define CLO_SORT_SATRADIX_KNAME_HISTOGRAM "satradix_histogram"
+#define CLO_SORT_SATRADIX_KNAME_SCATTER "satradix_scatter"
+#define CLO_SORT_ABITONIC_NUM_KERNELS 26
+
+/* Not upstream — parsed form of (elem_type, key_type, compare, get_key) shared
+ * by the three drivers. */
+typedef struct {
+	int elem_size;
+	int key_size;
+	int key_shift;     /* key = (elem >> key_shift) & key_mask */
+	int key_bits;      /* significant bits after masking */
+	int key_kind;      /* 0 unsigned, 1 signed, 2 float */
+	int descending;
+} CloSortKeySpec;
+const CloSortKeySpec* clo_sort_get_key_spec(CloSort* sorter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,275 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (clo_sort_* /
+clo_scan_* of libcl_ops_hip.so), against the CPU oracle on the same seeded
+inputs. Bit-exact equality everywhere (integer/byte work)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_u32(rng, n):
+    return rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+
+
+def rand_u64(rng, n):
+    return rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+
+
+# ----------------------------------------------------------------------------
+# scan
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 512, 1000, 4096, 16384, 16385, 100000, 1 << 20, (1 << 22) + 77])
+@pytest.mark.parametrize("types", [("uint", "uint"), ("uint", "ulong"), ("uchar", "uint"), ("int", "long"),
+                                   ("ushort", "ushort"), ("ulong", "ulong")])
+def test_scan_matches_serial_scan(gpu, n, types):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, st = types
+    rng = np.random.default_rng(n * 7 + len(et))
+    edt, sdt = clo.api.CLO_TYPE_NP[et], clo.api.CLO_TYPE_NP[st]
+    info = np.iinfo(edt)
+    a = rng.integers(max(info.min, -1000), min(info.max, 128) + 1, n).astype(edt)
+    sc = clo.Scanner("blelloch", ctx, et, st)
+    got = sc.with_host_data(a, q)
+    sc.close()
+    exp = O.serial_scan(a.astype(sdt) if np.issubdtype(edt, np.signedinteger) else a, sdt) \
+        if np.issubdtype(edt, np.signedinteger) else O.serial_scan(a, sdt)
+    assert got.dtype == sdt
+    assert np.array_equal(got, exp)
+
+
+def test_scan_wraps_in_sum_type(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = np.full(70000, 0xF0000000, dtype=np.uint32)
+    sc = clo.Scanner("blelloch", ctx, "uint", "uint")
+    got = sc.with_host_data(a, q)
+    sc.close()
+    assert np.array_equal(got, O.serial_scan(a, np.uint32))
+
+
+def test_scan_matches_reference_decomposition(gpu):
+    """3-kernel Blelloch restatement (oracle) == HIP single pass, where the
+    reference scans everything (numel multiple of 2*lws)."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = O.scan_bench_rand(0, np.uint32, 1 << 18)
+    sc = clo.Scanner("blelloch", ctx, "uint", "ulong")
+    got = sc.with_host_data(a, q)
+    sc.close()
+    assert np.array_equal(got, O.blelloch(a, np.uint64, dev_max_lws=256))
+
+
+# ----------------------------------------------------------------------------
+# satradix
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 16, 100, 1024, 4096, 8192, 8193, 50000, 1 << 17, (1 << 20) + 3])
+def test_satradix_u32_keys(gpu, n):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = rand_u32(np.random.default_rng(n), n)
+    s = clo.Sorter("satradix", ctx, "uint")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+
+
+@pytest.mark.parametrize("n", [16, 1024, 4096, 1 << 16])
+@pytest.mark.parametrize("radix", [2, 4, 16, 256])
+def test_satradix_matches_reference_decomposition(gpu, n, radix):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    if n < radix:
+        pytest.skip("upstream's launch shape needs numel >= radix (clo_sort_satradix.c:190-197)")
+    a = O.bench_rand(0, "uint", n)
+    s = clo.Sorter("satradix", ctx, "uint", options="radix=%d" % radix)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, O.satradix(a, radix=radix, dev_max_lws=256))
+
+
+@pytest.mark.parametrize("radix", [8, 32, 64, 128])
+def test_satradix_odd_digit_widths_sort_fully(gpu, radix):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = rand_u32(np.random.default_rng(radix), 30000)
+    s = clo.Sorter("satradix", ctx, "uint", options="radix=%d" % radix)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+
+
+@pytest.mark.parametrize("n", [1024, 4096, 70001, 1 << 19])
+def test_satradix_pairs_stable(gpu, n):
+    """BASELINE config 4 shape: ulong elements, uint key in the high word,
+    value = original index; heavy duplication exercises stability."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 1000, n, dtype=np.uint64)
+    e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    got = s.with_host_data(e, q)
+    s.close()
+    assert np.array_equal(got, O.stable_sort(e, key_size=4, key_shift=32))
+    if n <= 4096:
+        assert np.array_equal(got, O.satradix(e, key_size=4, key_shift=32, dev_max_lws=256))
+
+
+@pytest.mark.parametrize("n", [4096, 100000])
+def test_satradix_u64_keys(gpu, n):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = rand_u64(np.random.default_rng(n), n)
+    s = clo.Sorter("satradix", ctx, "ulong")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+
+
+@pytest.mark.parametrize("et", ["uchar", "ushort", "char", "short", "int", "long"])
+def test_satradix_other_integer_types_raw_bit_order(gpu, et):
+    """Reference ignores COMPARE and sorts by raw key bits (SURVEY §8a-6 iii)."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(5)
+    info = np.iinfo(dt)
+    a = rng.integers(info.min, info.max, 20000, dtype=np.int64).astype(dt)
+    s = clo.Sorter("satradix", ctx, et)
+    got = s.with_host_data(a, q)
+    s.close()
+    u = a.view(np.dtype("u%d" % dt.itemsize))
+    assert np.array_equal(got.view(u.dtype), np.sort(u))
+
+
+def test_satradix_degenerate_inputs(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    s = clo.Sorter("satradix", ctx, "uint")
+    n = 20000
+    for a in (np.zeros(n, np.uint32), np.full(n, 0xFFFFFFFF, np.uint32), np.arange(n, dtype=np.uint32),
+              np.arange(n, dtype=np.uint32)[::-1].copy(), np.full(n, 0x30, np.uint32),
+              (np.arange(n, dtype=np.uint32) % 3) << 4):
+        assert np.array_equal(s.with_host_data(a, q), np.sort(a))
+    s.close()
+
+
+def test_satradix_device_data_in_place_and_out_of_place(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 300000
+    a = rand_u32(np.random.default_rng(11), n)
+    s = clo.Sorter("satradix", ctx, "uint")
+    bin_, bout = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, a.nbytes)
+    bin_.write(q, a)
+    s.with_device_data(q, bin_, bout, n)
+    assert np.array_equal(bout.read(q, np.uint32, n), np.sort(a))
+    assert np.array_equal(bin_.read(q, np.uint32, n), a)  # input untouched
+    s.with_device_data(q, bin_, None, n)
+    assert np.array_equal(bin_.read(q, np.uint32, n), np.sort(a))
+    for b in (bin_, bout):
+        b.close()
+    s.close()
+
+
+# ----------------------------------------------------------------------------
+# bitonic
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+@pytest.mark.parametrize("n", [2, 4, 16, 32, 64, 256, 1024, 4096, 8192, 16384, 1 << 16, 1 << 18])
+def test_bitonic_u32(gpu, alg, n):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = O.bench_rand(0, "uint", n)
+    s = clo.Sorter(alg, ctx, "uint")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+    if n <= 1 << 16:
+        assert np.array_equal(got, O.sbitonic(a))
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+def test_bitonic_pairs_tie_order_matches_reference_network(gpu, alg):
+    """Non-identity keys: tie order depends on the exact network; must equal the
+    restated reference network bit for bit."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 15
+    rng = np.random.default_rng(3)
+    keys = rng.integers(0, 50, n, dtype=np.uint64)
+    e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter(alg, ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    got = s.with_host_data(e, q)
+    s.close()
+    assert np.array_equal(got, O.sbitonic(e, key_size=4, key_shift=32))
+    exp_ab, _ = O.abitonic(e, key_size=4, key_shift=32, dev_max_lws=256)
+    assert np.array_equal(got, exp_ab)
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+@pytest.mark.parametrize("et", ["int", "long", "float", "double", "ushort", "uchar"])
+def test_bitonic_typed_compare(gpu, alg, et):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(9)
+    n = 1 << 14
+    if np.issubdtype(dt, np.floating):
+        a = ((rng.random(n) - 0.5) * 1e6).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, n, dtype=np.int64).astype(dt)
+    s = clo.Sorter(alg, ctx, et)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+def test_bitonic_descending_compare(gpu, alg):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = rand_u32(np.random.default_rng(2), 1 << 13)
+    s = clo.Sorter(alg, ctx, "uint", compare="((a) < (b))")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a)[::-1])
+    assert np.array_equal(got, O.sbitonic(a, descending=True))
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+@pytest.mark.parametrize("n", [3, 100, 5000, 70000])
+def test_bitonic_non_power_of_two(gpu, alg, n):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = rand_u32(np.random.default_rng(n), n)
+    a[: n // 3] = 0xFFFFFFFF  # real elements equal to the pad value
+    s = clo.Sorter(alg, ctx, "uint")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+
+
+# ----------------------------------------------------------------------------
+# API surface on a live device
+# ----------------------------------------------------------------------------
+
+def test_profiler_reports_exec_queue_time(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = rand_u32(np.random.default_rng(0), 1 << 20)
+    s = clo.Sorter("satradix", ctx, "uint")
+    q.gc()
+    s.with_host_data(a, q)
+    prof = clo.Profiler(q)
+    ns = prof.duration_ns()
+    prof.close()
+    s.close()
+    assert 1000 < ns < 5e9
