@@ -65,6 +65,9 @@ _sig("clo_hip_bitonic_simple", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci)
 _sig("clo_hip_bitonic_tiled", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_kernel_lds_bytes", sz, C.c_char_p, ci, ci)
 _sig("clo_hip_check_status", ci, vp, vp)
+_sig("clo_hip_timing_enable", ci, ci)
+_sig("clo_hip_timing_reset", ci)
+_sig("clo_hip_timing_read", ci, C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float))
 _sig("clo_hip_radix_set_variant", ci, ci)
 
 
@@ -84,3 +87,10 @@ def device_count():
     n = ci(0)
     st = lib.clo_hip_device_count(C.byref(n))
     return n.value if st == 0 else 0
+
+
+def timing_read(label):
+    """(launch count, total ms) recorded under `label` since the last reset."""
+    n, ms = C.c_uint(0), C.c_float(0)
+    check(lib.clo_hip_timing_read(label.encode(), C.byref(n), C.byref(ms)), "clo_hip_timing_read")
+    return n.value, ms.value

@@ -244,6 +244,7 @@ int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_
 	const unsigned blocks = (unsigned) ((npairs + 255) / 256);
 	for (unsigned stage = 1; stage <= T; ++stage)
 		for (unsigned step = stage; step >= 1; --step) {
+			clo_timing_scope timing("bitonic_step", s);
 			hipLaunchKernelGGL((clo_bitonic_step_kernel<E>), dim3(blocks), dim3(256), 0, s, data, npairs, stage, step, kd);
 			++count;
 		}
@@ -254,6 +255,7 @@ int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_
 template <typename E, int NS>
 void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_desc& kd, hipStream_t s) {
 	const size_t threads = n >> NS;
+	clo_timing_scope timing("bitonic_strided", s);
 	hipLaunchKernelGGL((clo_bitonic_strided_kernel<E, NS>), dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, s,
 		data, n, stage, p, kd);
 }
@@ -278,7 +280,10 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 	const unsigned tiles = (unsigned) (n >> kl);
 	int count = 0;
 	// stages 1..kl inside the tiles
-	hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
+	{
+		clo_timing_scope timing("bitonic_tile", s);
+		hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
+	}
 	++count;
 	for (unsigned stage = kl + 1; stage <= T; ++stage) {
 		unsigned p = stage;
@@ -297,7 +302,10 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 			++count;
 			p -= ns;
 		}
-		hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, stage, kl, 0, kd);
+		{
+			clo_timing_scope timing("bitonic_tile", s);
+			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, stage, kl, 0, kd);
+		}
 		++count;
 	}
 	if (launches) *launches = count;

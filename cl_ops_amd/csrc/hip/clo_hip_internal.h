@@ -17,6 +17,16 @@
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 
+// Optional per-kernel timing (clo_hip_timing_* in clo_hip.h): when enabled,
+// launch sites bracket a kernel with a pair of HIP events on its own stream.
+void clo_timing_begin(const char* label, hipStream_t s);
+void clo_timing_end(hipStream_t s);
+struct clo_timing_scope {
+	hipStream_t s;
+	clo_timing_scope(const char* label, hipStream_t stream) : s(stream) { clo_timing_begin(label, s); }
+	~clo_timing_scope() { clo_timing_end(s); }
+};
+
 typedef unsigned long long clo_u64;
 
 // Look-back granule: one naturally aligned 8-byte word written by ONE store:

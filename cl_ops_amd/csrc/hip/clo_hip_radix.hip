@@ -27,6 +27,8 @@
 // (stable ascending by key), for any digit width.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
 
@@ -38,11 +40,12 @@ namespace {
 
 constexpr int HIST_THREADS = 256;
 constexpr int HIST_ITEMS = 16;  // elements per thread per block-iteration
+constexpr unsigned GH_COPIES = 256;  // partial global histograms per pass
 
 template <typename E>
 __global__ __launch_bounds__(HIST_THREADS)
 void clo_radix_hist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
-	unsigned* __restrict__ ghist32, unsigned long long* __restrict__ ghist64) {
+	unsigned* __restrict__ ghist32, unsigned stride, unsigned long long* __restrict__ ghist64) {
 
 	__shared__ unsigned h[HIST_THREADS / 64][256];
 	const unsigned tid = threadIdx.x, wave = tid >> 6;
@@ -66,10 +69,29 @@ void clo_radix_hist_kernel(const E* __restrict__ in, size_t n, unsigned shift, u
 		#pragma unroll
 		for (int w = 0; w < HIST_THREADS / 64; ++w) s += h[w][tid];
 		if (s) {
-			if (ghist32) atomicAdd(&ghist32[tid], s);
+			// ghist32 is GH_COPIES partial histograms of `stride` counters: spreading
+			// the adds keeps same-address atomics (one per ~12 ns) off the critical path
+			if (ghist32) atomicAdd(&ghist32[(size_t) (blockIdx.x % GH_COPIES) * stride + tid], s);
 			if (ghist64) atomicAdd(&ghist64[tid], (unsigned long long) s);
 		}
 	}
+}
+
+// Sum the partial histograms of one pass and turn them into global digit
+// bases (exclusive scan over digits). One work-group of 256 threads.
+__global__ __launch_bounds__(256)
+void clo_radix_bases_kernel(const unsigned* __restrict__ parts, unsigned stride, unsigned R, unsigned* __restrict__ gbase) {
+	__shared__ unsigned s_tmp[4];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	unsigned c = 0;
+	if (tid < R)
+		for (unsigned k = 0; k < GH_COPIES; ++k) c += parts[(size_t) k * stride + tid];
+	const unsigned incl = clo_wave_scan_inclusive<unsigned>(c, lane);
+	if (lane == 63) s_tmp[wave] = incl;
+	__syncthreads();
+	unsigned add = 0;
+	for (unsigned w = 0; w < wave; ++w) add += s_tmp[w];
+	if (tid < R) gbase[tid] = incl - c + add;
 }
 
 // ---------------------------------------------------------------------------
@@ -90,78 +112,104 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned x, unsigned tid, un
 	return incl - x + add;
 }
 
+// Decoupled look-back for one digit (one thread per digit). `g` holds the
+// granules of the 4 nearest predecessors, loaded earlier so that their latency
+// overlaps the LDS scatter. Returns the exclusive prefix of this tile.
+__device__ __forceinline__ unsigned radix_lookback(const clo_u64* state, unsigned R, unsigned d,
+	unsigned tile, unsigned epoch, clo_u64 (&g)[4], unsigned* status) {
+	unsigned excl = 0, spins = 0;
+	long j = (long) tile - 1;
+	bool done = false, fresh = true;
+	while (!done) {
+		if (!fresh) {
+			#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				g[k] = (j - k >= 0) ? clo_ld_agent(state + (size_t) (j - k) * R + d) : 0ull;
+		}
+		fresh = false;
+		bool stalled = false;
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			if (done || stalled) continue;
+			if (j - k < 0) { done = true; continue; }
+			const unsigned tag = clo_lb_tag(g[k]);
+			const unsigned st = tag & 3u;
+			if ((tag >> 2) != epoch || st == 0u) {
+				j -= k;
+				stalled = true;
+			} else {
+				excl += clo_lb_val(g[k]);
+				if (st == CLO_LB_PREFIX) done = true;
+			}
+		}
+		if (!done && !stalled) j -= 4;
+		if (stalled) {
+			if (++spins > CLO_MAX_SPINS) {
+				atomicExch(status, 1u);
+				done = true;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+	}
+	return excl;
+}
+
 template <typename E, int BITS, int THREADS, int ITEMS, int ROUNDS>
-__global__ __launch_bounds__(THREADS)
-void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
-	unsigned shift, unsigned mask,
-	int has_next, unsigned next_shift, unsigned next_mask,
-	unsigned* hdr, unsigned ticket_word,
-	const unsigned* __restrict__ ghist_cur, unsigned* __restrict__ ghist_next,
-	clo_u64* state, unsigned epoch) {
+struct radix_smem {
+	static constexpr int R = 1 << BITS;
+	static constexpr int WAVES = THREADS / 64;
+	static constexpr int STAGE = THREADS * ITEMS / ROUNDS;
+	E stage[STAGE];
+	unsigned wcnt[WAVES][R];  // per-wave digit counts, later tile-local start of (wave, digit)
+	unsigned next[WAVES][R];  // next pass's digit counts
+	unsigned delta[R];        // global index = tile-local position + delta[digit]
+	unsigned tmp[4];
+	unsigned tile;
+};
+
+template <bool FULL, typename E, int BITS, int THREADS, int ITEMS, int ROUNDS>
+__device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITEMS, ROUNDS>& sm,
+	const E* __restrict__ in, E* __restrict__ out, size_t n, size_t base, unsigned count, unsigned tile,
+	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
+	unsigned* hdr, const unsigned* __restrict__ gbase_cur, unsigned* __restrict__ ghist_next,
+	clo_u64* state, unsigned epoch, unsigned xflags) {
 
 	constexpr int R = 1 << BITS;
 	constexpr int WAVES = THREADS / 64;
-	constexpr int TILE = THREADS * ITEMS;
-	constexpr int STAGE = TILE / ROUNDS;
-	static_assert(R <= THREADS, "one thread per digit");
-	static_assert(STAGE % THREADS == 0, "stage is read back in whole rows");
-
-	__shared__ E s_stage[STAGE];
-	__shared__ unsigned s_wcnt[WAVES][R];   // per-wave running digit counts -> offsets
-	__shared__ unsigned s_next[WAVES][R];   // next pass's digit counts
-	__shared__ unsigned s_dstart[R];        // first tile-local position of each digit
-	__shared__ unsigned s_delta[R];         // global index = tile-local position + delta
-	__shared__ unsigned s_tmp[4];
-	__shared__ unsigned s_tile;
-
+	constexpr int STAGE = THREADS * ITEMS / ROUNDS;
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-
-	if (tid == 0) s_tile = atomicAdd(&hdr[ticket_word], 1u);
-	for (unsigned i = tid; i < WAVES * R; i += THREADS) {
-		(&s_wcnt[0][0])[i] = 0;
-		(&s_next[0][0])[i] = 0;
-	}
-	__syncthreads();
-	const unsigned tile = s_tile;
-	const size_t base = (size_t) tile * TILE;
-	if (base >= n) return;
-	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-
-	// global base of each digit = exclusive scan of this pass's histogram
-	const unsigned gcount = tid < (unsigned) R ? ghist_cur[tid] : 0u;
-	const unsigned gbase = block_excl_scan<THREADS>(gcount, tid, s_tmp);
-
-	// ---- 1. load, wave-striped ----
-	E key[ITEMS];
 	const unsigned wbase = wave * 64u * ITEMS + lane;
-	if (count == (unsigned) TILE) {
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) key[i] = in[base + wbase + i * 64];
-	} else {
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) {
-			const unsigned li = wbase + i * 64;
-			key[i] = li < count ? in[base + li] : (E) 0;
-		}
+
+	// ---- 1. load, wave-striped: lane l of wave w holds tile element w*64*ITEMS + i*64 + l ----
+	E key[ITEMS];
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		if (FULL) key[i] = in[base + wbase + i * 64];
+		else key[i] = (wbase + i * 64 < count) ? in[base + wbase + i * 64] : (E) 0;
 	}
 
 	// ---- 5. next pass's digit counts (order-independent, so done early) ----
-	if (has_next) {
+	if (has_next && !(xflags & 2u)) {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
-			if (wbase + i * 64 < count)
-				atomicAdd(&s_next[wave][(unsigned) (key[i] >> next_shift) & next_mask], 1u);
+			if (FULL || wbase + i * 64 < count)
+				atomicAdd(&sm.next[wave][(unsigned) (key[i] >> next_shift) & next_mask], 1u);
 		}
 	}
 
 	// ---- 2. stable rank of every element among equal digits of its wave ----
+	// Per item: the lanes holding my digit (match-any by one ballot per digit
+	// bit), my rank among them (v_mbcnt), and ONE lane per distinct digit adds
+	// the group size to the wave's running count with a returning LDS atomic
+	// (distinct addresses within the instruction; LDS executes a wave's atomics
+	// in issue order, so counts accumulate item by item = stable). The old
+	// count comes back to the group through ds_bpermute. No wait between items.
 	unsigned rank[ITEMS];
-	volatile unsigned* wrow = &s_wcnt[wave][0];
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
-		const bool valid = wbase + i * 64 < count;
+		const bool valid = FULL || (wbase + i * 64 < count);
 		const unsigned d = (unsigned) (key[i] >> shift) & mask;
-		clo_u64 peers = __ballot(valid);
+		clo_u64 peers = FULL ? ~0ull : __ballot(valid);
 		#pragma unroll
 		for (int k = 0; k < BITS; ++k) {
 			const bool bit = (d >> k) & 1u;
@@ -169,108 +217,126 @@ void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t
 			peers &= bit ? b : ~b;
 		}
 		const unsigned r = clo_mbcnt(peers);
-		const unsigned c = (unsigned) __popcll(peers);
-		const unsigned prior = wrow[d];
-		if (valid && r == 0) wrow[d] = prior + c;
+		unsigned prior = 0;
+		if (valid && r == 0) prior = atomicAdd(&sm.wcnt[wave][d], (unsigned) __popcll(peers));
+		const int leader = __ffsll((long long) peers) - 1;
+		prior = (unsigned) __shfl((int) prior, valid ? leader : (int) lane, 64);
 		rank[i] = prior + r;
 	}
 	__syncthreads();
 
-	// ---- tile histogram, per-wave offsets, digit starts ----
-	unsigned hist = 0;
+	// ---- tile histogram; publish it; starts of every (wave, digit) run ----
+	unsigned hist = 0, cw[WAVES];
+	clo_u64 g[4] = { 0ull, 0ull, 0ull, 0ull };
 	if (tid < (unsigned) R) {
 		#pragma unroll
-		for (int w = 0; w < WAVES; ++w) {
-			const unsigned c = s_wcnt[w][tid];
-			s_wcnt[w][tid] = hist;
-			hist += c;
-		}
-	}
-	const unsigned dstart = block_excl_scan<THREADS>(hist, tid, s_tmp);
-
-	// ---- 3. decoupled look-back, one thread per digit ----
-	if (tid < (unsigned) R) {
+		for (int w = 0; w < WAVES; ++w) { cw[w] = sm.wcnt[w][tid]; hist += cw[w]; }
 		clo_u64* my = state + (size_t) tile * R + tid;
-		unsigned excl = 0;
 		if (tile == 0) {
 			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_PREFIX, hist));
 		} else {
 			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_AGG, hist));
-			long j = (long) tile - 1;
-			unsigned spins = 0;
-			bool done = false;
-			while (!done) {
-				// up to 4 predecessors in flight per poll
-				clo_u64 g[4];
-				#pragma unroll
-				for (int k = 0; k < 4; ++k)
-					g[k] = (j - k >= 0) ? clo_ld_agent(state + (size_t) (j - k) * R + tid) : 0ull;
-				bool stalled = false;
-				#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					if (done || stalled) continue;
-					if (j - k < 0) { done = true; continue; }
-					const unsigned tag = clo_lb_tag(g[k]);
-					const unsigned st = tag & 3u;
-					if ((tag >> 2) != epoch || st == 0u) {
-						j -= k;
-						stalled = true;
-					} else {
-						excl += clo_lb_val(g[k]);
-						if (st == CLO_LB_PREFIX) done = true;
-					}
-				}
-				if (!done && !stalled) j -= 4;
-				if (stalled) {
-					if (++spins > CLO_MAX_SPINS) {
-						atomicExch(&hdr[0], 1u);
-						done = true;
-					}
-					__builtin_amdgcn_s_sleep(2);
-				}
-			}
-			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_PREFIX, excl + hist));
+			// first look-back poll: in flight while the tile is scattered in LDS
+			#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				g[k] = ((long) tile - 1 - k >= 0) ? clo_ld_agent(state + (size_t) (tile - 1 - k) * R + tid) : 0ull;
 		}
-		s_dstart[tid] = dstart;
-		s_delta[tid] = gbase + excl - dstart;
+	}
+	const unsigned dstart = block_excl_scan<THREADS>(hist, tid, sm.tmp);
+	if (tid < (unsigned) R) {
+		unsigned run = dstart;
+		#pragma unroll
+		for (int w = 0; w < WAVES; ++w) { sm.wcnt[w][tid] = run; run += cw[w]; }
 	}
 	__syncthreads();
 
-	// ---- 4. scatter through the LDS stage, then contiguous runs to HBM ----
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		const unsigned d = (unsigned) (key[i] >> shift) & mask;
-		rank[i] += s_dstart[d] + s_wcnt[wave][d];  // tile-local position
+		rank[i] += sm.wcnt[wave][d];  // tile-local position
 	}
+
+	// ---- 4. scatter through the LDS stage, then contiguous runs to HBM ----
 	#pragma unroll
 	for (int round = 0; round < ROUNDS; ++round) {
 		const unsigned lo = (unsigned) round * STAGE;
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
-			const bool valid = wbase + i * 64 < count;
+			const bool valid = FULL || (wbase + i * 64 < count);
 			const unsigned p = rank[i] - lo;
-			if (valid && p < (unsigned) STAGE) s_stage[p] = key[i];
+			if (ROUNDS == 1) { if (valid) sm.stage[p] = key[i]; }
+			else if (valid && p < (unsigned) STAGE) sm.stage[p] = key[i];
+		}
+		if (round == 0 && tid < (unsigned) R) {
+			// ---- 3. decoupled look-back, one thread per digit ----
+			unsigned excl = 0;
+			if (tile != 0) {
+				excl = radix_lookback(state, R, tid, tile, epoch, g, &hdr[0]);
+				clo_st_agent(state + (size_t) tile * R + tid, clo_lb_pack(epoch, CLO_LB_PREFIX, excl + hist));
+			}
+			sm.delta[tid] = gbase_cur[tid] + excl - dstart;
 		}
 		__syncthreads();
 		#pragma unroll
 		for (int j = 0; j < STAGE / THREADS; ++j) {
 			const unsigned p = lo + j * THREADS + tid;
-			if (p < count) {
-				const E e = s_stage[p - lo];
+			if (FULL || p < count) {
+				const E e = sm.stage[p - lo];
 				const unsigned d = (unsigned) (e >> shift) & mask;
-				out[(size_t) (unsigned) (p + s_delta[d])] = e;
+				// (bounded even if a look-back gave up and delta is garbage)
+				const size_t gi = (size_t) (unsigned) (p + sm.delta[d]);
+				if (gi < n) out[gi] = e;
 			}
 		}
 		if (round + 1 < ROUNDS) __syncthreads();
 	}
 
-	// ---- 5b. hand the next pass its global histogram ----
+	// ---- 5b. hand the next pass its (partial) global histogram ----
 	if (has_next && tid <= next_mask) {
 		unsigned s = 0;
 		#pragma unroll
-		for (int w = 0; w < WAVES; ++w) s += s_next[w][tid];
-		if (s) atomicAdd(&ghist_next[tid], s);
+		for (int w = 0; w < WAVES; ++w) s += sm.next[w][tid];
+		if (s) atomicAdd(&ghist_next[(size_t) (tile % GH_COPIES) * R + tid], s);
 	}
+}
+
+template <typename E, int BITS, int THREADS, int ITEMS, int ROUNDS, int MINW>
+__global__ __launch_bounds__(THREADS, MINW)
+void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
+	unsigned shift, unsigned mask,
+	int has_next, unsigned next_shift, unsigned next_mask,
+	unsigned* hdr, unsigned ticket_word,
+	const unsigned* __restrict__ gbase_cur, unsigned* __restrict__ ghist_next,
+	clo_u64* state, unsigned epoch, unsigned xflags) {
+
+	constexpr int R = 1 << BITS;
+	constexpr int WAVES = THREADS / 64;
+	constexpr int TILE = THREADS * ITEMS;
+	static_assert(R <= THREADS, "one thread per digit");
+	static_assert((TILE / ROUNDS) % THREADS == 0, "stage is read back in whole rows");
+
+	__shared__ radix_smem<E, BITS, THREADS, ITEMS, ROUNDS> sm;
+	const unsigned tid = threadIdx.x;
+
+	// tile id = ticket: ids follow dispatch order, so every predecessor a tile
+	// waits for in the look-back has already been handed to a running group
+	if (tid == 0) sm.tile = (xflags & 4u) ? blockIdx.x : atomicAdd(&hdr[ticket_word], 1u);
+	for (unsigned i = tid; i < WAVES * R; i += THREADS) {
+		(&sm.wcnt[0][0])[i] = 0;
+		(&sm.next[0][0])[i] = 0;
+	}
+	__syncthreads();
+	const unsigned tile = sm.tile;
+	const size_t base = (size_t) tile * TILE;
+	if (base >= n) return;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+
+	if (count == (unsigned) TILE)
+		radix_pass_body<true, E, BITS, THREADS, ITEMS, ROUNDS>(sm, in, out, n, base, count, tile, shift, mask,
+			has_next, next_shift, next_mask, hdr, gbase_cur, ghist_next, state, epoch, xflags);
+	else
+		radix_pass_body<false, E, BITS, THREADS, ITEMS, ROUNDS>(sm, in, out, n, base, count, tile, shift, mask,
+			has_next, next_shift, next_mask, hdr, gbase_cur, ghist_next, state, epoch, xflags);
 }
 
 // ---------------------------------------------------------------------------
@@ -278,25 +344,26 @@ void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t
 // ---------------------------------------------------------------------------
 
 int g_variant = 0;
+unsigned g_xflags = 0;  // developer experiments (CLO_RADIX_XFLAGS), never set in production
 
 struct tile_cfg { int threads, items, rounds; };
 
 // Tile shapes (threads, items per thread, LDS stage rounds). The LDS stage is
 // 32 KiB for 4/8-byte elements in every shape.
-template <typename E> struct shape0 { static constexpr int T = 512, I = (sizeof(E) == 8 ? 8 : 16), RD = 1; };
-template <typename E> struct shape1 { static constexpr int T = 512, I = (sizeof(E) == 8 ? 16 : 32), RD = 2; };
-template <typename E> struct shape2 { static constexpr int T = 1024, I = (sizeof(E) == 8 ? 8 : 16), RD = 2; };
+template <typename E> struct shape0 { static constexpr int T = 512, I = (sizeof(E) == 8 ? 8 : 16), RD = 1, W = 1; };
+template <typename E> struct shape1 { static constexpr int T = 256, I = (sizeof(E) == 8 ? 8 : 16), RD = 1, W = 1; };
+template <typename E> struct shape2 { static constexpr int T = 1024, I = (sizeof(E) == 8 ? 8 : 16), RD = 2, W = 1; };
 
 size_t tile_elems(int elem_size, int variant) {
 	const bool wide = elem_size == 8;
 	switch (variant) {
-		case 1: return 512u * (wide ? 16 : 32);
+		case 1: return 256u * (wide ? 8 : 16);
 		case 2: return 1024u * (wide ? 8 : 16);
 		default: return 512u * (wide ? 8 : 16);
 	}
 }
 
-struct ws_layout { size_t ghist, state, total, tiles; };
+struct ws_layout { size_t ghist, gbase, state, total, tiles; };
 
 ws_layout radix_layout(size_t n, int elem_size, int passes, int digit_bits, int variant) {
 	ws_layout L;
@@ -305,9 +372,10 @@ ws_layout radix_layout(size_t n, int elem_size, int passes, int digit_bits, int 
 	L.tiles = (n + tile - 1) / tile;
 	if (L.tiles == 0) L.tiles = 1;
 	L.ghist = CLO_WS_HEADER_BYTES;
-	size_t gh = (size_t) (passes + 1) * R * sizeof(unsigned);
-	gh = (gh + 255) & ~(size_t) 255;
-	L.state = L.ghist + gh;
+	const size_t gh = (size_t) (passes + 1) * GH_COPIES * R * sizeof(unsigned);
+	L.gbase = L.ghist + gh;
+	const size_t gb = ((size_t) passes * R * sizeof(unsigned) + 255) & ~(size_t) 255;
+	L.state = L.gbase + gb;
 	L.total = L.state + L.tiles * R * sizeof(clo_u64);
 	return L;
 }
@@ -317,10 +385,11 @@ void launch_pass(const E* in, E* out, size_t n, unsigned shift, unsigned mask,
 	int has_next, unsigned nshift, unsigned nmask, unsigned* hdr, unsigned ticket_word,
 	const unsigned* gh_cur, unsigned* gh_next, clo_u64* state, unsigned epoch,
 	size_t tiles, hipStream_t s) {
-	hipLaunchKernelGGL((clo_radix_pass_kernel<E, BITS, S::T, S::I, S::RD>),
+	clo_timing_scope timing("radix_pass", s);
+	hipLaunchKernelGGL((clo_radix_pass_kernel<E, BITS, S::T, S::I, S::RD, S::W>),
 		dim3((unsigned) tiles), dim3(S::T), 0, s,
 		in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word,
-		gh_cur, gh_next, state, epoch);
+		gh_cur, gh_next, state, epoch, g_xflags);
 }
 
 template <typename E, int BITS>
@@ -355,8 +424,10 @@ int radix_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int k
 	const ws_layout L = radix_layout(n, (int) sizeof(E), passes, BITS, variant);
 	unsigned* hdr = (unsigned*) ws;
 	unsigned* ghist = (unsigned*) ((char*) ws + L.ghist);
+	unsigned* gbase = (unsigned*) ((char*) ws + L.gbase);
 	clo_u64* state = (clo_u64*) ((char*) ws + L.state);
 	constexpr unsigned R = 1u << BITS;
+	constexpr size_t PART = (size_t) GH_COPIES * R;  // counters per pass
 
 	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
 	if (e != hipSuccess) return (int) e;
@@ -364,8 +435,11 @@ int radix_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int k
 	const unsigned bits0 = key_bits < BITS ? key_bits : BITS;
 	unsigned hist_blocks = (unsigned) ((n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
 	if (hist_blocks > 2048) hist_blocks = 2048;
-	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(hist_blocks), dim3(HIST_THREADS), 0, s,
-		src, n, (unsigned) key_shift, (1u << bits0) - 1u, ghist, (unsigned long long*) nullptr);
+	{
+		clo_timing_scope timing("radix_hist", s);
+		hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(hist_blocks), dim3(HIST_THREADS), 0, s,
+			src, n, (unsigned) key_shift, (1u << bits0) - 1u, ghist, R, (unsigned long long*) nullptr);
+	}
 
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
 	const E* cur_in = src;
@@ -378,11 +452,16 @@ int radix_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int k
 		const int has_next = p + 1 < passes;
 		const int nrem = key_bits - (p + 1) * BITS;
 		const unsigned nbits = has_next ? (nrem < BITS ? nrem : BITS) : 1;
+		{
+			clo_timing_scope timing("radix_bases", s);
+			hipLaunchKernelGGL(clo_radix_bases_kernel, dim3(1), dim3(256), 0, s,
+				(const unsigned*) (ghist + (size_t) p * PART), R, R, gbase + (size_t) p * R);
+		}
 		launch_pass_variant<E, BITS>(variant, cur_in, cur_out, n,
 			(unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
 			has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
 			hdr, (unsigned) (CLO_WS_TICKET_WORD + p),
-			ghist + (size_t) p * R, ghist + (size_t) (p + 1) * R, state, (unsigned) (p + 1),
+			gbase + (size_t) p * R, ghist + (size_t) (p + 1) * PART, state, (unsigned) (p + 1),
 			L.tiles, s);
 		cur_in = cur_out;
 	}
@@ -419,7 +498,7 @@ int msd_hist_impl(const void* src, size_t n, unsigned shift, unsigned mask, uint
 	if (blocks > 2048) blocks = 2048;
 	if (blocks == 0) blocks = 1;
 	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(blocks), dim3(HIST_THREADS), 0, s,
-		(const E*) src, n, shift, mask, (unsigned*) nullptr, (unsigned long long*) counts);
+		(const E*) src, n, shift, mask, (unsigned*) nullptr, 0u, (unsigned long long*) counts);
 	return (int) hipGetLastError();
 }
 
@@ -428,15 +507,18 @@ int msd_partition_impl(const E* src, E* dst, size_t n, unsigned shift, void* ws,
 	const ws_layout L = radix_layout(n, (int) sizeof(E), 1, BITS, 0);
 	unsigned* hdr = (unsigned*) ws;
 	unsigned* ghist = (unsigned*) ((char*) ws + L.ghist);
+	unsigned* gbase = (unsigned*) ((char*) ws + L.gbase);
 	clo_u64* state = (clo_u64*) ((char*) ws + L.state);
+	constexpr unsigned R = 1u << BITS;
 	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
 	if (e != hipSuccess) return (int) e;
 	unsigned blocks = (unsigned) ((n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
 	if (blocks > 2048) blocks = 2048;
 	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(blocks), dim3(HIST_THREADS), 0, s,
-		src, n, shift, (1u << BITS) - 1u, ghist, (unsigned long long*) nullptr);
-	launch_pass<E, BITS, shape0<E>>(src, dst, n, shift, (1u << BITS) - 1u, 0, 0u, 0u,
-		hdr, (unsigned) CLO_WS_TICKET_WORD, ghist, ghist + (1u << BITS), state, 1u, L.tiles, s);
+		src, n, shift, R - 1u, ghist, R, (unsigned long long*) nullptr);
+	hipLaunchKernelGGL(clo_radix_bases_kernel, dim3(1), dim3(256), 0, s, (const unsigned*) ghist, R, R, gbase);
+	launch_pass<E, BITS, shape0<E>>(src, dst, n, shift, R - 1u, 0, 0u, 0u,
+		hdr, (unsigned) CLO_WS_TICKET_WORD, gbase, ghist + (size_t) GH_COPIES * R, state, 1u, L.tiles, s);
 	return (int) hipGetLastError();
 }
 
@@ -446,6 +528,8 @@ extern "C" {
 
 int clo_hip_radix_set_variant(int variant) {
 	if (variant < 0 || variant > 2) return CLO_HIP_EARGS;
+	const char* x = getenv("CLO_RADIX_XFLAGS");
+	g_xflags = x ? (unsigned) atoi(x) : 0u;
 	g_variant = variant;
 	return 0;
 }

@@ -5,11 +5,68 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
 
+namespace {
+struct timing_rec { std::string label; hipEvent_t e0, e1; };
+std::mutex g_timing_mu;
+std::vector<timing_rec> g_timing;
+bool g_timing_on = false;
+}  // namespace
+
+void clo_timing_begin(const char* label, hipStream_t s) {
+	if (!g_timing_on) return;
+	std::lock_guard<std::mutex> lk(g_timing_mu);
+	timing_rec r;
+	r.label = label;
+	if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+	(void) hipEventRecord(r.e0, s);
+	g_timing.push_back(r);
+}
+
+void clo_timing_end(hipStream_t s) {
+	if (!g_timing_on) return;
+	std::lock_guard<std::mutex> lk(g_timing_mu);
+	if (!g_timing.empty()) (void) hipEventRecord(g_timing.back().e1, s);
+}
+
 extern "C" {
+
+int clo_hip_timing_enable(int on) {
+	std::lock_guard<std::mutex> lk(g_timing_mu);
+	g_timing_on = on != 0;
+	return 0;
+}
+
+int clo_hip_timing_reset(void) {
+	std::lock_guard<std::mutex> lk(g_timing_mu);
+	for (auto& r : g_timing) { (void) hipEventDestroy(r.e0); (void) hipEventDestroy(r.e1); }
+	g_timing.clear();
+	return 0;
+}
+
+int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms) {
+	if (!label || !count || !total_ms) return CLO_HIP_EARGS;
+	std::lock_guard<std::mutex> lk(g_timing_mu);
+	*count = 0;
+	*total_ms = 0.f;
+	for (auto& r : g_timing) {
+		if (r.label != label) continue;
+		hipError_t e = hipEventSynchronize(r.e1);
+		if (e != hipSuccess) return (int) e;
+		float ms = 0.f;
+		e = hipEventElapsedTime(&ms, r.e0, r.e1);
+		if (e != hipSuccess) return (int) e;
+		*total_ms += ms;
+		++*count;
+	}
+	return 0;
+}
 
 int clo_hip_device_count(int* count) {
 	if (!count) return CLO_HIP_EARGS;

@@ -225,6 +225,7 @@ int launch_scan(const void* in, void* out, size_t n, void* ws, hipStream_t s) {
 		const int aligned = ((uintptr_t) in % (4 * sizeof(TIn)) == 0) && ((uintptr_t) out % (4 * sizeof(TOut)) == 0);
 		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16, s);
 		if (e != hipSuccess) return (int) e;
+		clo_timing_scope timing("scan", s);
 		hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS>), dim3((unsigned) tiles), dim3(SCAN_THREADS), 0, s,
 			(const TIn*) in, (TOut*) out, n, hdr, state, aligned);
 		return (int) hipGetLastError();

@@ -135,6 +135,16 @@ int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
  * (synchronises `stream`). Returns 0, CLO_HIP_ETIMEOUT or a hip error. */
 int clo_hip_check_status(void* workspace, void* stream);
 
+/* ---- per-kernel device timing (measurement only; bench.py's roofline leg) ----
+ * While enabled, every kernel launch made by this library is bracketed by a
+ * pair of HIP events recorded on the stream the kernel runs on.
+ * clo_hip_timing_read sums the elapsed time of the launches recorded under
+ * `label` since the last reset ("radix_pass", "radix_hist", "scan",
+ * "bitonic_tile", "bitonic_strided", "bitonic_step"). */
+int clo_hip_timing_enable(int on);
+int clo_hip_timing_reset(void);
+int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms);
+
 /* Static LDS bytes per work-group of the kernel families, for the
  * get_localmem_usage introspection calls (sort/clo_sort_satradix.c:626-658,
  * scan/clo_scan_blelloch.c:307-319). family: "radix_hist", "radix_pass",
