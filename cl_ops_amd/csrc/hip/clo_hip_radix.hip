@@ -112,21 +112,17 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned x, unsigned tid, un
 	return incl - x + add;
 }
 
-// Decoupled look-back for one digit (one thread per digit). `g` holds the
-// granules of the 4 nearest predecessors, loaded earlier so that their latency
-// overlaps the LDS scatter. Returns the exclusive prefix of this tile.
-__device__ __forceinline__ unsigned radix_lookback(const clo_u64* state, unsigned R, unsigned d,
-	unsigned tile, unsigned epoch, clo_u64 (&g)[4], unsigned* status) {
-	unsigned excl = 0, spins = 0;
-	long j = (long) tile - 1;
-	bool done = false, fresh = true;
+// Serial tail of the look-back for one digit: polls predecessors j, j-1, ...
+// (4 granules in flight per poll) until one carries an inclusive prefix.
+__device__ __forceinline__ unsigned radix_lookback_serial(const clo_u64* state, unsigned R, unsigned d,
+	long j, unsigned excl, unsigned epoch, unsigned* status) {
+	unsigned spins = 0;
+	bool done = j < 0;
 	while (!done) {
-		if (!fresh) {
-			#pragma unroll
-			for (int k = 0; k < 4; ++k)
-				g[k] = (j - k >= 0) ? clo_ld_agent(state + (size_t) (j - k) * R + d) : 0ull;
-		}
-		fresh = false;
+		clo_u64 g[4];
+		#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			g[k] = (j - k >= 0) ? clo_ld_agent(state + (size_t) (j - k) * R + d) : 0ull;
 		bool stalled = false;
 		#pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -160,9 +156,10 @@ struct radix_smem {
 	static constexpr int WAVES = THREADS / 64;
 	static constexpr int STAGE = THREADS * ITEMS / ROUNDS;
 	E stage[STAGE];
-	unsigned wcnt[WAVES][R];  // per-wave digit counts, later tile-local start of (wave, digit)
-	unsigned next[WAVES][R];  // next pass's digit counts
-	unsigned delta[R];        // global index = tile-local position + delta[digit]
+	unsigned wcnt[WAVES][R];   // per-wave digit counts, then running tile-local position of (wave, digit)
+	unsigned next[WAVES][R];   // next pass's digit counts
+	clo_u64 lb[THREADS];       // look-back window, [THREADS / R][R]
+	unsigned delta[R];         // global index = tile-local position + delta[digit]
 	unsigned tmp[4];
 	unsigned tile;
 };
@@ -172,13 +169,17 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 	const E* __restrict__ in, E* __restrict__ out, size_t n, size_t base, unsigned count, unsigned tile,
 	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
 	unsigned* hdr, const unsigned* __restrict__ gbase_cur, unsigned* __restrict__ ghist_next,
-	clo_u64* state, unsigned epoch, unsigned xflags) {
+	clo_u64* state, unsigned epoch, unsigned xflags, unsigned long long* dbg) {
 
 	constexpr int R = 1 << BITS;
 	constexpr int WAVES = THREADS / 64;
 	constexpr int STAGE = THREADS * ITEMS / ROUNDS;
+	constexpr int LBW = THREADS / R;                 // threads per digit in the look-back window
+	constexpr int LBK = LBW >= 32 ? 1 : 32 / LBW;    // predecessors per thread (window = LBW * LBK >= 32)
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const unsigned wbase = wave * 64u * ITEMS + lane;
+	#define CLO_STAMP(k) do { if (dbg && tid == 0 && tile < 32768u) dbg[(size_t) tile * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+	CLO_STAMP(0);
 
 	// ---- 1. load, wave-striped: lane l of wave w holds tile element w*64*ITEMS + i*64 + l ----
 	E key[ITEMS];
@@ -187,6 +188,8 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 		if (FULL) key[i] = in[base + wbase + i * 64];
 		else key[i] = (wbase + i * 64 < count) ? in[base + wbase + i * 64] : (E) 0;
 	}
+	if (dbg) { asm volatile("" :: "v"((unsigned) key[ITEMS - 1])); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+	CLO_STAMP(1);
 
 	// ---- 5. next pass's digit counts (order-independent, so done early) ----
 	if (has_next && !(xflags & 2u)) {
@@ -197,14 +200,12 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 		}
 	}
 
-	// ---- 2. stable rank of every element among equal digits of its wave ----
-	// Per item: the lanes holding my digit (match-any by one ballot per digit
-	// bit), my rank among them (v_mbcnt), and ONE lane per distinct digit adds
-	// the group size to the wave's running count with a returning LDS atomic
-	// (distinct addresses within the instruction; LDS executes a wave's atomics
-	// in issue order, so counts accumulate item by item = stable). The old
-	// count comes back to the group through ds_bpermute. No wait between items.
-	unsigned rank[ITEMS];
+	// ---- 2a. match: per item, the lanes of my wave holding my digit ----
+	// One ballot per digit bit gives the group (match-any); v_mbcnt my rank in
+	// it. ONE lane per distinct digit (the group's first) adds the group size
+	// to the wave's digit count: distinct LDS addresses within the instruction,
+	// so no atomic conflicts. (rank, size, leader lane) stay packed in a VGPR.
+	unsigned grp[ITEMS];
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		const bool valid = FULL || (wbase + i * 64 < count);
@@ -217,30 +218,23 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 			peers &= bit ? b : ~b;
 		}
 		const unsigned r = clo_mbcnt(peers);
-		unsigned prior = 0;
-		if (valid && r == 0) prior = atomicAdd(&sm.wcnt[wave][d], (unsigned) __popcll(peers));
-		const int leader = __ffsll((long long) peers) - 1;
-		prior = (unsigned) __shfl((int) prior, valid ? leader : (int) lane, 64);
-		rank[i] = prior + r;
+		const unsigned c = (unsigned) __popcll(peers);
+		const unsigned leader = valid ? (unsigned) (__ffsll((long long) peers) - 1) : lane;
+		if (valid && r == 0) atomicAdd(&sm.wcnt[wave][d], c);
+		grp[i] = r | (c << 8) | (leader << 16);
 	}
+	if (dbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	CLO_STAMP(2);
 	__syncthreads();
+	CLO_STAMP(3);
 
-	// ---- tile histogram; publish it; starts of every (wave, digit) run ----
+	// ---- tile histogram; publish it; start of every (wave, digit) run ----
 	unsigned hist = 0, cw[WAVES];
-	clo_u64 g[4] = { 0ull, 0ull, 0ull, 0ull };
 	if (tid < (unsigned) R) {
 		#pragma unroll
 		for (int w = 0; w < WAVES; ++w) { cw[w] = sm.wcnt[w][tid]; hist += cw[w]; }
-		clo_u64* my = state + (size_t) tile * R + tid;
-		if (tile == 0) {
-			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_PREFIX, hist));
-		} else {
-			clo_st_agent(my, clo_lb_pack(epoch, CLO_LB_AGG, hist));
-			// first look-back poll: in flight while the tile is scattered in LDS
-			#pragma unroll
-			for (int k = 0; k < 4; ++k)
-				g[k] = ((long) tile - 1 - k >= 0) ? clo_ld_agent(state + (size_t) (tile - 1 - k) * R + tid) : 0ull;
-		}
+		clo_st_agent(state + (size_t) tile * R + tid,
+			clo_lb_pack(epoch, tile == 0 ? CLO_LB_PREFIX : CLO_LB_AGG, hist));
 	}
 	const unsigned dstart = block_excl_scan<THREADS>(hist, tid, sm.tmp);
 	if (tid < (unsigned) R) {
@@ -248,35 +242,83 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 		#pragma unroll
 		for (int w = 0; w < WAVES; ++w) { sm.wcnt[w][tid] = run; run += cw[w]; }
 	}
-	__syncthreads();
 
+	// ---- 3a. look-back window: every thread fetches the granules of LBK
+	// predecessors of one digit; they are in flight during step 2b/4a ----
+	const unsigned lb_d = tid % R, lb_q = tid / R;
+	clo_u64 g[LBK];
 	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) {
-		const unsigned d = (unsigned) (key[i] >> shift) & mask;
-		rank[i] += sm.wcnt[wave][d];  // tile-local position
+	for (int k = 0; k < LBK; ++k) {
+		const long j = (long) tile - 1 - (long) (lb_q * LBK + k);
+		g[k] = (j >= 0) ? clo_ld_agent(state + (size_t) j * R + lb_d) : 0ull;
 	}
+	__syncthreads();
+	CLO_STAMP(4);
 
-	// ---- 4. scatter through the LDS stage, then contiguous runs to HBM ----
+	// ---- 2b. rank: the group's first lane takes the group's slice of the
+	// (wave, digit) run with a returning LDS atomic (a wave's LDS atomics run in
+	// issue order, so slices follow item order = stable); ds_bpermute hands the
+	// slice start to the group. 4a. scatter into the LDS stage. ----
 	#pragma unroll
 	for (int round = 0; round < ROUNDS; ++round) {
 		const unsigned lo = (unsigned) round * STAGE;
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = FULL || (wbase + i * 64 < count);
-			const unsigned p = rank[i] - lo;
+			if (round == 0) {
+				const unsigned d = (unsigned) (key[i] >> shift) & mask;
+				const unsigned r = grp[i] & 0xffu, c = (grp[i] >> 8) & 0xffu, leader = grp[i] >> 16;
+				unsigned start = 0;
+				if (valid && r == 0) start = atomicAdd(&sm.wcnt[wave][d], c);
+				start = (unsigned) __shfl((int) start, (int) leader, 64);
+				grp[i] = start + r;  // tile-local position
+			}
+			const unsigned p = grp[i] - lo;
 			if (ROUNDS == 1) { if (valid) sm.stage[p] = key[i]; }
 			else if (valid && p < (unsigned) STAGE) sm.stage[p] = key[i];
 		}
-		if (round == 0 && tid < (unsigned) R) {
-			// ---- 3. decoupled look-back, one thread per digit ----
-			unsigned excl = 0;
-			if (tile != 0) {
-				excl = radix_lookback(state, R, tid, tile, epoch, g, &hdr[0]);
-				clo_st_agent(state + (size_t) tile * R + tid, clo_lb_pack(epoch, CLO_LB_PREFIX, excl + hist));
+		if (round == 0) {
+			CLO_STAMP(5);
+			// ---- 3b. reduce the window: nearest predecessor first ----
+			{
+				unsigned sum = 0, st = 3u, idx = 0;  // st: 3 = all aggregates, 2 = prefix found, 0 = stalled at idx
+				#pragma unroll
+				for (int k = 0; k < LBK; ++k) {
+					if (st != 3u) continue;
+					const long j = (long) tile - 1 - (long) (lb_q * LBK + k);
+					if (j < 0) { st = CLO_LB_PREFIX; continue; }
+					const unsigned tag = clo_lb_tag(g[k]);
+					if ((tag >> 2) != epoch || (tag & 3u) == 0u) { st = 0u; idx = (unsigned) k; continue; }
+					sum += clo_lb_val(g[k]);
+					if ((tag & 3u) == CLO_LB_PREFIX) st = CLO_LB_PREFIX;
+				}
+				sm.lb[lb_q * R + lb_d] = ((clo_u64) ((idx << 2) | st) << 32) | sum;
 			}
-			sm.delta[tid] = gbase_cur[tid] + excl - dstart;
+			__syncthreads();
+			if (tid < (unsigned) R) {
+				unsigned excl = 0;
+				if (tile != 0) {
+					long resume = -1;  // predecessor to resume serial polling at, if the window did not close
+					bool closed = false;
+					for (int q = 0; q < LBW && !closed && resume < 0; ++q) {
+						const clo_u64 w = sm.lb[q * R + tid];
+						const unsigned st = (unsigned) (w >> 32) & 3u, idx = (unsigned) (w >> 34);
+						excl += (unsigned) w;
+						if (st == CLO_LB_PREFIX) closed = true;
+						else if (st == 0u) resume = (long) tile - 1 - (long) (q * LBK + idx);
+					}
+					if (!closed) {
+						if (resume < 0) resume = (long) tile - 1 - (long) (LBW * LBK);
+						excl = radix_lookback_serial(state, R, tid, resume, excl, epoch, &hdr[0]);
+					}
+					clo_st_agent(state + (size_t) tile * R + tid, clo_lb_pack(epoch, CLO_LB_PREFIX, excl + hist));
+				}
+				sm.delta[tid] = gbase_cur[tid] + excl - dstart;
+			}
+			CLO_STAMP(6);
 		}
 		__syncthreads();
+		// ---- 4b. contiguous runs to HBM ----
 		#pragma unroll
 		for (int j = 0; j < STAGE / THREADS; ++j) {
 			const unsigned p = lo + j * THREADS + tid;
@@ -290,6 +332,9 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 		}
 		if (round + 1 < ROUNDS) __syncthreads();
 	}
+	if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	CLO_STAMP(7);
+	#undef CLO_STAMP
 
 	// ---- 5b. hand the next pass its (partial) global histogram ----
 	if (has_next && tid <= next_mask) {
@@ -307,7 +352,7 @@ void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t
 	int has_next, unsigned next_shift, unsigned next_mask,
 	unsigned* hdr, unsigned ticket_word,
 	const unsigned* __restrict__ gbase_cur, unsigned* __restrict__ ghist_next,
-	clo_u64* state, unsigned epoch, unsigned xflags) {
+	clo_u64* state, unsigned epoch, unsigned xflags, unsigned long long* dbg) {
 
 	constexpr int R = 1 << BITS;
 	constexpr int WAVES = THREADS / 64;
@@ -333,10 +378,10 @@ void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t
 
 	if (count == (unsigned) TILE)
 		radix_pass_body<true, E, BITS, THREADS, ITEMS, ROUNDS>(sm, in, out, n, base, count, tile, shift, mask,
-			has_next, next_shift, next_mask, hdr, gbase_cur, ghist_next, state, epoch, xflags);
+			has_next, next_shift, next_mask, hdr, gbase_cur, ghist_next, state, epoch, xflags, dbg);
 	else
 		radix_pass_body<false, E, BITS, THREADS, ITEMS, ROUNDS>(sm, in, out, n, base, count, tile, shift, mask,
-			has_next, next_shift, next_mask, hdr, gbase_cur, ghist_next, state, epoch, xflags);
+			has_next, next_shift, next_mask, hdr, gbase_cur, ghist_next, state, epoch, xflags, dbg);
 }
 
 // ---------------------------------------------------------------------------
@@ -344,6 +389,7 @@ void clo_radix_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t
 // ---------------------------------------------------------------------------
 
 int g_variant = 0;
+unsigned long long* g_dbg = nullptr;  // developer stamps buffer (8 u64 per tile), diagnostic runs only
 unsigned g_xflags = 0;  // developer experiments (CLO_RADIX_XFLAGS), never set in production
 
 struct tile_cfg { int threads, items, rounds; };
@@ -389,7 +435,7 @@ void launch_pass(const E* in, E* out, size_t n, unsigned shift, unsigned mask,
 	hipLaunchKernelGGL((clo_radix_pass_kernel<E, BITS, S::T, S::I, S::RD, S::W>),
 		dim3((unsigned) tiles), dim3(S::T), 0, s,
 		in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word,
-		gh_cur, gh_next, state, epoch, g_xflags);
+		gh_cur, gh_next, state, epoch, g_xflags, g_dbg);
 }
 
 template <typename E, int BITS>
@@ -412,7 +458,7 @@ void launch_pass_variant(int variant, const E* in, E* out, size_t n, unsigned sh
 
 // Variants other than 0 exist only for 4-bit digits on 4/8-byte elements.
 int effective_variant(int elem_size, int digit_bits) {
-	return (digit_bits == 4 && elem_size >= 4) ? g_variant : 0;
+	return (digit_bits == 4 && elem_size >= 4 && g_variant < 3) ? g_variant : 0;
 }
 
 template <typename E, int BITS>
@@ -526,8 +572,18 @@ int msd_partition_impl(const E* src, E* dst, size_t n, unsigned shift, void* ws,
 
 extern "C" {
 
+int clo_hip_radix_set_debug_buffer(void* dptr) {
+	g_dbg = (unsigned long long*) dptr;
+	return 0;
+}
+
 int clo_hip_radix_set_variant(int variant) {
-	if (variant < 0 || variant > 2) return CLO_HIP_EARGS;
+	// 0: default (chain-free path for digits <= 4 bits, look-back path above);
+	// 1, 2: other tile shapes of the look-back path; 3: look-back path always
+	// 4: default path with 8192-element tiles for 4-byte elements (default 4096)
+	if (variant < 0 || variant > 4) return CLO_HIP_EARGS;
+	clo_radix4_set_log_tile(variant == 4 ? 13 : 12);
+	if (variant == 4) variant = 0;
 	const char* x = getenv("CLO_RADIX_XFLAGS");
 	g_xflags = x ? (unsigned) atoi(x) : 0u;
 	g_variant = variant;
@@ -541,6 +597,10 @@ size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, 
 	size_t worst = 0;
 	for (int v = 0; v < 3; ++v) {
 		const size_t t = radix_layout(numel, elem_size, passes, digit_bits, v).total;
+		if (t > worst) worst = t;
+	}
+	if (digit_bits <= 4) {
+		const size_t t = clo_radix4_workspace_bytes(numel, elem_size, key_bits, digit_bits);
 		if (t > worst) worst = t;
 	}
 	return worst;
@@ -558,6 +618,8 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	if ((key_bits + digit_bits - 1) / digit_bits > CLO_WS_MAX_PASSES) return CLO_HIP_EARGS;
 	if (workspace_bytes < clo_hip_radix_workspace_bytes(numel, elem_size, key_bits, digit_bits)) return CLO_HIP_EWORKSPACE;
 	hipStream_t s = (hipStream_t) stream;
+	if (digit_bits <= 4 && g_variant == 0)
+		return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, workspace, s);
 	switch (elem_size) {
 		case 1: return radix_dispatch_bits<uint8_t>(src, dst, tmp, numel, key_shift, key_bits, digit_bits, workspace, s);
 		case 2: return radix_dispatch_bits<uint16_t>(src, dst, tmp, numel, key_shift, key_bits, digit_bits, workspace, s);

@@ -1,0 +1,407 @@
+// clo_hip_radix4.hip — LSD radix sort passes for small radices (digits of 1..4
+// bits, radix <= 16): the default "satradix" configuration (radix = 16).
+//
+// Structure per digit, the reference's own (sort/clo_sort_satradix.c:264-313):
+//   per-tile digit histogram -> scan of the counters -> scatter,
+// with two changes that remove every redundant pass over the keys:
+//   * the tile-local sort + scatter of a digit is ONE kernel that reads each
+//     element once and writes it once (clo_radix4_pass_kernel);
+//   * the per-tile histogram of the NEXT digit is accumulated by that same
+//     kernel while it scatters: an element's destination index, hence its tile
+//     in the next pass, is known when it is stored. Elements of one (tile,
+//     digit) run land in at most two destination tiles, so a 2 KiB LDS table
+//     [digit][2][next digit] collects the counts, flushed with 64-byte
+//     contiguous global atomics. Only the first digit needs a histogram kernel.
+// Between two passes a tiny two-kernel scan turns counts[tile][digit] into
+// global offsets (digit-major order, i.e. upstream's counters_sum). No kernel
+// waits on another work-group: no look-back, no tickets, no spinning.
+//
+// HBM traffic per element and digit: one read + one write (upstream: ~5 element
+// streams + 6 counter streams).
+#include <hip/hip_runtime.h>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+namespace {
+
+constexpr int R4_THREADS = 512;
+constexpr int R4_WAVES = R4_THREADS / 64;
+
+// LT = log2(tile elements): 13 (16 items per thread) or 12 (8 items per thread)
+template <int LT> struct r4_shape {
+	static constexpr int ITEMS = (1 << LT) / R4_THREADS;
+	static constexpr int TILE = 1 << LT;
+	static constexpr int LOG_TILE = LT;
+};
+int g_r4_log_tile4 = 12;  // tile shape for 4-byte elements: 4096 measured faster than 8192 (occupancy)
+
+// Lanes of the wave holding the same digit as the caller (match-any by one
+// ballot per digit bit), restricted to `valid` lanes.
+template <int BITS>
+__device__ __forceinline__ clo_u64 match_digit(unsigned d, clo_u64 valid_mask) {
+	clo_u64 peers = valid_mask;
+	#pragma unroll
+	for (int k = 0; k < BITS; ++k) {
+		const bool bit = (d >> k) & 1u;
+		const clo_u64 b = __ballot(bit);
+		peers &= bit ? b : ~b;
+	}
+	return peers;
+}
+
+// ---------------------------------------------------------------------------
+// first digit: per-tile histogram (upstream's satradix_histogram job)
+// ---------------------------------------------------------------------------
+template <typename E, int BITS, int LT>
+__global__ __launch_bounds__(R4_THREADS)
+void clo_radix4_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
+	unsigned* __restrict__ thist) {
+	constexpr int R = 1 << BITS;
+	constexpr int ITEMS = r4_shape<LT>::ITEMS;
+	constexpr int TILE = r4_shape<LT>::TILE;
+	__shared__ unsigned s_cnt[R4_WAVES][R];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const size_t base = (size_t) blockIdx.x * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	if (tid < R4_WAVES * R) (&s_cnt[0][0])[tid] = 0;
+	__syncthreads();
+	const unsigned wbase = wave * 64u * ITEMS + lane;
+	E key[ITEMS];
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) key[i] = (wbase + i * 64 < count) ? in[base + wbase + i * 64] : (E) 0;
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const bool valid = wbase + i * 64 < count;
+		const unsigned d = (unsigned) (key[i] >> shift) & mask;
+		const clo_u64 peers = match_digit<BITS>(d, __ballot(valid));
+		if (valid && clo_mbcnt(peers) == 0) atomicAdd(&s_cnt[wave][d], (unsigned) __popcll(peers));
+	}
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned h = 0;
+		#pragma unroll
+		for (int w = 0; w < R4_WAVES; ++w) h += s_cnt[w][tid];
+		thist[(size_t) blockIdx.x * R + tid] = h;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// counts[tile][digit] -> offsets[tile][digit] in digit-major order:
+//   off[t][d] = sum_{d'<d} total[d'] + sum_{t'<t} cnt[t'][d]
+// (exactly upstream's exclusive scan of counters[num_wgs*d + wg]).
+// Two small kernels over chunks of 256 tiles.
+// ---------------------------------------------------------------------------
+constexpr int OFF_CHUNK = 256;
+
+template <int R>
+__global__ __launch_bounds__(OFF_CHUNK)
+void clo_radix4_chunksum_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned* __restrict__ partial) {
+	__shared__ unsigned s_w[OFF_CHUNK / 64][R];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned t = blockIdx.x * OFF_CHUNK + tid;
+	#pragma unroll
+	for (int d = 0; d < R; ++d) {
+		const unsigned c = t < tiles ? thist[(size_t) t * R + d] : 0u;
+		const unsigned sum = clo_wave_reduce_sum<unsigned>(c);
+		if (lane == 0) s_w[wave][d] = sum;
+	}
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned s = 0;
+		#pragma unroll
+		for (int w = 0; w < OFF_CHUNK / 64; ++w) s += s_w[w][tid];
+		partial[(size_t) blockIdx.x * R + tid] = s;
+	}
+}
+
+template <int R>
+__global__ __launch_bounds__(OFF_CHUNK)
+void clo_radix4_offsets_kernel(const unsigned* __restrict__ thist, unsigned tiles,
+	const unsigned* __restrict__ partial, unsigned chunks, unsigned* __restrict__ toff) {
+	__shared__ unsigned s_before[R];   // count of digit d in earlier chunks
+	__shared__ unsigned s_total[R];    // count of digit d in all chunks
+	__shared__ unsigned s_w[OFF_CHUNK / 64][R];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	// every block re-derives its starting point from the chunk sums (<= a few KB)
+	if (tid < (unsigned) R) { s_before[tid] = 0; s_total[tid] = 0; }
+	__syncthreads();
+	for (unsigned i = tid; i < chunks * R; i += OFF_CHUNK) {
+		const unsigned c = i / R, d = i % R, v = partial[i];
+		if (v) {
+			atomicAdd(&s_total[d], v);
+			if (c < blockIdx.x) atomicAdd(&s_before[d], v);
+		}
+	}
+	__syncthreads();
+	const unsigned t = blockIdx.x * OFF_CHUNK + tid;
+	unsigned cnt[R], excl[R];
+	#pragma unroll
+	for (int d = 0; d < R; ++d) {
+		cnt[d] = t < tiles ? thist[(size_t) t * R + d] : 0u;
+		const unsigned incl = clo_wave_scan_inclusive<unsigned>(cnt[d], lane);
+		excl[d] = incl - cnt[d];
+		if (lane == 63) s_w[wave][d] = incl;
+	}
+	__syncthreads();
+	if (t < tiles) {
+		unsigned dbase = 0;
+		#pragma unroll
+		for (int d = 0; d < R; ++d) {
+			unsigned add = s_before[d] + dbase;
+			#pragma unroll
+			for (int w = 0; w < OFF_CHUNK / 64; ++w) if ((unsigned) w < wave) add += s_w[w][d];
+			toff[(size_t) t * R + d] = excl[d] + add;
+			dbase += s_total[d];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// one digit: tile-local stable sort + scatter, and the next digit's histogram
+// ---------------------------------------------------------------------------
+template <typename E, int BITS, int LT>
+__global__ __launch_bounds__(R4_THREADS)
+void clo_radix4_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
+	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
+	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff,
+	unsigned* __restrict__ thist_next) {
+
+	constexpr int R = 1 << BITS;
+	constexpr int ITEMS = r4_shape<LT>::ITEMS;
+	constexpr int TILE = r4_shape<LT>::TILE;
+	constexpr int LOG_TILE = r4_shape<LT>::LOG_TILE;
+
+	__shared__ E s_stage[TILE];
+	__shared__ unsigned s_wcnt[R4_WAVES][R];   // per-wave digit counts, then running position of (wave, digit)
+	__shared__ unsigned s_next[R][2][R];       // [digit][destination tile 0/1][next digit]
+	__shared__ unsigned s_delta[R];            // global index = tile-local position + delta[digit]
+	__shared__ unsigned s_first[R];            // first destination tile of the digit's run
+	__shared__ unsigned s_dstart[R];           // tile-local start of the digit's run
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned tile = blockIdx.x;
+	const size_t base = (size_t) tile * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	const bool full = count == (unsigned) TILE;
+	const unsigned wbase = wave * 64u * ITEMS + lane;
+
+	// ---- 1. load, wave-striped: lane l of wave w holds tile element w*64*ITEMS + i*64 + l ----
+	E key[ITEMS];
+	if (full) {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = in[base + wbase + i * 64];
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = (wbase + i * 64 < count) ? in[base + wbase + i * 64] : (E) 0;
+	}
+
+	// tile bookkeeping from the scanned counters (upstream's offsets / counters_sum)
+	if (tid < R4_WAVES * R) (&s_wcnt[0][0])[tid] = 0;
+	for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) (&s_next[0][0][0])[i] = 0;
+	if (tid < 64) {
+		const unsigned h = tid < (unsigned) R ? thist[(size_t) tile * R + tid] : 0u;
+		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
+		if (tid < (unsigned) R) {
+			const unsigned goff = toff[(size_t) tile * R + tid];
+			s_dstart[tid] = dstart;
+			s_delta[tid] = goff - dstart;
+			s_first[tid] = goff >> LOG_TILE;
+		}
+	}
+	__syncthreads();
+
+	// ---- 2a. match: per item, the lanes of my wave holding my digit; the
+	// group's first lane adds the group size to the wave's digit count
+	// (distinct LDS addresses within one instruction: no atomic conflicts) ----
+	unsigned grp[ITEMS];
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const bool valid = full || (wbase + i * 64 < count);
+		const unsigned d = (unsigned) (key[i] >> shift) & mask;
+		const clo_u64 peers = match_digit<BITS>(d, full ? ~0ull : __ballot(valid));
+		const unsigned r = clo_mbcnt(peers);
+		const unsigned c = (unsigned) __popcll(peers);
+		const unsigned leader = valid ? (unsigned) (__ffsll((long long) peers) - 1) : lane;
+		if (valid && r == 0) atomicAdd(&s_wcnt[wave][d], c);
+		grp[i] = r | (c << 8) | (leader << 16);
+	}
+	__syncthreads();
+
+	// ---- start of every (wave, digit) run inside the tile ----
+	if (tid < (unsigned) R) {
+		unsigned run = s_dstart[tid];
+		#pragma unroll
+		for (int w = 0; w < R4_WAVES; ++w) {
+			const unsigned c = s_wcnt[w][tid];
+			s_wcnt[w][tid] = run;
+			run += c;
+		}
+	}
+	__syncthreads();
+
+	// ---- 2b. rank: the group's first lane takes the group's slice of the run
+	// with a returning LDS atomic (a wave's LDS atomics execute in issue order,
+	// so slices follow item order: stable); ds_bpermute hands the start to the
+	// group. 4a. scatter into the LDS stage in digit order. ----
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const bool valid = full || (wbase + i * 64 < count);
+		const unsigned d = (unsigned) (key[i] >> shift) & mask;
+		const unsigned r = grp[i] & 0xffu, c = (grp[i] >> 8) & 0xffu, leader = grp[i] >> 16;
+		unsigned start = 0;
+		if (valid && r == 0) start = atomicAdd(&s_wcnt[wave][d], c);
+		start = (unsigned) __shfl((int) start, (int) leader, 64);
+		if (valid) s_stage[start + r] = key[i];
+	}
+	__syncthreads();
+
+	// ---- 4b. contiguous runs to HBM; 5. next digit's per-tile histogram ----
+	#pragma unroll
+	for (int j = 0; j < ITEMS; ++j) {
+		const unsigned p = j * R4_THREADS + tid;
+		if (full || p < count) {
+			const E e = s_stage[p];
+			const unsigned d = (unsigned) (e >> shift) & mask;
+			const unsigned gi = p + s_delta[d];
+			if ((size_t) gi < n) {
+				out[gi] = e;
+				if (has_next) {
+					const unsigned half = ((gi >> LOG_TILE) - s_first[d]) & 1u;
+					atomicAdd(&s_next[d][half][(unsigned) (e >> next_shift) & next_mask], 1u);
+				}
+			}
+		}
+	}
+	if (has_next) {
+		__syncthreads();
+		// 16 consecutive lanes = the 16 counters of one destination tile (64 B)
+		for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) {
+			const unsigned v = (&s_next[0][0][0])[i];
+			if (v) {
+				const unsigned d = i / (2 * R), half = (i / R) & 1u, dn = i % R;
+				atomicAdd(&thist_next[(size_t) (s_first[d] + half) * R + dn], v);
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+struct r4_layout { size_t thist, toff, partial, total, tiles, chunks; };
+
+int r4_log_tile(int elem_size) { return elem_size == 8 ? 12 : g_r4_log_tile4; }
+
+r4_layout r4_make_layout(size_t n, int elem_size, int passes, int digit_bits, int log_tile) {
+	r4_layout L;
+	const size_t R = (size_t) 1 << digit_bits;
+	const size_t tile = (size_t) 1 << log_tile;
+	L.tiles = (n + tile - 1) / tile;
+	if (L.tiles == 0) L.tiles = 1;
+	L.chunks = (L.tiles + OFF_CHUNK - 1) / OFF_CHUNK;
+	const size_t per_pass = (L.tiles + 1) * R * sizeof(unsigned);  // +1: a run may touch the tile after the last
+	L.thist = CLO_WS_HEADER_BYTES;
+	L.toff = L.thist + (size_t) passes * per_pass;
+	L.partial = L.toff + per_pass;
+	L.total = L.partial + ((L.chunks * R * sizeof(unsigned) + 255) & ~(size_t) 255);
+	return L;
+}
+
+template <typename E, int BITS, int LT>
+int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, void* ws, hipStream_t s) {
+	constexpr unsigned R = 1u << BITS;
+	const int passes = (key_bits + BITS - 1) / BITS;
+	const r4_layout L = r4_make_layout(n, (int) sizeof(E), passes, BITS, LT);
+	const size_t per_pass = (L.tiles + 1) * R;
+	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
+	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
+	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
+	const unsigned tiles = (unsigned) L.tiles, chunks = (unsigned) L.chunks;
+
+	// zero the header (status word) and every pass's histogram
+	hipError_t e = hipMemsetAsync(ws, 0, L.toff, s);
+	if (e != hipSuccess) return (int) e;
+
+	const unsigned bits0 = key_bits < BITS ? key_bits : BITS;
+	{
+		clo_timing_scope timing("radix_hist", s);
+		hipLaunchKernelGGL((clo_radix4_tilehist_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+			src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist);
+	}
+
+	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
+	const E* cur_in = src;
+	for (int p = 0; p < passes; ++p) {
+		E* cur_out;
+		if (inplace_odd) cur_out = (p % 2 == 0) ? tmp : dst;
+		else cur_out = ((passes - 1 - p) % 2 == 0) ? dst : tmp;
+		const int rem = key_bits - p * BITS;
+		const unsigned bits = rem < BITS ? rem : BITS;
+		const int has_next = p + 1 < passes;
+		const int nrem = key_bits - (p + 1) * BITS;
+		const unsigned nbits = has_next ? (nrem < BITS ? nrem : BITS) : 1;
+		unsigned* th = thist + (size_t) p * per_pass;
+		{
+			clo_timing_scope timing("radix_offsets", s);
+			hipLaunchKernelGGL((clo_radix4_chunksum_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
+				(const unsigned*) th, tiles, partial);
+			hipLaunchKernelGGL((clo_radix4_offsets_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
+				(const unsigned*) th, tiles, (const unsigned*) partial, chunks, toff);
+		}
+		{
+			clo_timing_scope timing("radix_pass", s);
+			hipLaunchKernelGGL((clo_radix4_pass_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+				cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
+				has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
+				(const unsigned*) th, (const unsigned*) toff, th + per_pass);
+		}
+		cur_in = cur_out;
+	}
+	e = hipGetLastError();
+	if (e != hipSuccess) return (int) e;
+	if (inplace_odd) {
+		e = hipMemcpyAsync(dst, tmp, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+		if (e != hipSuccess) return (int) e;
+	}
+	return 0;
+}
+
+template <typename E, int LT>
+int r4_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits, int digit_bits,
+	void* ws, hipStream_t s) {
+	switch (digit_bits) {
+		case 1: return r4_sort_impl<E, 1, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 2: return r4_sort_impl<E, 2, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 3: return r4_sort_impl<E, 3, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 4: return r4_sort_impl<E, 4, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+}  // namespace
+
+size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int digit_bits) {
+	const int passes = (key_bits + digit_bits - 1) / digit_bits;
+	return r4_make_layout(n, elem_size, passes, digit_bits, 12).total;  // the smaller tile needs more
+}
+
+int clo_radix4_set_log_tile(int log_tile) {
+	if (log_tile != 12 && log_tile != 13) return CLO_HIP_EARGS;
+	g_r4_log_tile4 = log_tile;
+	return 0;
+}
+
+int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
+	int key_bits, int digit_bits, void* ws, hipStream_t s) {
+	const bool small = r4_log_tile(elem_size) == 12;
+	switch (elem_size) {
+		case 1: return r4_dispatch<uint8_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
+		case 2: return r4_dispatch<uint16_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
+		case 4: return small ? r4_dispatch<uint32_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s)
+			: r4_dispatch<uint32_t, 13>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
+		case 8: return r4_dispatch<uint64_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}

@@ -153,6 +153,9 @@ size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param);
 
 /* Tuning knob (benchmark/tests only): radix tile variant, 0 = default. */
 int clo_hip_radix_set_variant(int variant);
+/* Developer diagnostics: device buffer of 8 uint64 per tile (first 32768 tiles)
+ * that receives s_memtime stamps of the pass kernel's phases; NULL disables. */
+int clo_hip_radix_set_debug_buffer(void* dptr);
 
 #ifdef __cplusplus
 }
