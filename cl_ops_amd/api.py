@@ -60,6 +60,8 @@ _sig("clo_sum", C.c_uint, C.c_uint)
 
 _sig("ccl_context_new_from_device_index", vp, ci, _E)
 _sig("ccl_context_new_gpu", vp, _E)
+_sig("ccl_context_new_offline", vp, _E)
+_sig("clo_sort_get_key_spec", vp, vp)
 _sig("ccl_context_destroy", None, vp)
 _sig("ccl_context_get_device", vp, vp, _u32, _E)
 _sig("ccl_device_get_index", ci, vp)
@@ -165,9 +167,12 @@ def clo_type(t):
 class Context:
     """CCLContext over one HIP device."""
 
-    def __init__(self, device_index=0):
+    def __init__(self, device_index=0, offline=False):
         err = _Err()
-        self.h = lib.ccl_context_new_from_device_index(device_index, err.ref)
+        if offline:  # host-logic tests only: nothing can be enqueued on it
+            self.h = lib.ccl_context_new_offline(err.ref)
+        else:
+            self.h = lib.ccl_context_new_from_device_index(device_index, err.ref)
         err.raise_if_set()
         if not self.h:
             raise CloError("clo", CLO_ERROR_LIBRARY, "could not create context")
@@ -288,6 +293,12 @@ class Sorter:
         if not ok:
             raise CloError("clo", CLO_ERROR_LIBRARY, "clo_sort_with_host_data failed")
         return out
+
+    def key_spec(self):
+        """(elem_size, key_size, key_shift, key_bits, key_kind, descending) as parsed from
+        elem/key types, get_key and compare."""
+        p = C.cast(lib.clo_sort_get_key_spec(self.h), C.POINTER(C.c_int * 6))
+        return tuple(p.contents)
 
     @property
     def element_size(self):

@@ -77,6 +77,10 @@ static int hip_failed(int st, GError** err, const char* what) {
 }
 
 static int use_device(CCLContext* ctx, GError** err) {
+	if (ctx->dev.index < 0) {
+		clo_gerror_set(err, CCL_HIP_ERROR, 100, "This context is offline (no device): nothing can be enqueued on it");
+		return 0;
+	}
 	return !hip_failed(clo_hip_set_device(ctx->dev.index), err, "hipSetDevice");
 }
 
@@ -104,6 +108,18 @@ CCLContext* ccl_context_new_from_device_index(int device_index, GError** err) {
 		return NULL;
 	}
 	if (!use_device(ctx, err)) { free(ctx); return NULL; }
+	return ctx;
+}
+
+CCLContext* ccl_context_new_offline(GError** err) {
+	(void) err;
+	CCLContext* ctx = (CCLContext*) calloc(1, sizeof(*ctx));
+	if (!ctx) return NULL;
+	ctx->refcount = 1;
+	ctx->dev.index = -1;
+	ctx->dev.props.max_threads_per_block = 1024;
+	ctx->dev.props.wavefront_size = 64;
+	strcpy(ctx->dev.props.name, "offline (no device)");
 	return ctx;
 }
 
@@ -160,6 +176,7 @@ CCLQueue* ccl_queue_new(CCLContext* ctx, CCLDevice* dev, cl_ulong properties, GE
 
 CCLQueue* ccl_queue_new_from_stream(CCLContext* ctx, void* hip_stream, cl_ulong properties, GError** err) {
 	if (!ctx) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL context"); return NULL; }
+	if (!use_device(ctx, err)) return NULL;
 	return queue_alloc(ctx, hip_stream, 0, properties);
 }
 
@@ -259,6 +276,7 @@ CCLBuffer* ccl_buffer_new(CCLContext* ctx, cl_ulong flags, size_t size, void* ho
 
 CCLBuffer* ccl_buffer_new_from_device_ptr(CCLContext* ctx, void* device_ptr, size_t size, GError** err) {
 	if (!ctx || !device_ptr) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL context or pointer"); return NULL; }
+	if (!use_device(ctx, err)) return NULL;
 	CCLBuffer* b = (CCLBuffer*) calloc(1, sizeof(*b));
 	if (!b) return NULL;
 	ccl_context_ref(ctx);

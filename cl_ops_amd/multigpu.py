@@ -1,0 +1,158 @@
+"""Sorting an array sharded over the GPUs of one node: most-significant-digit
+bucket exchange + local radix sorts (SURVEY.md §8e — new functionality, the
+reference is single-device).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on
+ROCm). Rank r ends up holding bucket r (the keys whose top log2(G) bits equal
+r), sorted; concatenating the ranks' results in rank order is the globally
+sorted array. Per sort:
+
+  1. local histogram of the top log2(G) key bits         (HIP kernel, 1 read)
+  2. all-gather of the G counts                          (64 B per rank)
+  3. local stable partition into G contiguous buckets    (HIP kernel, 1 read + 1 write)
+  4. all-to-all(v): ONE batch of G-1 send/recv pairs     (RCCL grouped ncclSend/ncclRecv;
+     every pair has its own xGMI link, so the G-1 transfers run concurrently)
+  5. local satradix sort of the received bucket          (clo_sort_* C API)
+
+torch is plumbing here: it owns the device buffers that RCCL needs and the
+process group. All computation goes through the C-ABI of libcl_ops_hip.so on
+the tensors' device pointers. The device-side steps are behind the small
+`LocalOps` interface so that the host logic (splits, offsets, exchange order)
+can be exercised by world_size-2 gloo tests on CPU tensors (tests inject an
+oracle-backed LocalOps; the product only ever uses HipLocalOps).
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def _log2_exact(g):
+    b = g.bit_length() - 1
+    if g < 1 or (1 << b) != g:
+        raise ValueError("world size must be a power of two, got %d" % g)
+    return b
+
+
+class HipLocalOps:
+    """Device-side steps on torch CUDA tensors through the C-ABI."""
+
+    def __init__(self, elem_type, device_index, key_bits=None):
+        import torch
+        import cl_ops_amd as clo
+        from cl_ops_amd import _hip
+        self.torch, self.clo, self._hip = torch, clo, _hip
+        self.lib = _hip.lib
+        self.elem_type = elem_type                      # "uint" or "ulong"
+        self.elem_size = 4 if elem_type == "uint" else 8
+        self.key_bits = key_bits or 8 * self.elem_size
+        self.ctx = clo.Context(device_index)
+        # run on torch's current stream so that ordering with RCCL is the stream's
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.queue = clo.Queue(self.ctx, stream=self.stream)
+        self.sorter = clo.Sorter("satradix", self.ctx, elem_type)
+        self._ws = None
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = self.torch.empty(nbytes, dtype=self.torch.uint8, device="cuda")
+        return self._ws
+
+    def msd_histogram(self, t, n, bucket_bits):
+        counts = self.torch.empty(1 << bucket_bits, dtype=self.torch.int64, device=t.device)
+        self._hip.check(self.lib.clo_hip_msd_histogram(t.data_ptr(), n, self.elem_size, 0, self.key_bits,
+                                                       bucket_bits, counts.data_ptr(), self.stream),
+                        "clo_hip_msd_histogram")
+        return counts
+
+    def msd_partition(self, src, dst, n, bucket_bits):
+        need = self.lib.clo_hip_msd_workspace_bytes(n, self.elem_size, bucket_bits)
+        ws = self._workspace(need)
+        self._hip.check(self.lib.clo_hip_msd_partition(src.data_ptr(), dst.data_ptr(), n, self.elem_size, 0,
+                                                       self.key_bits, bucket_bits, ws.data_ptr(), ws.numel(),
+                                                       self.stream), "clo_hip_msd_partition")
+
+    def sort_inplace(self, t, n):
+        buf = self.clo.Buffer(self.ctx, n * self.elem_size, device_ptr=t.data_ptr())
+        try:
+            self.sorter.with_device_data(self.queue, buf, None, n)
+        finally:
+            buf.close()
+
+    def close(self):
+        self.sorter.close()
+        self.queue.close()
+        self.ctx.close()
+
+
+class ShardedSorter:
+    """MSD bucket exchange + local sort over a torch.distributed process group."""
+
+    def __init__(self, ops, group=None, capacity_factor=1.25):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.ops = ops
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.bucket_bits = _log2_exact(self.world)
+        self.capacity_factor = capacity_factor
+        self._send = None
+        self._recv = None
+
+    def _buffers(self, like, n):
+        cap = int(n * self.capacity_factor) + 1024
+        if self._send is None or self._send.numel() < n:
+            self._send = self.torch.empty(n, dtype=like.dtype, device=like.device)
+        if self._recv is None or self._recv.numel() < cap:
+            self._recv = self.torch.empty(cap, dtype=like.dtype, device=like.device)
+        return self._send, self._recv
+
+    @staticmethod
+    def plan(count_matrix, rank):
+        """count_matrix[src][bucket] -> (send_counts, send_offsets, recv_counts, recv_offsets)
+        for `rank`. Pure host logic (numpy int64)."""
+        m = np.asarray(count_matrix, dtype=np.int64)
+        send_counts = m[rank].copy()
+        send_offsets = np.concatenate(([0], np.cumsum(send_counts)[:-1]))
+        recv_counts = m[:, rank].copy()
+        recv_offsets = np.concatenate(([0], np.cumsum(recv_counts)[:-1]))
+        return send_counts, send_offsets, recv_counts, recv_offsets
+
+    def sort(self, local, n=None):
+        """Sorts the global array whose shards are `local[:n]` on each rank.
+        Returns (tensor, m): this rank's bucket, sorted, in tensor[:m]."""
+        torch, dist = self.torch, self.dist
+        n = local.numel() if n is None else n
+        if self.world == 1:
+            self.ops.sort_inplace(local, n)
+            return local, n
+
+        send, recv = self._buffers(local, n)
+        b = self.bucket_bits
+        counts = self.ops.msd_histogram(local, n, b)                      # step 1
+        gathered = [torch.empty_like(counts) for _ in range(self.world)]
+        dist.all_gather(gathered, counts, group=self.group)               # step 2
+        matrix = torch.stack(gathered).cpu().numpy()
+        sc, so, rc, ro = self.plan(matrix, self.rank)
+        total = int(rc.sum())
+        if total > recv.numel():
+            self._recv = recv = torch.empty(total, dtype=local.dtype, device=local.device)
+        self.ops.msd_partition(local, send, n, b)                         # step 3
+
+        # step 4: own bucket by a device copy, the others as one P2P batch
+        r = self.rank
+        recv[ro[r]:ro[r] + rc[r]].copy_(send[so[r]:so[r] + sc[r]])
+        ops = []
+        for k in range(1, self.world):
+            dst, src = (r + k) % self.world, (r - k) % self.world
+            if sc[dst] > 0:
+                ops.append(dist.P2POp(dist.isend, send[so[dst]:so[dst] + sc[dst]], dst, self.group))
+            if rc[src] > 0:
+                ops.append(dist.P2POp(dist.irecv, recv[ro[src]:ro[src] + rc[src]], src, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if total > 0:
+            self.ops.sort_inplace(recv, total)                            # step 5
+        return recv, total

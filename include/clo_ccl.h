@@ -51,6 +51,12 @@ CCLContext* ccl_context_new_gpu(GError** err);
 CCLContext* ccl_context_new_from_menu_full(void* dev_idx_ptr, GError** err);
 /* Not in cf4ocl2: context on HIP device `device_index`. */
 CCLContext* ccl_context_new_from_device_index(int device_index, GError** err);
+/* Not in cf4ocl2: a context with no device behind it. Sorters and scanners can
+ * be constructed on it and introspected (option validation, kernel names, key
+ * parsing) — nothing that touches a GPU; creating a queue or a buffer on it
+ * fails with a CCL_HIP_ERROR. Lets host-side logic be tested on machines
+ * without a GPU; it is never a compute path. */
+CCLContext* ccl_context_new_offline(GError** err);
 void ccl_context_ref(CCLContext* ctx);
 void ccl_context_unref(CCLContext* ctx);
 void ccl_context_destroy(CCLContext* ctx);

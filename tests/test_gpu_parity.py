@@ -273,3 +273,123 @@ def test_profiler_reports_exec_queue_time(gpu):
     prof.close()
     s.close()
     assert 1000 < ns < 5e9
+
+
+# ----------------------------------------------------------------------------
+# MSD bucket split used by the multi-GPU exchange (C-ABI: clo_hip_msd_*)
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("bits", [1, 2, 3])
+@pytest.mark.parametrize("dt", [np.uint32, np.uint64])
+def test_msd_histogram_and_partition(gpu, bits, dt):
+    import ctypes as C
+    import cl_ops_amd as clo
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    ctx, q = gpu
+    n = 200003
+    a = rand_u32(np.random.default_rng(bits), n) if dt == np.uint32 else rand_u64(np.random.default_rng(bits), n)
+    es, kb = a.dtype.itemsize, 8 * a.dtype.itemsize
+    src, dst = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, a.nbytes)
+    cnt = clo.Buffer(ctx, 8 << bits)
+    ws_bytes = lib.clo_hip_msd_workspace_bytes(n, es, bits)
+    ws = clo.Buffer(ctx, ws_bytes)
+    src.write(q, a)
+    _hip.check(lib.clo_hip_msd_histogram(src.ptr, n, es, 0, kb, bits, cnt.ptr, q.stream))
+    _hip.check(lib.clo_hip_msd_partition(src.ptr, dst.ptr, n, es, 0, kb, bits, ws.ptr, ws_bytes, q.stream))
+    bucket = (a >> a.dtype.type(kb - bits)).astype(np.int64)
+    assert np.array_equal(cnt.read(q, np.uint64, 1 << bits), np.bincount(bucket, minlength=1 << bits).astype(np.uint64))
+    assert np.array_equal(dst.read(q, a.dtype, n), a[np.argsort(bucket, kind="stable")])
+    assert lib.clo_hip_check_status(ws.ptr, q.stream) == 0
+    for b in (src, dst, cnt, ws):
+        b.close()
+
+
+def test_sharded_sorter_world_size_one_uses_the_hip_ops(gpu):
+    import torch
+    from cl_ops_amd.multigpu import HipLocalOps, ShardedSorter
+    a = rand_u32(np.random.default_rng(1), 1 << 18)
+    t = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    ops = HipLocalOps("uint", 0)
+    out, m = ShardedSorter(ops).sort(t)
+    torch.cuda.synchronize()
+    assert m == a.size and np.array_equal(out.cpu().numpy().view(np.uint32), np.sort(a))
+    ops.close()
+
+
+# ----------------------------------------------------------------------------
+# BASELINE.json's full sizes, through size-independent properties
+# ----------------------------------------------------------------------------
+
+def _xor_sum(a):
+    return int(np.bitwise_xor.reduce(a)), int(a.sum(dtype=np.uint64))
+
+
+def test_full_size_satradix_u32_2p28(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 28
+    a = np.random.default_rng(28).integers(0, 1 << 32, n, dtype=np.uint32)
+    s = clo.Sorter("satradix", ctx, "uint")
+    src, dst = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, a.nbytes)
+    src.write(q, a)
+    s.with_device_data(q, src, dst, n)
+    got = dst.read(q, np.uint32, n)
+    assert bool(np.all(got[:-1] <= got[1:]))                 # the reference's own check
+    assert _xor_sum(got) == _xor_sum(a)                      # same multiset (checksum of checksums)
+    # exact equality with the CPU sort on a contiguous sample of the rank space
+    assert np.array_equal(got[: 1 << 20], np.sort(a[a <= got[(1 << 20) - 1]])[: 1 << 20])
+    s.with_device_data(q, dst, None, n)                      # idempotence, in place
+    assert np.array_equal(dst.read(q, np.uint32, n), got)
+    for b in (src, dst):
+        b.close()
+    s.close()
+
+
+def test_full_size_satradix_pairs_2p28(gpu):
+    """Config 4: 2^28 (uint key, uint value) pairs; stable == values increase inside equal-key runs."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 28
+    keys = np.random.default_rng(4).integers(0, 1 << 26, n, dtype=np.uint64)   # ~4 duplicates per key
+    a = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    del keys
+    s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    src = clo.Buffer(ctx, a.nbytes)
+    src.write(q, a)
+    chk = _xor_sum(a)
+    del a
+    s.with_device_data(q, src, None, n)
+    got = src.read(q, np.uint64, n)
+    k, v = got >> np.uint64(32), got & np.uint64(0xFFFFFFFF)
+    assert bool(np.all(k[:-1] <= k[1:]))
+    assert bool(np.all((k[:-1] != k[1:]) | (v[:-1] < v[1:])))   # stability
+    assert _xor_sum(got) == chk
+    src.close()
+    s.close()
+
+
+def test_full_size_scan_2p26(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 26
+    a = O.scan_bench_rand(0, np.uint32, 1 << 20)
+    a = np.tile(a, n >> 20)
+    for st, sdt in (("uint", np.uint32), ("ulong", np.uint64)):
+        sc = clo.Scanner("blelloch", ctx, "uint", st)
+        got = sc.with_host_data(a, q)
+        sc.close()
+        assert got[0] == 0
+        assert np.array_equal(np.diff(got.astype(np.uint64)).astype(np.uint32), a[:-1])   # out[i+1]-out[i] == in[i]
+        assert int(got[-1]) + int(a[-1]) == int(a.sum(dtype=np.uint64)) % (1 << (8 * np.dtype(sdt).itemsize))
+
+
+def test_full_size_abitonic_2p26(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 26
+    a = np.random.default_rng(26).integers(0, 1 << 32, n, dtype=np.uint32)
+    s = clo.Sorter("abitonic", ctx, "uint")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert bool(np.all(got[:-1] <= got[1:])) and _xor_sum(got) == _xor_sum(a)
