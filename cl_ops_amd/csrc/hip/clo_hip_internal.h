@@ -30,6 +30,7 @@ struct clo_timing_scope {
 // Chain-free radix path for digits of <= 4 bits (clo_hip_radix4.hip).
 size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int digit_bits);
 int clo_radix4_set_log_tile(int log_tile);
+int clo_radix4_set_match(int on);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
 	int key_bits, int digit_bits, void* ws, hipStream_t s);
 

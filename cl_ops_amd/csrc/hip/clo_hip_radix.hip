@@ -580,10 +580,12 @@ int clo_hip_radix_set_debug_buffer(void* dptr) {
 int clo_hip_radix_set_variant(int variant) {
 	// 0: default (chain-free path for digits <= 4 bits, look-back path above);
 	// 1, 2: other tile shapes of the look-back path; 3: look-back path always
-	// 4: default path with 8192-element tiles for 4-byte elements (default 4096)
-	if (variant < 0 || variant > 4) return CLO_HIP_EARGS;
+	// 4: default path with 8192-element tiles for 4-byte elements (default 4096);
+	// 5: default path with the match-any kernels instead of the packed-counter ones
+	if (variant < 0 || variant > 5) return CLO_HIP_EARGS;
 	clo_radix4_set_log_tile(variant == 4 ? 13 : 12);
-	if (variant == 4) variant = 0;
+	clo_radix4_set_match(variant == 4 || variant == 5);
+	if (variant >= 4) variant = 0;
 	const char* x = getenv("CLO_RADIX_XFLAGS");
 	g_xflags = x ? (unsigned) atoi(x) : 0u;
 	g_variant = variant;

@@ -34,6 +34,7 @@ template <int LT> struct r4_shape {
 	static constexpr int TILE = 1 << LT;
 	static constexpr int LOG_TILE = LT;
 };
+int g_r4_match = 0;      // 1: use the match-any kernels instead of the packed-counter ones (A/B runs)
 int g_r4_log_tile4 = 12;  // tile shape for 4-byte elements: 4096 measured faster than 8192 (occupancy)
 
 // Lanes of the wave holding the same digit as the caller (match-any by one
@@ -287,6 +288,256 @@ void clo_radix4_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 }
 
 // ---------------------------------------------------------------------------
+// Packed-counter variant of the two kernels above (the default).
+//
+// The match-any ranking costs ~40 VALU instructions per element (one ballot
+// and a 64-bit select/and per digit bit, per element); profiling showed the
+// pass kernel VALU-bound (SQ_INSTS_VALU = 85 per element). Here each thread
+// owns ITEMS = 8 CONSECUTIVE elements and counts digits in thread-private
+// packed counters (16 digits x 4 bits in two VGPRs), which also yield each
+// element's rank among the thread's own elements. One wave64 DPP scan of the
+// widened counters (16 digits x 16 bits in 8 VGPRs: 6 v_add_dpp each) plus a
+// cross-wave step through LDS gives, per thread, the exclusive count of every
+// digit among all earlier threads of the tile. Thread order = element order,
+// so the ranking is stable.
+// ---------------------------------------------------------------------------
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_add(unsigned x) {
+	return x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true);
+}
+
+// Inclusive scan over the 64 lanes with DPP: row_shr 1,2,4,8 inside rows of
+// 16, then row_bcast:15 (into rows 1,3) and row_bcast:31 (into rows 2,3).
+__device__ __forceinline__ unsigned wave_scan_dpp(unsigned x) {
+	x = dpp_add<0x111, 0xF>(x);
+	x = dpp_add<0x112, 0xF>(x);
+	x = dpp_add<0x114, 0xF>(x);
+	x = dpp_add<0x118, 0xF>(x);
+	x = dpp_add<0x142, 0xA>(x);
+	x = dpp_add<0x143, 0xC>(x);
+	return x;
+}
+
+// Thread-private digit counters: digit q lives in bits [4q, 4q+4) of lo (q < 8)
+// or hi (q >= 8). Good for up to 15 elements per thread.
+struct packed4 {
+	unsigned lo, hi;
+};
+
+// Count one digit; returns how many equal digits this thread counted before.
+template <int BITS>
+__device__ __forceinline__ unsigned packed4_count(packed4& c, unsigned d) {
+	const unsigned sh = (d & 7u) * 4u;
+	unsigned prev;
+	if (BITS <= 3) {
+		prev = (c.lo >> sh) & 15u;
+		c.lo += 1u << sh;
+	} else {
+		const bool up = d >= 8u;
+		prev = ((up ? c.hi : c.lo) >> sh) & 15u;
+		const unsigned inc = 1u << sh;
+		c.lo += up ? 0u : inc;
+		c.hi += up ? inc : 0u;
+	}
+	return prev;
+}
+
+template <int BITS> struct pc_words { static constexpr int H = (1 << BITS) >= 2 ? (1 << BITS) / 2 : 1; };
+
+// Widen to 16-bit fields: w[j] = count(2j) | count(2j+1) << 16.
+template <int BITS>
+__device__ __forceinline__ void packed4_widen(const packed4& c, unsigned (&w)[pc_words<BITS>::H]) {
+	#pragma unroll
+	for (int j = 0; j < pc_words<BITS>::H; ++j) {
+		const unsigned x = j < 4 ? c.lo : c.hi;
+		const int q = (j & 3) * 8;
+		w[j] = ((x >> q) & 15u) | (((x >> (q + 4)) & 15u) << 16);
+	}
+}
+
+template <typename E, int ITEMS>
+__device__ __forceinline__ void load_blocked(const E* __restrict__ p, E (&key)[ITEMS], bool aligned) {
+	if (aligned) {
+		typedef E vecN __attribute__((ext_vector_type(ITEMS)));
+		const vecN v = *reinterpret_cast<const vecN*>(p);
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = v[i];
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = p[i];
+	}
+}
+
+template <typename E, int BITS, int LT>
+__global__ __launch_bounds__(R4_THREADS)
+void clo_radix4_tilehist_pc_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
+	unsigned* __restrict__ thist, int aligned) {
+	constexpr int R = 1 << BITS;
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int ITEMS = r4_shape<LT>::ITEMS;
+	constexpr int TILE = r4_shape<LT>::TILE;
+	static_assert(ITEMS <= 15, "4-bit thread-private counters");
+	__shared__ unsigned s_wtot[R4_WAVES][H];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const size_t base = (size_t) blockIdx.x * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	const unsigned tbase = tid * ITEMS;
+	packed4 c = { 0u, 0u };
+	if (count == (unsigned) TILE) {
+		E key[ITEMS];
+		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) packed4_count<BITS>(c, (unsigned) (key[i] >> shift) & mask);
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i)
+			if (tbase + i < count) packed4_count<BITS>(c, (unsigned) (in[base + tbase + i] >> shift) & mask);
+	}
+	unsigned w[H];
+	packed4_widen<BITS>(c, w);
+	#pragma unroll
+	for (int j = 0; j < H; ++j) {
+		const unsigned tot = wave_scan_dpp(w[j]);
+		if (lane == 63) s_wtot[wave][j] = tot;
+	}
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned h = 0;
+		#pragma unroll
+		for (int wv = 0; wv < R4_WAVES; ++wv) h += (s_wtot[wv][tid >> 1] >> ((tid & 1u) * 16u)) & 0xffffu;
+		thist[(size_t) blockIdx.x * R + tid] = h;
+	}
+}
+
+template <typename E, int BITS, int LT>
+__global__ __launch_bounds__(R4_THREADS)
+void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
+	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
+	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff,
+	unsigned* __restrict__ thist_next, int aligned) {
+
+	constexpr int R = 1 << BITS;
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int ITEMS = r4_shape<LT>::ITEMS;
+	constexpr int TILE = r4_shape<LT>::TILE;
+	constexpr int LOG_TILE = r4_shape<LT>::LOG_TILE;
+	constexpr int SCR = H | 1;       // per-thread scratch stride in dwords, odd: conflict-free
+	static_assert(ITEMS <= 15, "4-bit thread-private counters");
+	static_assert(TILE <= 65536 / 2, "16-bit positions");
+
+	__shared__ E s_stage[TILE];
+	__shared__ unsigned s_scr[R4_THREADS * SCR];   // per thread: tile-local start of its slice of each digit (16-bit fields)
+	__shared__ unsigned s_wtot[R4_WAVES][H];       // wave totals
+	__shared__ unsigned s_wbase[R4_WAVES][H];      // digit start + totals of earlier waves
+	__shared__ unsigned s_next[R][2][R];           // [digit][destination tile 0/1][next digit]
+	__shared__ unsigned s_delta[R];                // global index = tile-local position + delta[digit]
+	__shared__ unsigned s_comb[R];                 // s_next row of (digit, destination tile t) = t*R + comb[digit]
+	__shared__ unsigned s_dstart16[H];             // tile-local digit starts, packed like the counters
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned tile = blockIdx.x;
+	const size_t base = (size_t) tile * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	const bool full = count == (unsigned) TILE;
+	const unsigned tbase = tid * ITEMS;
+
+	// ---- 1. load: ITEMS consecutive elements per thread (16-byte vector loads) ----
+	E key[ITEMS];
+	if (full) {
+		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
+	}
+
+	// tile bookkeeping from the scanned counters (upstream's offsets / counters_sum)
+	for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) (&s_next[0][0][0])[i] = 0;
+	if (tid < 64) {
+		const unsigned h = tid < (unsigned) R ? thist[(size_t) tile * R + tid] : 0u;
+		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
+		const unsigned odd = (unsigned) __shfl((int) dstart, (int) (lane | 1u), 64);
+		if (tid < (unsigned) R) {
+			const unsigned goff = toff[(size_t) tile * R + tid];
+			s_delta[tid] = goff - dstart;
+			s_comb[tid] = tid * 2u * R - ((goff >> LOG_TILE) << BITS);
+			if ((tid & 1u) == 0) s_dstart16[tid >> 1] = dstart | ((R > 1 ? odd : 0u) << 16);
+		}
+	}
+
+	// ---- 2a. thread-private digit counts; rank of each element among the thread's own ----
+	packed4 c = { 0u, 0u };
+	unsigned lrank = 0;   // 4 bits per element
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		if (full || tbase + i < count)
+			lrank |= packed4_count<BITS>(c, (unsigned) (key[i] >> shift) & mask) << (4 * i);
+	}
+
+	// ---- 2b. count of every digit among all earlier threads of the tile ----
+	unsigned w[H];
+	packed4_widen<BITS>(c, w);
+	#pragma unroll
+	for (int j = 0; j < H; ++j) {
+		const unsigned incl = wave_scan_dpp(w[j]);
+		if (lane == 63) s_wtot[wave][j] = incl;
+		w[j] = incl - w[j];   // exclusive within the wave
+	}
+	__syncthreads();
+	if (tid < R4_WAVES * H) {
+		const unsigned wv = tid / H, j = tid % H;
+		unsigned run = s_dstart16[j];
+		for (unsigned k = 0; k < wv; ++k) run += s_wtot[k][j];
+		s_wbase[wv][j] = run;
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int j = 0; j < H; ++j) s_scr[tid * SCR + j] = w[j] + s_wbase[wave][j];
+
+	// ---- 4a. scatter into the LDS stage in digit order ----
+	const unsigned short* my16 = reinterpret_cast<const unsigned short*>(&s_scr[tid * SCR]);
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		if (full || tbase + i < count) {
+			const unsigned d = (unsigned) (key[i] >> shift) & mask;
+			const unsigned pos = (unsigned) my16[d] + ((lrank >> (4 * i)) & 15u);
+			s_stage[pos] = key[i];
+		}
+	}
+	__syncthreads();
+
+	// ---- 4b. contiguous runs to HBM; 5. next digit's per-tile histogram ----
+	#pragma unroll
+	for (int j = 0; j < ITEMS; ++j) {
+		const unsigned p = j * R4_THREADS + tid;
+		if (full || p < count) {
+			const E e = s_stage[p];
+			const unsigned d = (unsigned) (e >> shift) & mask;
+			const unsigned gi = p + s_delta[d];
+			if ((size_t) gi < n) {
+				out[gi] = e;
+				if (has_next) {
+					const unsigned row = ((gi >> LOG_TILE) << BITS) + s_comb[d];   // (digit*2 + tile 0/1) * R
+					atomicAdd(&(&s_next[0][0][0])[(row + ((unsigned) (e >> next_shift) & next_mask)) & (2u * R * R - 1u)], 1u);
+				}
+			}
+		}
+	}
+	if (has_next) {
+		__syncthreads();
+		// 16 consecutive lanes = the 16 counters of one destination tile (64 B)
+		for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) {
+			const unsigned v = (&s_next[0][0][0])[i];
+			if (v) {
+				const unsigned d = i / (2 * R), half = (i / R) & 1u, dn = i % R;
+				const unsigned first = (d * 2u * R - s_comb[d]) >> BITS;
+				atomicAdd(&thist_next[(size_t) (first + half) * R + dn], v);
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 
@@ -325,10 +576,17 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	if (e != hipSuccess) return (int) e;
 
 	const unsigned bits0 = key_bits < BITS ? key_bits : BITS;
+	const bool use_pc = !g_r4_match && LT == 12;
 	{
 		clo_timing_scope timing("radix_hist", s);
-		hipLaunchKernelGGL((clo_radix4_tilehist_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-			src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist);
+		if (use_pc) {
+			if constexpr (LT == 12)
+				hipLaunchKernelGGL((clo_radix4_tilehist_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+					src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist, (int) ((uintptr_t) src % 16 == 0));
+		} else {
+			hipLaunchKernelGGL((clo_radix4_tilehist_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+				src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist);
+		}
 	}
 
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
@@ -352,10 +610,19 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		}
 		{
 			clo_timing_scope timing("radix_pass", s);
-			hipLaunchKernelGGL((clo_radix4_pass_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-				cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
-				has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
-				(const unsigned*) th, (const unsigned*) toff, th + per_pass);
+			if (use_pc) {
+				if constexpr (LT == 12)
+					hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+						cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
+						has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
+						(const unsigned*) th, (const unsigned*) toff, th + per_pass,
+						(int) ((uintptr_t) cur_in % 16 == 0));
+			} else {
+				hipLaunchKernelGGL((clo_radix4_pass_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+					cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
+					has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
+					(const unsigned*) th, (const unsigned*) toff, th + per_pass);
+			}
 		}
 		cur_in = cur_out;
 	}
@@ -390,6 +657,11 @@ size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int dig
 int clo_radix4_set_log_tile(int log_tile) {
 	if (log_tile != 12 && log_tile != 13) return CLO_HIP_EARGS;
 	g_r4_log_tile4 = log_tile;
+	return 0;
+}
+
+int clo_radix4_set_match(int on) {
+	g_r4_match = on != 0;
 	return 0;
 }
 

@@ -117,12 +117,12 @@ def main():
     q = clo.Queue(ctx)
     print("device:", ctx.device_name, flush=True)
     if "radix" in what:
-        for v in (0, 4):
+        for v in (0, 5):
             probe_radix(ctx, q, 28, "uint", v)
         probe_radix(ctx, q, 24, "uint", 0)
         probe_radix(ctx, q, 28, "uint", 0, radix=256)
     if "pairs" in what:
-        for v in (0, 3):
+        for v in (0, 5):
             probe_radix(ctx, q, 28, "ulong", v, pairs=True)
         probe_radix(ctx, q, 28, "ulong", 0)
     if "scan" in what:
