@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
@@ -50,17 +51,31 @@ __device__ __forceinline__ unsigned long long okey(E e, const key_desc& kd) {
 }
 
 // Compare-exchange with the reference's rule (abitonic.cl:31-38).
-template <typename E>
+// MODE 0: any key (shift/mask/typed compare). MODE 1 / 2: the key is the whole
+// element, unsigned / signed integer: equal keys are equal elements, so the
+// exchange is min/max (2 VALU + 2 selects instead of ~20); a descending
+// compare is the ascending one with the direction bit flipped.
+template <typename E, int MODE>
 __device__ __forceinline__ void cmpxch(E& a, E& b, unsigned dir, const key_desc& kd) {
-	const unsigned long long ka = okey<E>(a, kd), kb = okey<E>(b, kd);
-	const bool cmp = kd.descending ? (ka < kb) : (ka > kb);
-	if (cmp != (bool) dir) { const E t = a; a = b; b = t; }
+	if (MODE == 0) {
+		const unsigned long long ka = okey<E>(a, kd), kb = okey<E>(b, kd);
+		const bool cmp = kd.descending ? (ka < kb) : (ka > kb);
+		if (cmp != (bool) dir) { const E t = a; a = b; b = t; }
+	} else {
+		typedef typename std::make_signed<E>::type S;
+		E lo, hi;
+		if (MODE == 1) { lo = a < b ? a : b; hi = a < b ? b : a; }
+		else { lo = (S) a < (S) b ? a : b; hi = (S) a < (S) b ? b : a; }
+		const bool up = (dir ^ kd.descending) == 0;
+		a = up ? lo : hi;
+		b = up ? hi : lo;
+	}
 }
 
 // Up to log2(V) steps on the V values of one thread: strides 2^(nsteps-1) .. 1
 // (the register networks of abitonic.cl:163-224, any size). Value j sits at
 // element index idx0 | (j << b0); its direction bit is bit S of that index.
-template <typename E, int V>
+template <typename E, int V, int MODE>
 __device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, unsigned b0, unsigned S,
 	const key_desc& kd) {
 	const unsigned dbase = (unsigned) ((idx0 >> S) & 1);
@@ -73,7 +88,7 @@ __device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, 
 			for (int j = 0; j < V; ++j)
 				if ((j & half) == 0) {
 					const unsigned dir = dsel ? (((unsigned) j & dsel) ? 1u : 0u) : dbase;
-					cmpxch<E>(v[j], v[j + half], dir, kd);
+					cmpxch<E, MODE>(v[j], v[j + half], dir, kd);
 				}
 		}
 	}
@@ -90,12 +105,12 @@ void clo_bitonic_step_kernel(E* __restrict__ data, size_t npairs, unsigned stage
 	const size_t i2 = i1 + ((size_t) 1 << sh);
 	E a = data[i1], b = data[i2];
 	const E a0 = a, b0 = b;
-	cmpxch<E>(a, b, (unsigned) ((i1 >> stage) & 1), kd);
+	cmpxch<E, 0>(a, b, (unsigned) ((i1 >> stage) & 1), kd);
 	if (a != a0 || b != b0) { data[i1] = a; data[i2] = b; }
 }
 
 // ---- strided register kernel: steps p .. p-NS+1 of stage S, p-NS >= 6 ----
-template <typename E, int NS>
+template <typename E, int NS, int MODE>
 __global__ __launch_bounds__(256)
 void clo_bitonic_strided_kernel(E* __restrict__ data, size_t n, unsigned stage, unsigned p, key_desc kd) {
 	constexpr int V = 1 << NS;
@@ -106,7 +121,7 @@ void clo_bitonic_strided_kernel(E* __restrict__ data, size_t n, unsigned stage, 
 	E v[V];
 	#pragma unroll
 	for (int j = 0; j < V; ++j) v[j] = data[base + ((size_t) j << b0)];
-	reg_network<E, V>(v, NS, base, b0, stage, kd);
+	reg_network<E, V, MODE>(v, NS, base, b0, stage, kd);
 	#pragma unroll
 	for (int j = 0; j < V; ++j) data[base + ((size_t) j << b0)] = v[j];
 }
@@ -115,7 +130,7 @@ void clo_bitonic_strided_kernel(E* __restrict__ data, size_t n, unsigned stage, 
 // Q register bits, 256 threads, tile = 2^(8+Q) elements max; kl = log2 of the
 // tile actually used (Q <= kl <= 8+Q). mode 0: run steps p_hi..1 of `stage`;
 // mode 1: run all of stages 1..stage (stage <= kl).
-template <typename E, int Q>
+template <typename E, int Q, int MODE>
 __global__ __launch_bounds__(256)
 void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, int mode, key_desc kd) {
 	constexpr int V = 1 << Q;
@@ -159,7 +174,7 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 				}
 				cur_b0 = (int) b0;
 			}
-			if (tid < nthr) reg_network<E, V>(v, nsteps, gbase + base, b0, S, kd);
+			if (tid < nthr) reg_network<E, V, MODE>(v, nsteps, gbase + base, b0, S, kd);
 			p = b0;
 		}
 	}
@@ -252,16 +267,16 @@ int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_
 	return (int) hipGetLastError();
 }
 
-template <typename E, int NS>
+template <typename E, int NS, int MODE>
 void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_desc& kd, hipStream_t s) {
 	const size_t threads = n >> NS;
 	clo_timing_scope timing("bitonic_strided", s);
-	hipLaunchKernelGGL((clo_bitonic_strided_kernel<E, NS>), dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, s,
+	hipLaunchKernelGGL((clo_bitonic_strided_kernel<E, NS, MODE>), dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, s,
 		data, n, stage, p, kd);
 }
 
-template <typename E>
-int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
+template <typename E, int MODE>
+int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, hipStream_t s) {
 	// register bits per thread: 32 values of <= 4 bytes, 16 values of 8 bytes
 	constexpr int Q = sizeof(E) == 8 ? 4 : 5;
@@ -281,8 +296,8 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 	int count = 0;
 	// stages 1..kl inside the tiles
 	{
-		clo_timing_scope timing("bitonic_tile", s);
-		hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
+		clo_timing_scope timing("bitonic_presort", s);
+		hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
 	}
 	++count;
 	for (unsigned stage = kl + 1; stage <= T; ++stage) {
@@ -291,12 +306,12 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 			unsigned ns = p - kl;
 			if (ns > (unsigned) Q) ns = Q;
 			switch (ns) {
-				case 1: launch_strided<E, 1>(data, n, stage, p, kd, s); break;
-				case 2: launch_strided<E, 2>(data, n, stage, p, kd, s); break;
-				case 3: launch_strided<E, 3>(data, n, stage, p, kd, s); break;
-				case 4: launch_strided<E, 4>(data, n, stage, p, kd, s); break;
+				case 1: launch_strided<E, 1, MODE>(data, n, stage, p, kd, s); break;
+				case 2: launch_strided<E, 2, MODE>(data, n, stage, p, kd, s); break;
+				case 3: launch_strided<E, 3, MODE>(data, n, stage, p, kd, s); break;
+				case 4: launch_strided<E, 4, MODE>(data, n, stage, p, kd, s); break;
 				default:
-					if constexpr (Q >= 5) launch_strided<E, 5>(data, n, stage, p, kd, s);
+					if constexpr (Q >= 5) launch_strided<E, 5, MODE>(data, n, stage, p, kd, s);
 					break;
 			}
 			++count;
@@ -304,12 +319,23 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 		}
 		{
 			clo_timing_scope timing("bitonic_tile", s);
-			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q>), dim3(tiles), dim3(256), 0, s, data, kl, stage, kl, 0, kd);
+			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, stage, kl, 0, kd);
 		}
 		++count;
 	}
 	if (launches) *launches = count;
 	return (int) hipGetLastError();
+}
+
+template <typename E>
+int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, hipStream_t s) {
+	const bool identity = key_shift == 0 && key_bits == 8 * (int) sizeof(E) && key_size == (int) sizeof(E);
+	if (identity && key_kind == 0)
+		return tiled_run<E, 1>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+	if (identity && key_kind == 1)
+		return tiled_run<E, 2>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+	return tiled_run<E, 0>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
 }
 
 }  // namespace

@@ -175,7 +175,7 @@ __device__ __forceinline__ void radix_pass_body(radix_smem<E, BITS, THREADS, ITE
 	constexpr int WAVES = THREADS / 64;
 	constexpr int STAGE = THREADS * ITEMS / ROUNDS;
 	constexpr int LBW = THREADS / R;                 // threads per digit in the look-back window
-	constexpr int LBK = LBW >= 32 ? 1 : 32 / LBW;    // predecessors per thread (window = LBW * LBK >= 32)
+	constexpr int LBK = LBW >= 4 ? 1 : 4 / LBW;      // predecessors per thread (window = LBW * LBK >= 4)
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const unsigned wbase = wave * 64u * ITEMS + lane;
 	#define CLO_STAMP(k) do { if (dbg && tid == 0 && tile < 32768u) dbg[(size_t) tile * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)

@@ -124,15 +124,29 @@ void clo_radix4_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 	__shared__ unsigned s_total[R];    // count of digit d in all chunks
 	__shared__ unsigned s_w[OFF_CHUNK / 64][R];
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	// every block re-derives its starting point from the chunk sums (<= a few KB)
-	if (tid < (unsigned) R) { s_before[tid] = 0; s_total[tid] = 0; }
-	__syncthreads();
-	for (unsigned i = tid; i < chunks * R; i += OFF_CHUNK) {
-		const unsigned c = i / R, d = i % R, v = partial[i];
-		if (v) {
-			atomicAdd(&s_total[d], v);
-			if (c < blockIdx.x) atomicAdd(&s_before[d], v);
+	// every block re-derives its starting point from the chunk sums (<= a few KB):
+	// thread (g, d) sums digit d over chunks g, g+G, ... in registers, then the G
+	// groups are combined through LDS
+	constexpr int G = OFF_CHUNK / R;
+	__shared__ unsigned s_pb[G][R], s_pt[G][R];
+	{
+		const unsigned d = tid % R, g = tid / R;
+		unsigned before = 0, total = 0;
+		for (unsigned c = g; c < chunks; c += G) {
+			const unsigned v = partial[(size_t) c * R + d];
+			total += v;
+			if (c < blockIdx.x) before += v;
 		}
+		s_pb[g][d] = before;
+		s_pt[g][d] = total;
+	}
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned before = 0, total = 0;
+		#pragma unroll
+		for (int g = 0; g < G; ++g) { before += s_pb[g][tid]; total += s_pt[g][tid]; }
+		s_before[tid] = before;
+		s_total[tid] = total;
 	}
 	__syncthreads();
 	const unsigned t = blockIdx.x * OFF_CHUNK + tid;
