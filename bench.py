@@ -191,7 +191,6 @@ def main():
         if world > 1:
             from cl_ops_amd.multigpu import HipLocalOps, ShardedSorter
             sharded = ShardedSorter(HipLocalOps(etype, local_rank))
-            work = torch.empty_like(src)
     elif workload == "scan":
         op = clo.Scanner("blelloch", ctx, "uint", "uint")
     else:
@@ -199,8 +198,7 @@ def main():
 
     def step():
         if sharded is not None:
-            work.copy_(src)                      # fresh unsorted shard (device copy, inside the step)
-            return sharded.sort(work, n)
+            return sharded.sort(src, n)          # the shard is only read: histogram + partition into the send buffer
         if workload == "scan":
             op.with_device_data(q, bsrc, bdst, n)
         else:

@@ -19,6 +19,7 @@
 // CLO_SCAN_SUM_TYPE additions (blelloch.cl:79-124).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "clo_hip.h"
@@ -46,26 +47,38 @@ __device__ __forceinline__ void store4(T* p, const T (&v)[4]) {
 	*reinterpret_cast<vec4*>(p) = x;
 }
 
-// Look-back over predecessor tiles, run by wave 0 (all 64 lanes): lane l
-// inspects tile (idx - l). NG granules per tile carry the sum in 32-bit pieces.
+// One look-back window, run by wave 0 (all 64 lanes): lane l inspects entry
+// (idx - l) of `state` as long as it is >= lo. Waits until every inspected
+// entry nearer than the nearest inclusive prefix is published, then returns
+// their sum; *closed tells whether a prefix ended the window. Entries below
+// `lo` end the window: as a prefix of 0 if `floor_is_prefix`, else silently.
+// NG granules per entry carry the sum in 32-bit pieces.
 template <typename TSum, int NG>
-__device__ TSum scan_lookback(const clo_u64* state, unsigned tile, unsigned lane, unsigned* status) {
-	TSum excl = 0;
-	long idx = (long) tile - 1;
+__device__ __forceinline__ void scan_read_entry(const clo_u64* state, long j, unsigned& tag, TSum& val) {
+	const clo_u64 g0 = clo_ld_agent(&state[(size_t) j * 2]);
+	tag = clo_lb_tag(g0);
+	val = (TSum) clo_lb_val(g0);
+	if (NG == 2) {
+		const clo_u64 g1 = clo_ld_agent(&state[(size_t) j * 2 + 1]);
+		if (clo_lb_tag(g1) != tag) tag = 0;  // mid-update: poll again
+		val = (TSum) (((clo_u64) clo_lb_val(g1) << 32) | clo_lb_val(g0));
+	}
+}
+
+// `alt` (may be NULL): a second array consulted for entries whose `state`
+// granule is not published yet (super-tiles keep aggregates and prefixes in
+// two single-writer arrays).
+template <typename TSum, int NG>
+__device__ TSum scan_window(const clo_u64* state, const clo_u64* alt, long idx, long lo, bool floor_is_prefix,
+	unsigned lane, bool* closed, unsigned* status) {
 	unsigned spins = 0;
 	while (true) {
-		long j = idx - (long) lane;
-		unsigned tag = (1u << 2) | CLO_LB_PREFIX;  // tiles before 0: prefix 0
+		const long j = idx - (long) lane;
+		unsigned tag = (1u << 2) | (floor_is_prefix ? CLO_LB_PREFIX : CLO_LB_AGG);  // below lo: value 0
 		TSum val = 0;
-		if (j >= 0) {
-			clo_u64 g0 = clo_ld_agent(&state[(size_t) j * 2]);
-			tag = clo_lb_tag(g0);
-			val = (TSum) clo_lb_val(g0);
-			if (NG == 2) {
-				clo_u64 g1 = clo_ld_agent(&state[(size_t) j * 2 + 1]);
-				if (clo_lb_tag(g1) != tag) tag = 0;  // mid-update: poll again
-				val = (TSum) (((clo_u64) clo_lb_val(g1) << 32) | clo_lb_val(g0));
-			}
+		if (j >= lo) {
+			scan_read_entry<TSum, NG>(state, j, tag, val);
+			if (alt != nullptr && !((tag >> 2) == 1u && (tag & 3u) != 0u)) scan_read_entry<TSum, NG>(alt, j, tag, val);
 		}
 		const unsigned st = tag & 3u;
 		const bool valid = (tag >> 2) == 1u && st != 0u;
@@ -75,20 +88,56 @@ __device__ TSum scan_lookback(const clo_u64* state, unsigned tile, unsigned lane
 			const unsigned first = (unsigned) __ffsll((long long) pmask) - 1u;
 			const clo_u64 below = (first == 0) ? 0ull : ((~0ull) >> (64 - first));
 			if ((imask & below) == 0) {
-				excl += clo_wave_reduce_sum<TSum>(lane <= first ? val : (TSum) 0);
-				break;
+				*closed = true;
+				return clo_wave_reduce_sum<TSum>(lane <= first ? val : (TSum) 0);
 			}
 		} else if (imask == 0) {
-			excl += clo_wave_reduce_sum<TSum>(val);
-			idx -= 64;
-			continue;
+			*closed = false;
+			return clo_wave_reduce_sum<TSum>(val);
 		}
 		if (++spins > CLO_MAX_SPINS) {
 			if (lane == 0) atomicExch(status, 1u);
-			break;
+			*closed = true;
+			return 0;
 		}
 		__builtin_amdgcn_s_sleep(4);
 	}
+}
+
+// Two-level look-back. A running prefix handed tile to tile advances at most
+// one window (64 tiles) per poll round trip, and a round trip to another
+// XCD's granule costs microseconds under streaming load: measured, that chain
+// alone capped the scan at 0.14 ms for 4096 tiles (0.11 ms with the look-back
+// stubbed out). So tiles are grouped in super-tiles of 64: a tile sums the
+// AGGREGATES of the earlier tiles of its own super-tile (published as soon as
+// those tiles have loaded, no chain) and takes the prefix of its super-tile
+// from a second granule array that carries super-tile aggregates/prefixes
+// (64 super-tiles = 4096 tiles per window).
+constexpr int SCAN_SUPER_LOG = 6;
+
+template <typename TSum, int NG>
+__device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsigned st, TSum v);
+
+// Super-tile state lives in two arrays with one writer each (two writers on a
+// two-granule entry could leave a mixed pair): `sagg` gets the super-tile's
+// aggregate from whichever tile arrives 64th at the super-tile's accumulator,
+// `sprefix` gets its inclusive prefix from the super-tile's last tile.
+template <typename TSum, int NG>
+__device__ TSum scan_lookback2(clo_u64* tstate, clo_u64* sprefix, const clo_u64* sagg, unsigned tile, TSum aggregate,
+	unsigned lane, unsigned* status) {
+	const unsigned q = tile & ((1u << SCAN_SUPER_LOG) - 1u);
+	const long sup = (long) (tile >> SCAN_SUPER_LOG);
+	bool closed = false;
+	TSum excl = 0;
+	if (q != 0)
+		excl = scan_window<TSum, NG>(tstate, nullptr, (long) tile - 1, sup << SCAN_SUPER_LOG, false, lane, &closed, status);
+	long idx = sup - 1;
+	while (!closed) {
+		excl += scan_window<TSum, NG>(sprefix, sagg, idx, 0, true, lane, &closed, status);
+		idx -= 64;
+	}
+	if (q == (1u << SCAN_SUPER_LOG) - 1u && lane == 0)
+		scan_publish<TSum, NG>(sprefix, (unsigned) sup, CLO_LB_PREFIX, (TSum) (excl + aggregate));
 	return excl;
 }
 
@@ -105,7 +154,7 @@ __device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsi
 template <typename TIn, typename TOut, typename TSum, int ROWS>
 __global__ __launch_bounds__(SCAN_THREADS)
 void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n,
-	unsigned* hdr, clo_u64* state, int aligned) {
+	unsigned* hdr, clo_u64* state, clo_u64* sstate, clo_u64* sagg, clo_u64* sacc, int aligned, unsigned xflags) {
 
 	constexpr int ROW_ELEMS = SCAN_THREADS * SCAN_VEC;
 	constexpr int TILE = ROW_ELEMS * ROWS;
@@ -171,15 +220,38 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	}
 	const TSum aggregate = run;
 
-	// ---- chained prefix across tiles (wave 0) ----
+	// ---- prefix of the tile (wave 0): two-level decoupled look-back ----
 	if (wave == 0) {
 		TSum excl = 0;
-		if (tile == 0) {
-			if (lane == 0) scan_publish<TSum, NG>(state, 0, CLO_LB_PREFIX, aggregate);
-		} else {
-			if (lane == 0) scan_publish<TSum, NG>(state, tile, CLO_LB_AGG, aggregate);
-			excl = scan_lookback<TSum, NG>(state, tile, lane, &hdr[0]);
+		const bool first = tile == 0 || (xflags & 1u);
+		const unsigned sup = tile >> SCAN_SUPER_LOG;
+		if (lane == 0) {
+			scan_publish<TSum, NG>(state, tile, first ? CLO_LB_PREFIX : CLO_LB_AGG, aggregate);
+			// add the aggregate to the super-tile's accumulator; the 64th arrival publishes the total
+			bool last;
+			TSum total;
+			if (NG == 1) {
+				const clo_u64 old = __hip_atomic_fetch_add(&sacc[(size_t) sup * 2],
+					((clo_u64) aggregate << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				last = (unsigned) old == (1u << SCAN_SUPER_LOG) - 1u;
+				total = (TSum) ((unsigned) (old >> 32)) + aggregate;
+			} else {
+				// RETURNING add: its result coming back means the add has been performed at
+				// the memory side, so the sum is in before the arrival is counted
+				const clo_u64 before = __hip_atomic_fetch_add(&sacc[(size_t) sup * 2], (clo_u64) aggregate,
+					__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				asm volatile("s_waitcnt vmcnt(0)" :: "v"((unsigned) before) : "memory");
+				const clo_u64 cnt = __hip_atomic_fetch_add(&sacc[(size_t) sup * 2 + 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				last = cnt == (1ull << SCAN_SUPER_LOG) - 1ull;
+				total = last ? (TSum) clo_ld_agent(&sacc[(size_t) sup * 2]) : (TSum) 0;
+			}
+			if (last) scan_publish<TSum, NG>(sagg, sup, CLO_LB_AGG, total);
+		}
+		if (!first) {
+			excl = scan_lookback2<TSum, NG>(state, sstate, sagg, tile, aggregate, lane, &hdr[0]);
 			if (lane == 0) scan_publish<TSum, NG>(state, tile, CLO_LB_PREFIX, (TSum) (excl + aggregate));
+		} else if (tile == 0 && lane == 0 && (1u << SCAN_SUPER_LOG) == 1u) {
+			scan_publish<TSum, NG>(sstate, 0, CLO_LB_PREFIX, aggregate);
 		}
 		if (lane == 0) s_excl = excl;
 	}
@@ -207,6 +279,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	}
 }
 
+unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never set in production
+
 constexpr size_t scan_tile_elems(int sum_size) {
 	return (size_t) SCAN_THREADS * SCAN_VEC * (sum_size > 4 ? 8 : 16);
 }
@@ -222,12 +296,16 @@ int launch_scan(const void* in, void* out, size_t n, void* ws, hipStream_t s) {
 		const size_t tiles = (n + tile - 1) / tile;
 		unsigned* hdr = (unsigned*) ws;
 		clo_u64* state = (clo_u64*) ((char*) ws + CLO_WS_HEADER_BYTES);
+		const size_t supers = (tiles >> SCAN_SUPER_LOG) + 1;
+		clo_u64* sstate = state + tiles * 2;
+		clo_u64* sagg = sstate + supers * 2;
+		clo_u64* sacc = sagg + supers * 2;
 		const int aligned = ((uintptr_t) in % (4 * sizeof(TIn)) == 0) && ((uintptr_t) out % (4 * sizeof(TOut)) == 0);
-		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16, s);
+		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16 + supers * 48, s);
 		if (e != hipSuccess) return (int) e;
 		clo_timing_scope timing("scan", s);
 		hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS>), dim3((unsigned) tiles), dim3(SCAN_THREADS), 0, s,
-			(const TIn*) in, (TOut*) out, n, hdr, state, aligned);
+			(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags);
 		return (int) hipGetLastError();
 	}
 }
@@ -251,7 +329,8 @@ size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
 	(void) elem_size;
 	const size_t tile = scan_tile_elems(sum_size);
 	const size_t tiles = (numel + tile - 1) / tile;
-	return CLO_WS_HEADER_BYTES + (tiles ? tiles : 1) * 16;
+	const size_t t = tiles ? tiles : 1;
+	return CLO_WS_HEADER_BYTES + t * 16 + ((t >> SCAN_SUPER_LOG) + 1) * 48;
 }
 
 int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
@@ -261,6 +340,10 @@ int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
 	if (numel == 0) return 0;
 	if (!data_in || !data_out || !workspace) return CLO_HIP_EARGS;
 	if (sum_size < elem_size) return CLO_HIP_EUNSUPPORTED;
+	{
+		const char* x = getenv("CLO_SCAN_XFLAGS");
+		g_scan_xflags = x ? (unsigned) atoi(x) : 0u;
+	}
 	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
 	if (numel / scan_tile_elems(sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
 	hipStream_t s = (hipStream_t) stream;
