@@ -119,6 +119,24 @@ class ShardedSorter:
         recv_offsets = np.concatenate(([0], np.cumsum(recv_counts)[:-1]))
         return send_counts, send_offsets, recv_counts, recv_offsets
 
+    def exchange(self, send, recv, sc, so, rc, ro):
+        """All-to-all(v): own bucket by a device copy, the others as ONE batch of
+        send/recv pairs (RCCL: grouped ncclSend/ncclRecv, every pair on its own
+        xGMI link). Peers are visited in ring order so that all ranks post matching
+        operations in a compatible order."""
+        dist, r = self.dist, self.rank
+        recv[ro[r]:ro[r] + rc[r]].copy_(send[so[r]:so[r] + sc[r]])
+        ops = []
+        for k in range(1, self.world):
+            dst, src = (r + k) % self.world, (r - k) % self.world
+            if sc[dst] > 0:
+                ops.append(dist.P2POp(dist.isend, send[so[dst]:so[dst] + sc[dst]], dst, self.group))
+            if rc[src] > 0:
+                ops.append(dist.P2POp(dist.irecv, recv[ro[src]:ro[src] + rc[src]], src, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
     def sort(self, local, n=None):
         """Sorts the global array whose shards are `local[:n]` on each rank.
         Returns (tensor, m): this rank's bucket, sorted, in tensor[:m]."""
@@ -140,19 +158,7 @@ class ShardedSorter:
             self._recv = recv = torch.empty(total, dtype=local.dtype, device=local.device)
         self.ops.msd_partition(local, send, n, b)                         # step 3
 
-        # step 4: own bucket by a device copy, the others as one P2P batch
-        r = self.rank
-        recv[ro[r]:ro[r] + rc[r]].copy_(send[so[r]:so[r] + sc[r]])
-        ops = []
-        for k in range(1, self.world):
-            dst, src = (r + k) % self.world, (r - k) % self.world
-            if sc[dst] > 0:
-                ops.append(dist.P2POp(dist.isend, send[so[dst]:so[dst] + sc[dst]], dst, self.group))
-            if rc[src] > 0:
-                ops.append(dist.P2POp(dist.irecv, recv[ro[src]:ro[src] + rc[src]], src, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        self.exchange(send, recv, sc, so, rc, ro)                         # step 4
         if total > 0:
             self.ops.sort_inplace(recv, total)                            # step 5
         return recv, total

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path, called through the C-ABI (clo_sort_* /
 clo_scan_* of libcl_ops_hip.so), against the CPU oracle on the same seeded
 inputs. Bit-exact equality everywhere (integer/byte work)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -393,3 +395,61 @@ def test_full_size_abitonic_2p26(gpu):
     got = s.with_host_data(a, q)
     s.close()
     assert bool(np.all(got[:-1] <= got[1:])) and _xor_sum(got) == _xor_sum(a)
+
+
+# ----------------------------------------------------------------------------
+# two ranks sharing the one GPU of this box: HipLocalOps end to end. RCCL
+# refuses two ranks on one device, so this test (and only this test) stages the
+# exchange through host memory over gloo; everything else is the product path.
+# ----------------------------------------------------------------------------
+
+def _two_rank_worker(rank, world, port, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    from cl_ops_amd.multigpu import HipLocalOps, ShardedSorter
+
+    class HostStaged(ShardedSorter):
+        def exchange(self, send, recv, sc, so, rc, ro):
+            hs, hr = send.cpu(), torch.empty(recv.numel(), dtype=recv.dtype)
+            r = self.rank
+            hr[ro[r]:ro[r] + rc[r]] = hs[so[r]:so[r] + sc[r]]
+            ops = []
+            for k in range(1, self.world):
+                dst, src = (r + k) % self.world, (r - k) % self.world
+                if sc[dst] > 0:
+                    ops.append(dist.P2POp(dist.isend, hs[so[dst]:so[dst] + sc[dst]].contiguous(), dst))
+                if rc[src] > 0:
+                    ops.append(dist.P2POp(dist.irecv, hr[ro[src]:ro[src] + rc[src]], src))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            recv.copy_(hr)
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        a = np.random.default_rng(50 + rank).integers(0, 1 << 32, n, dtype=np.uint32)
+        local = torch.from_numpy(a.view(np.int32).copy()).cuda()
+        ops = HipLocalOps("uint", 0)
+        out, m = HostStaged(ops).sort(local, n)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), a)
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), out[:m].cpu().numpy().view(np.uint32))
+        assert np.array_equal(local.cpu().numpy().view(np.uint32), a)   # the shard is only read
+        ops.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_hip_ops_end_to_end(gpu, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, 300000, str(tmp_path)), nprocs=2, join=True)
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(2)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)]
+    assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
+    assert np.all(outs[0] >> 31 == 0) and np.all(outs[1] >> 31 == 1)
