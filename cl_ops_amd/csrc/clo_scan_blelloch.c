@@ -39,9 +39,6 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 		return NULL;
 	}
 
-	CCLEvent* evt = ccl_queue_begin_command(cq_exec, "clo_scan_blelloch_wgscan", err);
-	if (!evt) return NULL;
-
 	if (numel > 0) {
 		if (data->last_stream && data->last_stream != stream)
 			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
@@ -49,6 +46,12 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 		const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
 		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return NULL;
 		clo_debug("BLELLOCH: N=%zu elem=%dB sum=%dB workspace=%zuB", numel, es, ss, ws);
+	}
+
+	CCLEvent* evt = ccl_queue_begin_command(cq_exec, "clo_scan_blelloch_wgscan", err);
+	if (!evt) return NULL;
+
+	if (numel > 0) {
 		int st = clo_hip_scan_exclusive(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out),
 			numel, es, clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 			data->workspace.ptr, data->workspace.bytes, stream);

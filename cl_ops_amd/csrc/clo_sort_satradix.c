@@ -86,19 +86,21 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 	clo_debug("SATRADIX: radix=%u (bits_in_digit=%d), numel=%zu, key bits [%d,%d)",
 		data->radix, bits_in_digit, numel, ks->key_shift, ks->key_shift + ks->key_bits);
 
+	if (numel > 0) {
+		/* The cached buffers belong to one stream at a time. Reserved before the
+		 * command's start event so that (re)allocation is not timed as device work. */
+		if (data->last_stream && data->last_stream != stream)
+			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
+		data->last_stream = stream;
+		const size_t ws_bytes = clo_hip_radix_workspace_bytes(numel, ks->elem_size, ks->key_bits, bits_in_digit);
+		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, bytes), err, "hipMalloc(satradix aux)")) return NULL;
+		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws_bytes), err, "hipMalloc(satradix workspace)")) return NULL;
+	}
+
 	evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
 	if (!evt) return NULL;
 
 	if (numel > 0) {
-		/* The cached buffers belong to one stream at a time. */
-		if (data->last_stream && data->last_stream != stream)
-			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
-		data->last_stream = stream;
-
-		const size_t ws_bytes = clo_hip_radix_workspace_bytes(numel, ks->elem_size, ks->key_bits, bits_in_digit);
-		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, bytes), err, "hipMalloc(satradix aux)")) return NULL;
-		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws_bytes), err, "hipMalloc(satradix workspace)")) return NULL;
-
 		void* src = ccl_buffer_get_device_ptr(data_in);
 		void* dst = data_out ? ccl_buffer_get_device_ptr(data_out) : src;
 		int st = clo_hip_radix_sort(src, dst, data->tmp.ptr, numel, ks->elem_size, ks->key_shift,
