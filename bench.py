@@ -330,7 +330,8 @@ def main():
                                  "run right after the timed region" % args.steps},
         }
         if not args.no_cpu_baseline and world == 1:
-            default_sample = {"satradix_u32": 27, "satradix_pairs": 26, "satradix_u64": 25, "scan": 26,
+            # sized for about 10-30 core-seconds of CPU work
+            default_sample = {"satradix_u32": 28, "satradix_pairs": 27, "satradix_u64": 26, "scan": 26,
                               "abitonic": 20, "sbitonic": 16}[workload]
             out["cpu_baseline"] = cpu_baseline(workload, host, args.radix,
                                                args.cpu_sample_log2n or default_sample)
