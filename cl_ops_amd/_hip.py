@@ -64,6 +64,9 @@ _sig("clo_hip_bitonic_padded_numel", sz, sz)
 _sig("clo_hip_bitonic_simple", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_bitonic_tiled", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_kernel_lds_bytes", sz, C.c_char_p, ci, ci)
+_sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
+_sig("clo_hip_bitonic_jit_destroy", None, vp)
+_sig("clo_hip_bitonic_jit_sort", ci, vp, vp, sz, ci, C.POINTER(ci), vp)
 _sig("clo_hip_check_status", ci, vp, vp)
 _sig("clo_hip_timing_enable", ci, ci)
 _sig("clo_hip_timing_reset", ci)

@@ -62,6 +62,7 @@ _sig("ccl_context_new_from_device_index", vp, ci, _E)
 _sig("ccl_context_new_gpu", vp, _E)
 _sig("ccl_context_new_offline", vp, _E)
 _sig("clo_sort_get_key_spec", vp, vp)
+_sig("clo_sort_get_jit", vp, vp)
 _sig("ccl_context_destroy", None, vp)
 _sig("ccl_context_get_device", vp, vp, _u32, _E)
 _sig("ccl_device_get_index", ci, vp)

@@ -21,6 +21,7 @@ struct clo_sort {
 	CloType key_type;
 	void* data;
 	CloSortKeySpec spec;
+	void* jit;  /* hiprtc-specialised bitonic kernels, or NULL */
 };
 
 /* ------------------------------------------------------------------ */
@@ -205,20 +206,35 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Type 'half' is not supported by the HIP build");
 			goto error_handler;
 		}
-		if (!parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
-				"Unsupported get_key expression '%s' (supported: x, shifts, low-bit masks, integer casts)",
-				get_key ? get_key : "(x)");
-			goto error_handler;
-		}
-		if (ks->key_kind == 2 && (ks->key_shift != 0 || ks->key_bits != 8 * ks->key_size || ks->elem_size != ks->key_size)) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Floating point keys must be the whole element");
-			goto error_handler;
-		}
-		if (!parse_compare(compare, &ks->descending)) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
-				"Unsupported compare expression '%s' (supported: ((a) > (b)), ((a) < (b)))", compare);
-			goto error_handler;
+		const int is_bitonic = strcmp(type, "sbitonic") == 0 || strcmp(type, "abitonic") == 0;
+		const int key_ok = parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)
+			&& !(ks->key_kind == 2 && (ks->key_shift != 0 || ks->key_bits != 8 * ks->key_size || ks->elem_size != ks->key_size));
+		const int cmp_ok = parse_compare(compare, &ks->descending);
+		if (!key_ok || !cmp_ok) {
+			if (!is_bitonic) {
+				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
+					"Unsupported %s expression '%s' for %s (supported ahead of time: x, shifts, low-bit masks, "
+					"integer casts; ((a) > (b)), ((a) < (b)))", key_ok ? "compare" : "get_key",
+					key_ok ? compare : (get_key ? get_key : "(x)"), type);
+				goto error_handler;
+			}
+			/* what upstream does for every sorter: paste the two macro bodies into
+			 * the kernel source and build it (clo_sort_abstract.c:144-179) */
+			char* log = NULL;
+			int st = clo_hip_bitonic_jit_create((int) sorter->elem_type, (int) sorter->key_type, compare, get_key,
+				&sorter->jit, &log);
+			if (st != 0) {
+				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
+					"Could not build kernels for compare '%s' / get_key '%s': %s%s%.300s",
+					compare ? compare : "((a) > (b))", get_key ? get_key : "(x)", clo_hip_error_string(st),
+					log ? "\n" : "", log ? log : "");
+				free(log);
+				goto error_handler;
+			}
+			free(log);
+			ks->key_shift = 0;
+			ks->key_bits = 8 * ks->key_size;
+			ks->descending = 0;
 		}
 
 		const char* token = sorter->impl_def.init(sorter, options, &err_internal);
@@ -241,6 +257,7 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 error_handler:
 	if (sorter) {
 		/* finalize only what init created */
+		if (sorter->jit) clo_hip_bitonic_jit_destroy(sorter->jit);
 		if (sorter->data) sorter->impl_def.finalize(sorter);
 		ccl_context_unref(sorter->ctx);
 		ccl_program_destroy(sorter->prg);
@@ -252,6 +269,7 @@ error_handler:
 void clo_sort_destroy(CloSort* sorter) {
 	clo_return_if_fail(sorter != NULL);
 	sorter->impl_def.finalize(sorter);
+	if (sorter->jit) clo_hip_bitonic_jit_destroy(sorter->jit);
 	if (sorter->ctx) ccl_context_unref(sorter->ctx);
 	if (sorter->prg) ccl_program_destroy(sorter->prg);
 	free(sorter);
@@ -392,6 +410,11 @@ const char* clo_sort_get_kernel_name(CloSort* sorter, cl_uint i, GError** err) {
 size_t clo_sort_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max, size_t numel, GError** err) {
 	clo_return_val_if_fail(sorter != NULL, 0);
 	return sorter->impl_def.get_localmem_usage(sorter, i, lws_max, numel, err);
+}
+
+void* clo_sort_get_jit(CloSort* sorter) {
+	clo_return_val_if_fail(sorter != NULL, NULL);
+	return sorter->jit;
 }
 
 const CloSortKeySpec* clo_sort_get_key_spec(CloSort* sorter) {

@@ -47,7 +47,19 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 	evt = ccl_queue_begin_command(cq_exec, evt_name, err);
 	if (!evt) return NULL;
 
-	if (numel > 1) {
+	void* jit = clo_sort_get_jit(sorter);
+	if (numel > 1 && jit != NULL) {
+		/* kernels specialised at run time for the user's compare / get_key */
+		if (clo_hip_bitonic_padded_numel(numel) != numel) {
+			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
+				"bitonic sorts with a run-time compiled compare/get_key need a power-of-two numel");
+			return NULL;
+		}
+		int launches = 0;
+		int st = clo_hip_bitonic_jit_sort(jit, ccl_buffer_get_device_ptr(target), numel, tiled, &launches, stream);
+		if (clo_hip_failed(st, err, "clo_hip_bitonic_jit_sort")) return NULL;
+		clo_debug("%s (jit): numel=%zu launches=%d", evt_name, numel, launches);
+	} else if (numel > 1) {
 		const size_t padded = clo_hip_bitonic_padded_numel(numel);
 		void* work = ccl_buffer_get_device_ptr(target);
 		int use_pad = 0;

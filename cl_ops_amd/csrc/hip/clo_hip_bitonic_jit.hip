@@ -1,0 +1,305 @@
+// clo_hip_bitonic_jit.hip — bitonic sorts specialised at run time for arbitrary
+// `compare` / `get_key` expressions.
+//
+// Upstream specialises its kernels by JIT: the sorter constructor prepends
+//   #define CLO_SORT_ELEM_TYPE / CLO_SORT_KEY_TYPE / CLO_SORT_COMPARE(a,b) / CLO_SORT_KEY_GET(x)
+// to the OpenCL C source and builds it (sort/clo_sort_abstract.c:144-179). The
+// ahead-of-time kernels of clo_hip_bitonic.hip cover the common family (shifts,
+// masks, casts; a > b, a < b). Anything else takes this path: the same three
+// kernels (one step / strided register network / LDS tile — the schedule of
+// clo_hip_bitonic_tiled) are compiled with hiprtc for gfx950 with the user's
+// two macro bodies pasted in, exactly as upstream pastes them, and launched
+// through the module API. The macro bodies are C expressions over OpenCL's
+// scalar type names (uchar, ushort, uint, ulong are typedef'd for them).
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+namespace {
+
+// Device source. E/K are the element/key C types; Q = register bits per thread
+// of the tile kernel (5 for <= 4-byte elements, 4 for 8-byte ones).
+const char* k_src = R"CLOJIT(
+typedef unsigned char uchar;
+typedef unsigned short ushort;
+typedef unsigned int uint;
+typedef unsigned long ulong;
+typedef CLO_SORT_ELEM_TYPE E;
+typedef CLO_SORT_KEY_TYPE K;
+
+__device__ __forceinline__ void cmpxch(E& e1, E& e2, unsigned dir) {
+	const K a = (K) (CLO_SORT_KEY_GET_X(e1));
+	const K b = (K) (CLO_SORT_KEY_GET_X(e2));
+	const bool cmp = (bool) (CLO_SORT_COMPARE_AB(a, b));
+	if (cmp != (bool) dir) { const E t = e1; e1 = e2; e2 = t; }
+}
+
+template <int V>
+__device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, unsigned long idx0, unsigned b0, unsigned S) {
+	const unsigned dbase = (unsigned) ((idx0 >> S) & 1);
+	const unsigned dsel = (S >= b0 && S - b0 < 31u) ? ((1u << (S - b0)) & (unsigned) (V - 1)) : 0u;
+	#pragma unroll
+	for (int half = V / 2; half >= 1; half /= 2) {
+		if (half < (1 << nsteps)) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j)
+				if ((j & half) == 0) {
+					const unsigned dir = dsel ? (((unsigned) j & dsel) ? 1u : 0u) : dbase;
+					cmpxch(v[j], v[j + half], dir);
+				}
+		}
+	}
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void jit_step(E* __restrict__ data, unsigned long npairs, unsigned stage, unsigned step) {
+	const unsigned long gid = (unsigned long) blockIdx.x * 256 + threadIdx.x;
+	if (gid >= npairs) return;
+	const unsigned sh = step - 1;
+	const unsigned long i1 = ((gid >> sh) << (sh + 1)) | (gid & ((1ul << sh) - 1));
+	const unsigned long i2 = i1 + (1ul << sh);
+	E a = data[i1], b = data[i2];
+	cmpxch(a, b, (unsigned) ((i1 >> stage) & 1));
+	data[i1] = a;
+	data[i2] = b;
+}
+
+template <int NS>
+__device__ __forceinline__ void strided_body(E* __restrict__ data, unsigned long n, unsigned stage, unsigned p) {
+	constexpr int V = 1 << NS;
+	const unsigned long t = (unsigned long) blockIdx.x * 256 + threadIdx.x;
+	if (t >= (n >> NS)) return;
+	const unsigned b0 = p - NS;
+	const unsigned long base = ((t >> b0) << (b0 + NS)) | (t & ((1ul << b0) - 1));
+	E v[V];
+	#pragma unroll
+	for (int j = 0; j < V; ++j) v[j] = data[base + ((unsigned long) j << b0)];
+	reg_network<V>(v, NS, base, b0, stage);
+	#pragma unroll
+	for (int j = 0; j < V; ++j) data[base + ((unsigned long) j << b0)] = v[j];
+}
+extern "C" __global__ __launch_bounds__(256) void jit_strided1(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<1>(d, n, s, p); }
+extern "C" __global__ __launch_bounds__(256) void jit_strided2(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<2>(d, n, s, p); }
+extern "C" __global__ __launch_bounds__(256) void jit_strided3(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<3>(d, n, s, p); }
+extern "C" __global__ __launch_bounds__(256) void jit_strided4(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<4>(d, n, s, p); }
+#if CLO_JIT_Q >= 5
+extern "C" __global__ __launch_bounds__(256) void jit_strided5(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<5>(d, n, s, p); }
+#endif
+
+extern "C" __global__ __launch_bounds__(256)
+void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, int mode) {
+	constexpr int Q = CLO_JIT_Q;
+	constexpr int V = 1 << Q;
+	constexpr int TILE_MAX = 256 * V;
+	__shared__ E s[TILE_MAX + TILE_MAX / 32];
+	const unsigned tid = threadIdx.x;
+	const unsigned tile = 1u << kl;
+	const unsigned nthr = tile >> Q;
+	const unsigned long gbase = (unsigned long) blockIdx.x << kl;
+	#define PHYS(i) ((i) + ((i) >> 5))
+	for (unsigned i = tid; i < tile; i += 256) s[PHYS(i)] = data[gbase + i];
+	__syncthreads();
+	E v[V];
+	int cur_b0 = -1;
+	unsigned base = 0;
+	const unsigned s_first = mode ? 1u : stage;
+	for (unsigned S = s_first; S <= stage; ++S) {
+		unsigned p = mode ? S : p_hi;
+		while (p >= 1) {
+			const unsigned b0 = p > (unsigned) Q ? p - Q : 0u;
+			const int nsteps = (int) (p - b0);
+			if (cur_b0 != (int) b0) {
+				if (cur_b0 >= 0) {
+					if (tid < nthr) {
+						#pragma unroll
+						for (int j = 0; j < V; ++j) s[PHYS(base + ((unsigned) j << cur_b0))] = v[j];
+					}
+					__syncthreads();
+				}
+				base = ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u));
+				if (tid < nthr) {
+					#pragma unroll
+					for (int j = 0; j < V; ++j) v[j] = s[PHYS(base + ((unsigned) j << b0))];
+				}
+				cur_b0 = (int) b0;
+			}
+			if (tid < nthr) reg_network<V>(v, nsteps, gbase + base, b0, S);
+			p = b0;
+		}
+	}
+	if (cur_b0 >= 0 && tid < nthr) {
+		#pragma unroll
+		for (int j = 0; j < V; ++j) s[PHYS(base + ((unsigned) j << cur_b0))] = v[j];
+	}
+	__syncthreads();
+	for (unsigned i = tid; i < tile; i += 256) data[gbase + i] = s[PHYS(i)];
+}
+)CLOJIT";
+
+struct jit_sorter {
+	hipModule_t module = nullptr;
+	hipFunction_t step = nullptr, tile = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	int elem_size = 0;
+	int q = 0;
+};
+
+const char* ctype_of(int clo_type) {
+	// CloType numbering (clo_common.h)
+	static const char* names[] = { "signed char", "unsigned char", "short", "unsigned short", "int", "unsigned int",
+		"long", "unsigned long", nullptr, "float", "double" };
+	return (clo_type >= 0 && clo_type <= 10) ? names[clo_type] : nullptr;
+}
+
+int type_size(int clo_type) {
+	static const int sizes[] = { 1, 1, 2, 2, 4, 4, 8, 8, 2, 4, 8 };
+	return (clo_type >= 0 && clo_type <= 10) ? sizes[clo_type] : 0;
+}
+
+void set_log(char** log, const std::string& text) {
+	if (!log) return;
+	*log = (char*) malloc(text.size() + 1);
+	if (*log) memcpy(*log, text.c_str(), text.size() + 1);
+}
+
+int launch(hipFunction_t f, unsigned blocks, hipStream_t s, void** args) {
+	return (int) hipModuleLaunchKernel(f, blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare, const char* get_key,
+	void** handle, char** log) {
+	if (log) *log = nullptr;
+	if (!handle) return CLO_HIP_EARGS;
+	*handle = nullptr;
+	const char* et = ctype_of(elem_type);
+	const char* kt = ctype_of(key_type);
+	if (!et || !kt) return CLO_HIP_EUNSUPPORTED;
+	const int es = type_size(elem_type);
+	const int q = es == 8 ? 4 : 5;
+
+	std::string src;
+	src += std::string("#define CLO_SORT_ELEM_TYPE ") + et + "\n";
+	src += std::string("#define CLO_SORT_KEY_TYPE ") + kt + "\n";
+	src += std::string("#define CLO_SORT_COMPARE_AB(a, b) ") + (compare ? compare : "((a) > (b))") + "\n";
+	src += std::string("#define CLO_SORT_KEY_GET_X(x) ") + (get_key ? get_key : "(x)") + "\n";
+	src += "#define CLO_JIT_Q " + std::to_string(q) + "\n";
+	src += k_src;
+
+	hiprtcProgram prog = nullptr;
+	if (hiprtcCreateProgram(&prog, src.c_str(), "clo_sort_bitonic_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+		set_log(log, "hiprtcCreateProgram failed");
+		return CLO_HIP_EUNSUPPORTED;
+	}
+	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17" };
+	const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+	if (cr != HIPRTC_SUCCESS) {
+		size_t n = 0;
+		hiprtcGetProgramLogSize(prog, &n);
+		std::string text(n ? n : 1, '\0');
+		if (n) hiprtcGetProgramLog(prog, &text[0]);
+		set_log(log, text);
+		hiprtcDestroyProgram(&prog);
+		return CLO_HIP_EARGS;  // the user's expression does not compile
+	}
+	size_t code_size = 0;
+	hiprtcGetCodeSize(prog, &code_size);
+	std::vector<char> code(code_size);
+	hiprtcGetCode(prog, code.data());
+	hiprtcDestroyProgram(&prog);
+
+	jit_sorter* js = new jit_sorter();
+	js->elem_size = es;
+	js->q = q;
+	hipError_t e = hipModuleLoadData(&js->module, code.data());
+	if (e == hipSuccess) e = hipModuleGetFunction(&js->step, js->module, "jit_step");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js->tile, js->module, "jit_tile");
+	for (int ns = 1; ns <= q && e == hipSuccess; ++ns) {
+		const std::string name = "jit_strided" + std::to_string(ns);
+		e = hipModuleGetFunction(&js->strided[ns], js->module, name.c_str());
+	}
+	if (e != hipSuccess) {
+		set_log(log, std::string("loading the compiled module failed: ") + hipGetErrorString(e));
+		if (js->module) (void) hipModuleUnload(js->module);
+		delete js;
+		return (int) e;
+	}
+	*handle = js;
+	return 0;
+}
+
+void clo_hip_bitonic_jit_destroy(void* handle) {
+	jit_sorter* js = (jit_sorter*) handle;
+	if (!js) return;
+	if (js->module) (void) hipModuleUnload(js->module);
+	delete js;
+}
+
+// In-place sort of data[0..numel), numel a power of two. tiled = 0: one launch
+// per step; 1: the tile/strided schedule.
+int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream) {
+	jit_sorter* js = (jit_sorter*) handle;
+	if (launches) *launches = 0;
+	if (!js || !data) return CLO_HIP_EARGS;
+	if (numel <= 1) return 0;
+	if ((numel & (numel - 1)) != 0) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	unsigned T = 0;
+	while (((size_t) 1 << T) < numel) ++T;
+	unsigned long n = numel;
+	int count = 0, st = 0;
+	const unsigned Q = (unsigned) js->q, KL_MAX = 8 + Q;
+
+	if (!tiled || T < Q) {
+		unsigned long npairs = n / 2;
+		const unsigned blocks = (unsigned) ((npairs + 255) / 256);
+		for (unsigned stage = 1; stage <= T && !st; ++stage)
+			for (unsigned step = stage; step >= 1 && !st; --step) {
+				void* args[] = { &data, &npairs, &stage, &step };
+				st = launch(js->step, blocks, s, args);
+				++count;
+			}
+	} else {
+		unsigned kl = T < KL_MAX ? T : KL_MAX;
+		const unsigned tiles = (unsigned) (n >> kl);
+		int mode = 1;
+		unsigned stage = kl, p_hi = kl;
+		{
+			void* args[] = { &data, &kl, &stage, &p_hi, &mode };
+			st = launch(js->tile, tiles, s, args);
+			++count;
+		}
+		mode = 0;
+		for (stage = kl + 1; stage <= T && !st; ++stage) {
+			unsigned p = stage;
+			while (p > kl && !st) {
+				unsigned ns = p - kl;
+				if (ns > Q) ns = Q;
+				const unsigned long threads = n >> ns;
+				void* args[] = { &data, &n, &stage, &p };
+				st = launch(js->strided[ns], (unsigned) ((threads + 255) / 256), s, args);
+				++count;
+				p -= ns;
+			}
+			if (!st) {
+				void* args[] = { &data, &kl, &stage, &p_hi, &mode };
+				st = launch(js->tile, tiles, s, args);
+				++count;
+			}
+		}
+	}
+	if (launches) *launches = count;
+	return st;
+}
+
+}  // extern "C"

@@ -129,6 +129,19 @@ int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
 	int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, void* stream);
 
+/* ---- bitonic sorts specialised at run time (hiprtc) for arbitrary compare /
+ *      get_key expressions — what upstream does for every sorter by OpenCL JIT
+ *      (sort/clo_sort_abstract.c:144-179). elem_type / key_type: CloType numbers.
+ *      compare: body of CLO_SORT_COMPARE(a, b) (NULL: "((a) > (b))"); get_key:
+ *      body of CLO_SORT_KEY_GET(x) (NULL: "(x)"). On a compile error returns
+ *      CLO_HIP_EARGS and, if log != NULL, a malloc'd build log (caller frees). ----
+ */
+int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare, const char* get_key,
+	void** handle, char** log);
+void clo_hip_bitonic_jit_destroy(void* handle);
+/* In place, numel a power of two. tiled: 0 = sbitonic schedule, 1 = abitonic. */
+int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream);
+
 /* ---- status word of the bounded spins (decoupled look-back) ----
  * Every kernel that polls another work-group's state bounds its spin; on
  * give-up it sets a word in the workspace and finishes. This reads it back

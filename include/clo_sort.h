@@ -11,8 +11,10 @@
  * Divergences from upstream, all deliberate:
  *  - `compare` / `get_key` are OpenCL C macro bodies upstream (JIT). Here they
  *    are parsed into a fixed family: get_key = x, (x) >> N, ((x) >> N) & MASK,
- *    optional casts; compare = ((a) > (b)) or ((a) < (b)). Anything else:
- *    CLO_ERROR_ARGS.
+ *    optional casts; compare = ((a) > (b)) or ((a) < (b)) select ahead-of-time
+ *    kernels. Any other expression: the bitonic sorters compile it at run time
+ *    with hiprtc (as upstream does with the OpenCL JIT); satradix, which needs
+ *    the key's bit layout, answers CLO_ERROR_ARGS.
  *  - data_out != NULL works (upstream sorts data_in regardless,
  *    clo_sort_satradix.c:276,305 / clo_sort_abitonic.c:388) and leaves data_in
  *    untouched; numel need not be a power of two.
@@ -88,6 +90,9 @@ typedef struct {
 	int descending;
 } CloSortKeySpec;
 const CloSortKeySpec* clo_sort_get_key_spec(CloSort* sorter);
+/* Not upstream — non-NULL when the sorter was specialised at run time (hiprtc)
+ * because compare/get_key fall outside the ahead-of-time family. */
+void* clo_sort_get_jit(CloSort* sorter);
 
 #ifdef __cplusplus
 }

@@ -453,3 +453,64 @@ def test_two_ranks_on_one_gpu_hip_ops_end_to_end(gpu, tmp_path):
     outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)]
     assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
     assert np.all(outs[0] >> 31 == 0) and np.all(outs[1] >> 31 == 1)
+
+
+# ----------------------------------------------------------------------------
+# compare / get_key outside the ahead-of-time family: compiled at run time
+# (hiprtc), as upstream compiles every sorter by OpenCL JIT
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+def test_jit_get_key_division_equals_shift(gpu, alg):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = O.bench_rand(3, "uint", 1 << 15)
+    s = clo.Sorter(alg, ctx, "uint", get_key="((x) / 65536)")       # == x >> 16, but not parseable as a shift
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, O.sbitonic(a, key_shift=16))           # bit-exact incl. tie order
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+def test_jit_compare_low_byte_order(gpu, alg):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = O.bench_rand(4, "uint", 1 << 16)
+    s = clo.Sorter(alg, ctx, "uint", compare="(((a) & 0xFF) > ((b) & 0xFF))")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, O.sbitonic(a, key_size=1))             # key = low byte, same network, same ties
+    assert np.all(np.diff((got & 0xFF).astype(np.int64)) >= 0)
+
+
+def test_jit_negated_compare_and_float_keys(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    a = O.bench_rand(5, "uint", 1 << 14)
+    s = clo.Sorter("abitonic", ctx, "uint", compare="(!((a) <= (b)))")
+    assert np.array_equal(s.with_host_data(a, q), np.sort(a))
+    s.close()
+    f = np.random.default_rng(6).permutation(1 << 14).astype(np.float32) - 5000.0   # distinct values
+    s = clo.Sorter("abitonic", ctx, "float", get_key="(-(x))")
+    assert np.array_equal(s.with_host_data(f, q), np.sort(f)[::-1])
+    s.close()
+    pairs = (np.random.default_rng(7).integers(0, 1 << 20, 1 << 14, dtype=np.uint64) << np.uint64(32)) \
+        | np.arange(1 << 14, dtype=np.uint64)
+    s = clo.Sorter("sbitonic", ctx, "ulong", key_type="uint", get_key="(uint) ((x) / 4294967296ul)")
+    assert np.array_equal(s.with_host_data(pairs, q), O.sbitonic(pairs, key_size=4, key_shift=32))
+    s.close()
+
+
+def test_jit_reports_compile_errors_and_needs_pow2(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    with pytest.raises(clo.CloError) as e:
+        clo.Sorter("abitonic", ctx, "uint", get_key="((x) +* 3)")
+    assert e.value.code == 2 and "Could not build kernels" in e.value.message
+    s = clo.Sorter("abitonic", ctx, "uint", get_key="((x) % 1000)")
+    with pytest.raises(clo.CloError) as e:
+        s.with_host_data(np.arange(1000, dtype=np.uint32), q)
+    assert "power-of-two" in e.value.message
+    got = s.with_host_data(np.arange(1024, dtype=np.uint32)[::-1].copy(), q)
+    assert np.all(np.diff((got % 1000).astype(np.int64)) >= 0) and np.array_equal(np.sort(got), np.arange(1024))
+    s.close()
