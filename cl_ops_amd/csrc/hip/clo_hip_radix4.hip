@@ -436,12 +436,12 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	constexpr int ITEMS = r4_shape<LT>::ITEMS;
 	constexpr int TILE = r4_shape<LT>::TILE;
 	constexpr int LOG_TILE = r4_shape<LT>::LOG_TILE;
-	constexpr int SCR = H | 1;       // per-thread scratch stride in dwords, odd: conflict-free
 	static_assert(ITEMS <= 15, "4-bit thread-private counters");
 	static_assert(TILE <= 65536 / 2, "16-bit positions");
 
 	__shared__ E s_stage[TILE];
-	__shared__ unsigned s_scr[R4_THREADS * SCR];   // per thread: tile-local start of its slice of each digit (16-bit fields)
+	__shared__ unsigned s_scr[H][R4_THREADS];      // [word][thread]: tile-local start of the thread's slice of each digit
+	                                               // (16-bit fields); a lane only touches its own column: conflict-free
 	__shared__ unsigned s_wtot[R4_WAVES][H];       // wave totals
 	__shared__ unsigned s_wbase[R4_WAVES][H];      // digit start + totals of earlier waves
 	__shared__ unsigned s_next[R][2][R];           // [digit][destination tile 0/1][next digit]
@@ -506,15 +506,15 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	}
 	__syncthreads();
 	#pragma unroll
-	for (int j = 0; j < H; ++j) s_scr[tid * SCR + j] = w[j] + s_wbase[wave][j];
+	for (int j = 0; j < H; ++j) s_scr[j][tid] = w[j] + s_wbase[wave][j];
 
 	// ---- 4a. scatter into the LDS stage in digit order ----
-	const unsigned short* my16 = reinterpret_cast<const unsigned short*>(&s_scr[tid * SCR]);
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		if (full || tbase + i < count) {
 			const unsigned d = (unsigned) (key[i] >> shift) & mask;
-			const unsigned pos = (unsigned) my16[d] + ((lrank >> (4 * i)) & 15u);
+			const unsigned start = (s_scr[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
+			const unsigned pos = start + ((lrank >> (4 * i)) & 15u);
 			s_stage[pos] = key[i];
 		}
 	}
