@@ -39,6 +39,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PREWARM = 3
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy ceiling)
 
 
@@ -212,7 +213,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # PREWARM untimed steps first (allocations of the cached aux buffers, clock
+    # ramp), then the W warm-up steps the caller asked for
+    for _ in range(PREWARM + args.warmup):
         step()
     fence()
 
@@ -249,27 +252,21 @@ def main():
     ok = True
     if sharded is not None:
         out_t, m = last
-        got = out_t[:m].cpu().numpy().view(np.uint32 if es == 4 else np.uint64)
+        udt = np.uint32 if es == 4 else np.uint64
+        got = out_t[:m].cpu().numpy().view(udt)
         ok = bool(np.all(got[:-1] <= got[1:])) if m > 1 else True
-        lo_hi = torch.tensor([int(got[0]) if m else 0, int(got[-1]) if m else 0, m,
-                              int(np.bitwise_xor.reduce(got)) if m else 0], dtype=torch.int64, device="cuda")
-        alls = [torch.empty_like(lo_hi) for _ in range(world)]
-        dist.all_gather(alls, lo_hi)
-        xin = torch.tensor([int(np.bitwise_xor.reduce(host))], dtype=torch.int64, device="cuda")
-        xins = [torch.empty_like(xin) for _ in range(world)]
-        dist.all_gather(xins, xin)
+        # per rank: [first key, last key, count, xor of output keys, xor of input keys] as raw 64-bit words
+        mine = np.array([int(got[0]) if m else 0, int(got[-1]) if m else 0, m,
+                         int(np.bitwise_xor.reduce(got)) if m else 0, int(np.bitwise_xor.reduce(host))],
+                        dtype=np.uint64)
+        t_mine = torch.from_numpy(mine.view(np.int64).copy()).cuda()
+        alls = [torch.empty_like(t_mine) for _ in range(world)]
+        dist.all_gather(alls, t_mine)
         if rank == 0:
-            a = torch.stack(alls).cpu().numpy()
-            ok = ok and int(a[:, 2].sum()) == n * world
-            ok = ok and all(np.uint64(a[i, 1]) <= np.uint64(a[i + 1, 0]) for i in range(world - 1)
-                            if a[i, 2] and a[i + 1, 2])
-            xo = 0
-            for v in a[:, 3]:
-                xo ^= int(v)
-            xi = 0
-            for v in torch.stack(xins).cpu().numpy()[:, 0]:
-                xi ^= int(v)
-            ok = ok and xo == xi
+            a = torch.stack(alls).cpu().numpy().view(np.uint64)
+            ok = ok and int(a[:, 2].sum()) == n * world                    # nothing lost
+            ok = ok and all(a[i, 1] <= a[i + 1, 0] for i in range(world - 1) if a[i, 2] and a[i + 1, 2])  # rank order = key order
+            ok = ok and int(np.bitwise_xor.reduce(a[:, 3])) == int(np.bitwise_xor.reduce(a[:, 4]))       # same multiset
     else:
         got = dst.cpu().numpy().view(host.dtype)
         if workload == "scan":
@@ -308,6 +305,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm": PREWARM,
             "ms_per_step": round(t_max / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

@@ -392,8 +392,6 @@ int g_variant = 0;
 unsigned long long* g_dbg = nullptr;  // developer stamps buffer (8 u64 per tile), diagnostic runs only
 unsigned g_xflags = 0;  // developer experiments (CLO_RADIX_XFLAGS), never set in production
 
-struct tile_cfg { int threads, items, rounds; };
-
 // Tile shapes (threads, items per thread, LDS stage rounds). The LDS stage is
 // 32 KiB for 4/8-byte elements in every shape.
 template <typename E> struct shape0 { static constexpr int T = 512, I = (sizeof(E) == 8 ? 8 : 16), RD = 1, W = 1; };
@@ -430,8 +428,8 @@ template <typename E, int BITS, typename S>
 void launch_pass(const E* in, E* out, size_t n, unsigned shift, unsigned mask,
 	int has_next, unsigned nshift, unsigned nmask, unsigned* hdr, unsigned ticket_word,
 	const unsigned* gh_cur, unsigned* gh_next, clo_u64* state, unsigned epoch,
-	size_t tiles, hipStream_t s) {
-	clo_timing_scope timing("radix_pass", s);
+	size_t tiles, hipStream_t s, const char* label = "radix_pass") {
+	clo_timing_scope timing(label, s);
 	hipLaunchKernelGGL((clo_radix_pass_kernel<E, BITS, S::T, S::I, S::RD, S::W>),
 		dim3((unsigned) tiles), dim3(S::T), 0, s,
 		in, out, n, shift, mask, has_next, nshift, nmask, hdr, ticket_word,
@@ -564,7 +562,7 @@ int msd_partition_impl(const E* src, E* dst, size_t n, unsigned shift, void* ws,
 		src, n, shift, R - 1u, ghist, R, (unsigned long long*) nullptr);
 	hipLaunchKernelGGL(clo_radix_bases_kernel, dim3(1), dim3(256), 0, s, (const unsigned*) ghist, R, R, gbase);
 	launch_pass<E, BITS, shape0<E>>(src, dst, n, shift, R - 1u, 0, 0u, 0u,
-		hdr, (unsigned) CLO_WS_TICKET_WORD, gbase, ghist + (size_t) GH_COPIES * R, state, 1u, L.tiles, s);
+		hdr, (unsigned) CLO_WS_TICKET_WORD, gbase, ghist + (size_t) GH_COPIES * R, state, 1u, L.tiles, s, "msd_partition");
 	return (int) hipGetLastError();
 }
 

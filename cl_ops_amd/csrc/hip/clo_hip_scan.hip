@@ -31,8 +31,6 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_VEC = 4;
 constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 
-template <typename T, int N> struct vec_of { T v[N]; };
-
 // 4 consecutive elements as one aligned vector access where possible.
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, T (&v)[4]) {
