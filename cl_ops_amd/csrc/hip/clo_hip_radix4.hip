@@ -129,7 +129,7 @@ void clo_radix4_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 	// groups are combined through LDS
 	constexpr int G = OFF_CHUNK / R;
 	__shared__ unsigned s_pb[G][R], s_pt[G][R];
-	{
+	if (chunks > 1) {  // (a single chunk derives its totals from its own scan below: one launch fewer)
 		const unsigned d = tid % R, g = tid / R;
 		unsigned before = 0, total = 0;
 		for (unsigned c = g; c < chunks; c += G) {
@@ -141,7 +141,7 @@ void clo_radix4_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 		s_pt[g][d] = total;
 	}
 	__syncthreads();
-	if (tid < (unsigned) R) {
+	if (chunks > 1 && tid < (unsigned) R) {
 		unsigned before = 0, total = 0;
 		#pragma unroll
 		for (int g = 0; g < G; ++g) { before += s_pb[g][tid]; total += s_pt[g][tid]; }
@@ -159,6 +159,16 @@ void clo_radix4_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 		if (lane == 63) s_w[wave][d] = incl;
 	}
 	__syncthreads();
+	if (chunks == 1) {
+		if (tid < (unsigned) R) {
+			unsigned total = 0;
+			#pragma unroll
+			for (int w = 0; w < OFF_CHUNK / 64; ++w) total += s_w[w][tid];
+			s_before[tid] = 0;
+			s_total[tid] = total;
+		}
+		__syncthreads();
+	}
 	if (t < tiles) {
 		unsigned dbase = 0;
 		#pragma unroll
@@ -552,6 +562,89 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 }
 
 // ---------------------------------------------------------------------------
+// Arrays of at most one tile: every digit pass inside ONE work-group, one
+// launch for the whole sort (upstream's harness sweeps sizes from 2^4 up; a
+// multi-kernel sort costs ~25 dependent launches however small the array).
+// Same packed-counter ranking as above; the tile goes through the LDS stage
+// once per digit.
+// ---------------------------------------------------------------------------
+template <typename E, int BITS, int LT>
+__global__ __launch_bounds__(R4_THREADS)
+void clo_radix4_small_kernel(const E* in, E* out, unsigned n,
+	unsigned key_shift, unsigned key_bits) {
+	constexpr int R = 1 << BITS;
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int ITEMS = r4_shape<LT>::ITEMS;
+	constexpr int TILE = r4_shape<LT>::TILE;
+	__shared__ E s_stage[TILE];
+	__shared__ unsigned s_scr[H][R4_THREADS];
+	__shared__ unsigned s_wtot[R4_WAVES][H];
+	__shared__ unsigned s_wbase[R4_WAVES][H];
+	__shared__ unsigned s_dstart16[H];
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned tbase = tid * ITEMS;
+	E key[ITEMS];
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < n) ? in[tbase + i] : (E) 0;
+
+	for (unsigned done = 0; done < key_bits; done += BITS) {
+		const unsigned shift = key_shift + done;
+		const unsigned bits = key_bits - done < (unsigned) BITS ? key_bits - done : (unsigned) BITS;
+		const unsigned mask = (1u << bits) - 1u;
+		packed4 c = { 0u, 0u };
+		unsigned lrank = 0;
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i)
+			if (tbase + i < n) lrank |= packed4_count<BITS>(c, (unsigned) (key[i] >> shift) & mask) << (4 * i);
+		unsigned w[H];
+		packed4_widen<BITS>(c, w);
+		#pragma unroll
+		for (int j = 0; j < H; ++j) {
+			const unsigned incl = wave_scan_dpp(w[j]);
+			if (lane == 63) s_wtot[wave][j] = incl;
+			w[j] = incl - w[j];
+		}
+		__syncthreads();
+		if (tid < 64) {
+			// digit totals -> tile-local digit starts (exclusive scan over digits)
+			unsigned h = 0;
+			if (tid < (unsigned) R) {
+				#pragma unroll
+				for (int wv = 0; wv < R4_WAVES; ++wv) h += (s_wtot[wv][tid >> 1] >> ((tid & 1u) * 16u)) & 0xffffu;
+			}
+			const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
+			const unsigned odd = (unsigned) __shfl((int) dstart, (int) (lane | 1u), 64);
+			if (tid < (unsigned) R && (tid & 1u) == 0) s_dstart16[tid >> 1] = dstart | ((R > 1 ? odd : 0u) << 16);
+		}
+		__syncthreads();
+		if (tid < R4_WAVES * H) {
+			const unsigned wv = tid / H, j = tid % H;
+			unsigned run = s_dstart16[j];
+			for (unsigned k = 0; k < wv; ++k) run += s_wtot[k][j];
+			s_wbase[wv][j] = run;
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int j = 0; j < H; ++j) s_scr[j][tid] = w[j] + s_wbase[wave][j];
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			if (tbase + i < n) {
+				const unsigned d = (unsigned) (key[i] >> shift) & mask;
+				const unsigned start = (s_scr[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
+				s_stage[start + ((lrank >> (4 * i)) & 15u)] = key[i];
+			}
+		}
+		__syncthreads();
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) key[i] = s_stage[tbase + i];
+		__syncthreads();
+	}
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) out[tbase + i] = key[i];
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 
@@ -585,6 +678,15 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles, chunks = (unsigned) L.chunks;
 
+	if (LT == 12 && n <= ((size_t) 1 << LT)) {
+		if constexpr (LT == 12) {
+			clo_timing_scope timing("radix_small", s);
+			hipLaunchKernelGGL((clo_radix4_small_kernel<E, BITS, LT>), dim3(1), dim3(R4_THREADS), 0, s,
+				src, dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits);
+		}
+		return (int) hipGetLastError();
+	}
+
 	// zero the header (status word) and every pass's histogram
 	hipError_t e = hipMemsetAsync(ws, 0, L.toff, s);
 	if (e != hipSuccess) return (int) e;
@@ -617,8 +719,9 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		unsigned* th = thist + (size_t) p * per_pass;
 		{
 			clo_timing_scope timing("radix_offsets", s);
-			hipLaunchKernelGGL((clo_radix4_chunksum_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
-				(const unsigned*) th, tiles, partial);
+			if (chunks > 1)
+				hipLaunchKernelGGL((clo_radix4_chunksum_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
+					(const unsigned*) th, tiles, partial);
 			hipLaunchKernelGGL((clo_radix4_offsets_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
 				(const unsigned*) th, tiles, (const unsigned*) partial, chunks, toff);
 		}
