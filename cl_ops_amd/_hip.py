@@ -58,7 +58,7 @@ _sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_radix_workspace_bytes", sz, sz, ci, ci, ci)
 _sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)
-_sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, sz, vp)
+_sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, vp, sz, vp)
 _sig("clo_hip_msd_workspace_bytes", sz, sz, ci, ci)
 _sig("clo_hip_bitonic_padded_numel", sz, sz)
 _sig("clo_hip_bitonic_simple", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)

@@ -29,6 +29,9 @@ struct clo_timing_scope {
 
 // Chain-free radix path for digits of <= 4 bits (clo_hip_radix4.hip).
 size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int digit_bits);
+size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits);
+int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
+	unsigned long long* counts, void* ws, hipStream_t s);
 int clo_radix4_set_log_tile(int log_tile);
 int clo_radix4_set_match(int on);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,

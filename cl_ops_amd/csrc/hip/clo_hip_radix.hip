@@ -546,26 +546,6 @@ int msd_hist_impl(const void* src, size_t n, unsigned shift, unsigned mask, uint
 	return (int) hipGetLastError();
 }
 
-template <typename E, int BITS>
-int msd_partition_impl(const E* src, E* dst, size_t n, unsigned shift, void* ws, hipStream_t s) {
-	const ws_layout L = radix_layout(n, (int) sizeof(E), 1, BITS, 0);
-	unsigned* hdr = (unsigned*) ws;
-	unsigned* ghist = (unsigned*) ((char*) ws + L.ghist);
-	unsigned* gbase = (unsigned*) ((char*) ws + L.gbase);
-	clo_u64* state = (clo_u64*) ((char*) ws + L.state);
-	constexpr unsigned R = 1u << BITS;
-	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
-	if (e != hipSuccess) return (int) e;
-	unsigned blocks = (unsigned) ((n + HIST_THREADS * HIST_ITEMS - 1) / (HIST_THREADS * HIST_ITEMS));
-	if (blocks > 2048) blocks = 2048;
-	hipLaunchKernelGGL((clo_radix_hist_kernel<E>), dim3(blocks), dim3(HIST_THREADS), 0, s,
-		src, n, shift, R - 1u, ghist, R, (unsigned long long*) nullptr);
-	hipLaunchKernelGGL(clo_radix_bases_kernel, dim3(1), dim3(256), 0, s, (const unsigned*) ghist, R, R, gbase);
-	launch_pass<E, BITS, shape0<E>>(src, dst, n, shift, R - 1u, 0, 0u, 0u,
-		hdr, (unsigned) CLO_WS_TICKET_WORD, gbase, ghist + (size_t) GH_COPIES * R, state, 1u, L.tiles, s, "msd_partition");
-	return (int) hipGetLastError();
-}
-
 }  // namespace
 
 extern "C" {
@@ -631,7 +611,7 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {
 	if (bucket_bits < 1 || bucket_bits > 3) return 0;
-	return radix_layout(numel, elem_size, 1, bucket_bits, 0).total;
+	return clo_radix4_partition_workspace_bytes(numel, elem_size, bucket_bits);
 }
 
 int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
@@ -651,27 +631,22 @@ int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
 }
 
 int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_size,
-	int key_shift, int key_bits, int bucket_bits,
+	int key_shift, int key_bits, int bucket_bits, uint64_t* counts_dev,
 	void* workspace, size_t workspace_bytes, void* stream) {
-	if (numel == 0) return 0;
-	if (!src || !dst || src == dst || !workspace) return CLO_HIP_EARGS;
-	if (bucket_bits < 1 || bucket_bits > 3 || bucket_bits > key_bits) return CLO_HIP_EARGS;
-	if (numel > 0xffffffffull) return CLO_HIP_EARGS;
-	if (workspace_bytes < clo_hip_msd_workspace_bytes(numel, elem_size, bucket_bits)) return CLO_HIP_EWORKSPACE;
 	hipStream_t s = (hipStream_t) stream;
-	const unsigned shift = (unsigned) (key_shift + key_bits - bucket_bits);
-	#define CLO_MSD_CASE(E, B) return msd_partition_impl<E, B>((const E*) src, (E*) dst, numel, shift, workspace, s)
-	if (elem_size == 4) {
-		if (bucket_bits == 1) CLO_MSD_CASE(uint32_t, 1);
-		if (bucket_bits == 2) CLO_MSD_CASE(uint32_t, 2);
-		CLO_MSD_CASE(uint32_t, 3);
-	} else if (elem_size == 8) {
-		if (bucket_bits == 1) CLO_MSD_CASE(uint64_t, 1);
-		if (bucket_bits == 2) CLO_MSD_CASE(uint64_t, 2);
-		CLO_MSD_CASE(uint64_t, 3);
+	if (bucket_bits < 1 || bucket_bits > 3 || bucket_bits > key_bits) return CLO_HIP_EARGS;
+	if (numel == 0) {
+		if (counts_dev) return (int) hipMemsetAsync(counts_dev, 0, sizeof(uint64_t) << bucket_bits, s);
+		return 0;
 	}
-	#undef CLO_MSD_CASE
-	return CLO_HIP_EUNSUPPORTED;
+	if (!src || !dst || src == dst || !workspace) return CLO_HIP_EARGS;
+	if (numel > 0xffffffffull) return CLO_HIP_EARGS;
+	if (elem_size != 4 && elem_size != 8) return CLO_HIP_EUNSUPPORTED;
+	if (workspace_bytes < clo_hip_msd_workspace_bytes(numel, elem_size, bucket_bits)) return CLO_HIP_EWORKSPACE;
+	const unsigned shift = (unsigned) (key_shift + key_bits - bucket_bits);
+	// one chain-free radix pass on the top bits (clo_hip_radix4.hip)
+	return clo_radix4_partition(src, dst, numel, elem_size, shift, bucket_bits,
+		(unsigned long long*) counts_dev, workspace, s);
 }
 
 }  // extern "C"

@@ -752,6 +752,55 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	return 0;
 }
 
+// Bucket sizes of a single-pass partition, from the per-tile histograms
+// (uint64 because the exchange plan adds them across ranks).
+template <int R>
+__global__ __launch_bounds__(256)
+void clo_radix4_counts_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned long long* __restrict__ counts) {
+	constexpr int G = 256 / R;
+	__shared__ unsigned long long s_part[G][R];
+	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R;
+	unsigned long long c = 0;
+	for (unsigned t = g; t < tiles; t += G) c += thist[(size_t) t * R + d];
+	s_part[g][d] = c;
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned long long tot = 0;
+		#pragma unroll
+		for (int k = 0; k < G; ++k) tot += s_part[k][tid];
+		counts[tid] = tot;
+	}
+}
+
+// One stable pass on `bits` bits at `shift`: the MSD bucket split of the
+// multi-GPU exchange. counts (optional) receives the 1 << bits bucket sizes.
+template <typename E, int BITS>
+int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned long long* counts, void* ws, hipStream_t s) {
+	constexpr unsigned R = 1u << BITS;
+	constexpr int LT = 12;
+	const r4_layout L = r4_make_layout(n, (int) sizeof(E), 1, BITS, LT);
+	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
+	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
+	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
+	const unsigned tiles = (unsigned) L.tiles, chunks = (unsigned) L.chunks;
+	hipError_t e = hipMemsetAsync(ws, 0, L.toff, s);
+	if (e != hipSuccess) return (int) e;
+	clo_timing_scope timing("msd_partition", s);
+	hipLaunchKernelGGL((clo_radix4_tilehist_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+		src, n, shift, R - 1u, thist, (int) ((uintptr_t) src % 16 == 0));
+	if (counts)
+		hipLaunchKernelGGL((clo_radix4_counts_kernel<R>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);
+	if (chunks > 1)
+		hipLaunchKernelGGL((clo_radix4_chunksum_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
+			(const unsigned*) thist, tiles, partial);
+	hipLaunchKernelGGL((clo_radix4_offsets_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
+		(const unsigned*) thist, tiles, (const unsigned*) partial, chunks, toff);
+	hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+		src, dst, n, shift, R - 1u, 0, 0u, 0u, (const unsigned*) thist, (const unsigned*) toff,
+		thist + (L.tiles + 1) * R, (int) ((uintptr_t) src % 16 == 0));
+	return (int) hipGetLastError();
+}
+
 template <typename E, int LT>
 int r4_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits, int digit_bits,
 	void* ws, hipStream_t s) {
@@ -769,6 +818,26 @@ int r4_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, 
 size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int digit_bits) {
 	const int passes = (key_bits + digit_bits - 1) / digit_bits;
 	return r4_make_layout(n, elem_size, passes, digit_bits, 12).total;  // the smaller tile needs more
+}
+
+size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits) {
+	return r4_make_layout(n, elem_size, 2, bits, 12).total;
+}
+
+int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
+	unsigned long long* counts, void* ws, hipStream_t s) {
+	#define CLO_R4P(E, B) return r4_partition_impl<E, B>((const E*) src, (E*) dst, n, shift, counts, ws, s)
+	if (elem_size == 4) {
+		if (bits == 1) CLO_R4P(uint32_t, 1);
+		if (bits == 2) CLO_R4P(uint32_t, 2);
+		if (bits == 3) CLO_R4P(uint32_t, 3);
+	} else if (elem_size == 8) {
+		if (bits == 1) CLO_R4P(uint64_t, 1);
+		if (bits == 2) CLO_R4P(uint64_t, 2);
+		if (bits == 3) CLO_R4P(uint64_t, 3);
+	}
+	#undef CLO_R4P
+	return CLO_HIP_EUNSUPPORTED;
 }
 
 int clo_radix4_set_log_tile(int log_tile) {

@@ -7,12 +7,12 @@ ROCm). Rank r ends up holding bucket r (the keys whose top log2(G) bits equal
 r), sorted; concatenating the ranks' results in rank order is the globally
 sorted array. Per sort:
 
-  1. local histogram of the top log2(G) key bits         (HIP kernel, 1 read)
+  1. local stable partition into G contiguous buckets by the top log2(G) key
+     bits; the bucket sizes fall out of it              (HIP kernels, 2 reads + 1 write)
   2. all-gather of the G counts                          (64 B per rank)
-  3. local stable partition into G contiguous buckets    (HIP kernel, 1 read + 1 write)
-  4. all-to-all(v): ONE batch of G-1 send/recv pairs     (RCCL grouped ncclSend/ncclRecv;
+  3. all-to-all(v): ONE batch of G-1 send/recv pairs     (RCCL grouped ncclSend/ncclRecv;
      every pair has its own xGMI link, so the G-1 transfers run concurrently)
-  5. local satradix sort of the received bucket          (clo_sort_* C API)
+  4. local satradix sort of the received bucket          (clo_sort_* C API)
 
 torch is plumbing here: it owns the device buffers that RCCL needs and the
 process group. All computation goes through the C-ABI of libcl_ops_hip.so on
@@ -65,11 +65,15 @@ class HipLocalOps:
         return counts
 
     def msd_partition(self, src, dst, n, bucket_bits):
+        """Stable bucket split src -> dst; returns the bucket sizes (int64 tensor on the device)."""
         need = self.lib.clo_hip_msd_workspace_bytes(n, self.elem_size, bucket_bits)
         ws = self._workspace(need)
+        counts = self.torch.empty(1 << bucket_bits, dtype=self.torch.int64, device=src.device)
         self._hip.check(self.lib.clo_hip_msd_partition(src.data_ptr(), dst.data_ptr(), n, self.elem_size, 0,
-                                                       self.key_bits, bucket_bits, ws.data_ptr(), ws.numel(),
-                                                       self.stream), "clo_hip_msd_partition")
+                                                       self.key_bits, bucket_bits, counts.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), self.stream),
+                        "clo_hip_msd_partition")
+        return counts
 
     def sort_inplace(self, t, n):
         buf = self.clo.Buffer(self.ctx, n * self.elem_size, device_ptr=t.data_ptr())
@@ -148,7 +152,7 @@ class ShardedSorter:
 
         send, recv = self._buffers(local, n)
         b = self.bucket_bits
-        counts = self.ops.msd_histogram(local, n, b)                      # step 1
+        counts = self.ops.msd_partition(local, send, n, b)                # step 1
         gathered = [torch.empty_like(counts) for _ in range(self.world)]
         dist.all_gather(gathered, counts, group=self.group)               # step 2
         matrix = torch.stack(gathered).cpu().numpy()
@@ -156,9 +160,8 @@ class ShardedSorter:
         total = int(rc.sum())
         if total > recv.numel():
             self._recv = recv = torch.empty(total, dtype=local.dtype, device=local.device)
-        self.ops.msd_partition(local, send, n, b)                         # step 3
 
-        self.exchange(send, recv, sc, so, rc, ro)                         # step 4
+        self.exchange(send, recv, sc, so, rc, ro)                         # step 3
         if total > 0:
-            self.ops.sort_inplace(recv, total)                            # step 5
+            self.ops.sort_inplace(recv, total)                            # step 4
         return recv, total

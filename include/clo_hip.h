@@ -97,14 +97,15 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 
 /* MSD bucket partition used by the multi-GPU exchange (new
  * functionality): stable split of src into 1<<bucket_bits buckets by the top
- * bucket_bits of the key field. counts (device, 1<<bucket_bits uint64) receives
- * the bucket sizes; dst gets the buckets back to back in bucket order.
- * Two steps so the caller can exchange counts between them. */
+ * bucket_bits of the key field; dst gets the buckets back to back in bucket
+ * order. counts_dev (device, 1<<bucket_bits uint64; may be NULL for the
+ * partition) receives the bucket sizes — the partition produces them as a
+ * by-product, clo_hip_msd_histogram computes them alone. */
 int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
 	int key_shift, int key_bits, int bucket_bits,
 	uint64_t* counts_dev, void* stream);
 int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_size,
-	int key_shift, int key_bits, int bucket_bits,
+	int key_shift, int key_bits, int bucket_bits, uint64_t* counts_dev,
 	void* workspace, size_t workspace_bytes, void* stream);
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits);
 

@@ -297,10 +297,13 @@ def test_msd_histogram_and_partition(gpu, bits, dt):
     ws_bytes = lib.clo_hip_msd_workspace_bytes(n, es, bits)
     ws = clo.Buffer(ctx, ws_bytes)
     src.write(q, a)
+    cnt2 = clo.Buffer(ctx, 8 << bits)
     _hip.check(lib.clo_hip_msd_histogram(src.ptr, n, es, 0, kb, bits, cnt.ptr, q.stream))
-    _hip.check(lib.clo_hip_msd_partition(src.ptr, dst.ptr, n, es, 0, kb, bits, ws.ptr, ws_bytes, q.stream))
+    _hip.check(lib.clo_hip_msd_partition(src.ptr, dst.ptr, n, es, 0, kb, bits, cnt2.ptr, ws.ptr, ws_bytes, q.stream))
     bucket = (a >> a.dtype.type(kb - bits)).astype(np.int64)
     assert np.array_equal(cnt.read(q, np.uint64, 1 << bits), np.bincount(bucket, minlength=1 << bits).astype(np.uint64))
+    assert np.array_equal(cnt2.read(q, np.uint64, 1 << bits), np.bincount(bucket, minlength=1 << bits).astype(np.uint64))
+    cnt2.close()
     assert np.array_equal(dst.read(q, a.dtype, n), a[np.argsort(bucket, kind="stable")])
     assert lib.clo_hip_check_status(ws.ptr, q.stream) == 0
     for b in (src, dst, cnt, ws):

@@ -31,9 +31,11 @@ class NumpyLocalOps:
         return torch.from_numpy(np.bincount(b.astype(np.int64), minlength=1 << bucket_bits).astype(np.int64))
 
     def msd_partition(self, src, dst, n, bucket_bits):
+        import torch
         a = self._view(src, n)
         b = a >> self.np_dtype(self.key_bits - bucket_bits)
         self._view(dst, n)[:] = a[np.argsort(b, kind="stable")]
+        return torch.from_numpy(np.bincount(b.astype(np.int64), minlength=1 << bucket_bits).astype(np.int64))
 
     def sort_inplace(self, t, n):
         import oracle_lib as O
