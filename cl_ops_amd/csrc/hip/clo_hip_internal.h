@@ -34,6 +34,7 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 	unsigned long long* counts, void* ws, hipStream_t s);
 int clo_radix4_set_log_tile(int log_tile);
 int clo_radix4_set_match(int on);
+void clo_radix4_set_debug_buffer(void* p);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
 	int key_bits, int digit_bits, void* ws, hipStream_t s);
 

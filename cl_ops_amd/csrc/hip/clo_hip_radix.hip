@@ -552,6 +552,7 @@ extern "C" {
 
 int clo_hip_radix_set_debug_buffer(void* dptr) {
 	g_dbg = (unsigned long long*) dptr;
+	clo_radix4_set_debug_buffer(dptr);
 	return 0;
 }
 

@@ -34,6 +34,7 @@ template <int LT> struct r4_shape {
 	static constexpr int TILE = 1 << LT;
 	static constexpr int LOG_TILE = LT;
 };
+unsigned long long* g_r4_dbg = nullptr;  // developer stamps buffer, see clo_hip_radix_set_debug_buffer
 int g_r4_match = 0;      // 1: use the match-any kernels instead of the packed-counter ones (A/B runs)
 int g_r4_log_tile4 = 12;  // tile shape for 4-byte elements: 4096 measured faster than 8192 (occupancy)
 
@@ -343,27 +344,18 @@ __device__ __forceinline__ unsigned wave_scan_dpp(unsigned x) {
 	return x;
 }
 
-// Thread-private digit counters: digit q lives in bits [4q, 4q+4) of lo (q < 8)
-// or hi (q >= 8). Good for up to 15 elements per thread.
+// Thread-private digit counters: digit q lives in bits [4q, 4q+4) of a 64-bit
+// word. Good for up to 15 elements per thread.
 struct packed4 {
-	unsigned lo, hi;
+	unsigned long long c;
 };
 
 // Count one digit; returns how many equal digits this thread counted before.
 template <int BITS>
 __device__ __forceinline__ unsigned packed4_count(packed4& c, unsigned d) {
-	const unsigned sh = (d & 7u) * 4u;
-	unsigned prev;
-	if (BITS <= 3) {
-		prev = (c.lo >> sh) & 15u;
-		c.lo += 1u << sh;
-	} else {
-		const bool up = d >= 8u;
-		prev = ((up ? c.hi : c.lo) >> sh) & 15u;
-		const unsigned inc = 1u << sh;
-		c.lo += up ? 0u : inc;
-		c.hi += up ? inc : 0u;
-	}
+	const unsigned sh = d * 4u;
+	const unsigned prev = (unsigned) (c.c >> sh) & 15u;
+	c.c += 1ull << sh;
 	return prev;
 }
 
@@ -374,7 +366,7 @@ template <int BITS>
 __device__ __forceinline__ void packed4_widen(const packed4& c, unsigned (&w)[pc_words<BITS>::H]) {
 	#pragma unroll
 	for (int j = 0; j < pc_words<BITS>::H; ++j) {
-		const unsigned x = j < 4 ? c.lo : c.hi;
+		const unsigned x = j < 4 ? (unsigned) c.c : (unsigned) (c.c >> 32);
 		const int q = (j & 3) * 8;
 		w[j] = ((x >> q) & 15u) | (((x >> (q + 4)) & 15u) << 16);
 	}
@@ -407,7 +399,7 @@ void clo_radix4_tilehist_pc_kernel(const E* __restrict__ in, size_t n, unsigned 
 	const size_t base = (size_t) blockIdx.x * TILE;
 	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
 	const unsigned tbase = tid * ITEMS;
-	packed4 c = { 0u, 0u };
+	packed4 c = { 0ull };
 	if (count == (unsigned) TILE) {
 		E key[ITEMS];
 		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
@@ -434,30 +426,75 @@ void clo_radix4_tilehist_pc_kernel(const E* __restrict__ in, size_t n, unsigned 
 	}
 }
 
+// ---- pass kernel: two-stage packed scan ----
+// The thread-private 4-bit counters first widen to 8-bit fields only (4
+// digits per VGPR): an inclusive scan inside a row of 16 lanes cannot exceed
+// 16 * 15 = 240. Only then do they widen to 16-bit fields for the two
+// cross-row steps. Field order after the two widenings: 16-bit field `half`
+// of word j holds digit pc2_digit(j, half).
+template <int BITS> struct pc2 {
+	static constexpr int R = 1 << BITS;
+	static constexpr int NB = R == 16 ? 4 : 2;   // words of 8-bit fields
+	static constexpr int NW = 2 * NB;            // words of 16-bit fields
+};
+__host__ __device__ constexpr int pc2_digit(int j, int half) {
+	return ((j >> 2) & 1) * 8 + ((j >> 1) & 1) + (j & 1) * 2 + half * 4;
+}
+
+// Inclusive scan over the wave of every digit's thread-private count.
+template <int BITS>
+__device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned (&w)[pc2<BITS>::NW]) {
+	constexpr int NB = pc2<BITS>::NB;
+	unsigned b[NB];
+	const unsigned lo = (unsigned) c, hi = (unsigned) (c >> 32);
+	b[0] = lo & 0x0f0f0f0fu;
+	b[1] = (lo >> 4) & 0x0f0f0f0fu;
+	if constexpr (NB == 4) {
+		b[2] = hi & 0x0f0f0f0fu;
+		b[3] = (hi >> 4) & 0x0f0f0f0fu;
+	}
+	#pragma unroll
+	for (int k = 0; k < NB; ++k) {
+		unsigned x = b[k];
+		x = dpp_add<0x111, 0xF>(x);
+		x = dpp_add<0x112, 0xF>(x);
+		x = dpp_add<0x114, 0xF>(x);
+		x = dpp_add<0x118, 0xF>(x);
+		unsigned e = x & 0x00ff00ffu, o = (x >> 8) & 0x00ff00ffu;
+		e = dpp_add<0x142, 0xA>(e);
+		o = dpp_add<0x142, 0xA>(o);
+		w[2 * k] = dpp_add<0x143, 0xC>(e);
+		w[2 * k + 1] = dpp_add<0x143, 0xC>(o);
+	}
+}
+
 template <typename E, int BITS, int LT>
 __global__ __launch_bounds__(R4_THREADS)
 void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff,
-	unsigned* __restrict__ thist_next, int aligned) {
+	unsigned* __restrict__ thist_next, int aligned, unsigned long long* dbg) {
 
 	constexpr int R = 1 << BITS;
-	constexpr int H = pc_words<BITS>::H;
+	constexpr int NW = pc2<BITS>::NW;
 	constexpr int ITEMS = r4_shape<LT>::ITEMS;
 	constexpr int TILE = r4_shape<LT>::TILE;
 	constexpr int LOG_TILE = r4_shape<LT>::LOG_TILE;
-	static_assert(ITEMS <= 15, "4-bit thread-private counters");
+	static_assert(ITEMS <= 15, "4-bit thread-private counters, 8-bit row sums");
 	static_assert(TILE <= 65536 / 2, "16-bit positions");
+	// developer diagnostics: phase stamps of the first 32768 tiles (dbg != NULL only in tools/stamp_probe.py)
+	#define CLO_STAMP(k) do { if (dbg && threadIdx.x == 0 && blockIdx.x < 32768u) dbg[(size_t) blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+	CLO_STAMP(0);
 
 	__shared__ E s_stage[TILE];
-	__shared__ unsigned s_scr[H][R4_THREADS];      // [word][thread]: tile-local start of the thread's slice of each digit
-	                                               // (16-bit fields); a lane only touches its own column: conflict-free
-	__shared__ unsigned s_wtot[R4_WAVES][H];       // wave totals
-	__shared__ unsigned s_wbase[R4_WAVES][H];      // digit start + totals of earlier waves
-	__shared__ unsigned s_next[R][2][R];           // [digit][destination tile 0/1][next digit]
-	__shared__ unsigned s_delta[R];                // global index = tile-local position + delta[digit]
-	__shared__ unsigned s_comb[R];                 // s_next row of (digit, destination tile t) = t*R + comb[digit]
-	__shared__ unsigned s_dstart16[H];             // tile-local digit starts, packed like the counters
+	__shared__ unsigned short s_end[R][R4_THREADS];   // [digit][thread]: tile-local END of the thread's slice of the digit;
+	                                                  // a lane only touches its own column
+	__shared__ unsigned s_wtot[R4_WAVES][NW];         // wave totals (packed like pc2_wave_scan's result)
+	__shared__ unsigned s_wbase[R4_WAVES][NW];        // digit start + totals of earlier waves
+	__shared__ unsigned s_next[R][2][R];              // [digit][destination tile 0/1][next digit]
+	__shared__ unsigned s_delta[R];                   // global index = tile-local position + delta[digit]
+	__shared__ unsigned s_comb[R];                    // s_next row of (digit, destination tile t) = t*R + comb[digit]
+	__shared__ unsigned s_dstart16[NW];               // tile-local digit starts, packed like the counters
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const unsigned tile = blockIdx.x;
@@ -465,6 +502,16 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
 	const bool full = count == (unsigned) TILE;
 	const unsigned tbase = tid * ITEMS;
+
+	// tile bookkeeping from the scanned counters (upstream's offsets /
+	// counters_sum): requested BEFORE the keys so that their latency hides
+	// behind the key loads instead of stalling wave 0 in front of a barrier
+	unsigned h = 0, goff = 0;
+	if (tid < (unsigned) R) {
+		h = thist[(size_t) tile * R + tid];
+		goff = toff[(size_t) tile * R + tid];
+	}
+	for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) (&s_next[0][0][0])[i] = 0;
 
 	// ---- 1. load: ITEMS consecutive elements per thread (16-byte vector loads) ----
 	E key[ITEMS];
@@ -475,83 +522,144 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
 	}
 
-	// tile bookkeeping from the scanned counters (upstream's offsets / counters_sum)
-	for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) (&s_next[0][0][0])[i] = 0;
-	if (tid < 64) {
-		const unsigned h = tid < (unsigned) R ? thist[(size_t) tile * R + tid] : 0u;
-		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
-		const unsigned odd = (unsigned) __shfl((int) dstart, (int) (lane | 1u), 64);
-		if (tid < (unsigned) R) {
-			const unsigned goff = toff[(size_t) tile * R + tid];
-			s_delta[tid] = goff - dstart;
-			s_comb[tid] = tid * 2u * R - ((goff >> LOG_TILE) << BITS);
-			if ((tid & 1u) == 0) s_dstart16[tid >> 1] = dstart | ((R > 1 ? odd : 0u) << 16);
+	if (dbg) { asm volatile("" :: "v"((unsigned) key[ITEMS - 1])); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+	CLO_STAMP(1);
+
+	// ---- 2a. thread-private digit counts, LAST element first: rr = 1 + the
+	// number of LATER elements of the thread with the same digit, so that the
+	// element's position is (end of the thread's slice of that digit) - rr ----
+	unsigned long long c = 0;
+	unsigned rr = 0;   // 4 bits per element
+	#pragma unroll
+	for (int i = ITEMS - 1; i >= 0; --i) {
+		if (full || tbase + i < count) {
+			const unsigned sh = ((unsigned) (key[i] >> shift) & mask) * 4u;
+			c += 1ull << sh;
+			rr |= ((unsigned) (c >> sh) & 15u) << (4 * i);
 		}
 	}
 
-	// ---- 2a. thread-private digit counts; rank of each element among the thread's own ----
-	packed4 c = { 0u, 0u };
-	unsigned lrank = 0;   // 4 bits per element
-	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) {
-		if (full || tbase + i < count)
-			lrank |= packed4_count<BITS>(c, (unsigned) (key[i] >> shift) & mask) << (4 * i);
+	// ---- 2b. inclusive count of every digit over the threads of the wave ----
+	unsigned w[NW];
+	pc2_wave_scan<BITS>(c, w);
+	if (lane == 63) {
+		#pragma unroll
+		for (int j = 0; j < NW; ++j) s_wtot[wave][j] = w[j];
 	}
-
-	// ---- 2b. count of every digit among all earlier threads of the tile ----
-	unsigned w[H];
-	packed4_widen<BITS>(c, w);
-	#pragma unroll
-	for (int j = 0; j < H; ++j) {
-		const unsigned incl = wave_scan_dpp(w[j]);
-		if (lane == 63) s_wtot[wave][j] = incl;
-		w[j] = incl - w[j];   // exclusive within the wave
+	if (tid < 64) {
+		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
+		if (tid < (unsigned) R) {
+			s_delta[tid] = goff - dstart;
+			s_comb[tid] = tid * 2u * R - ((goff >> LOG_TILE) << BITS);
+		}
+		// gather the starts into the packed field order (lanes >= R hold the tile count: unused digits)
+		const unsigned j = lane & (NW - 1);
+		const unsigned d0 = ((j >> 2) & 1u) * 8u + ((j >> 1) & 1u) + (j & 1u) * 2u;
+		const unsigned lo16 = (unsigned) __shfl((int) dstart, (int) d0, 64);
+		const unsigned hi16 = (unsigned) __shfl((int) dstart, (int) (d0 + 4u), 64);
+		if (tid < (unsigned) NW) s_dstart16[tid] = (d0 < (unsigned) R ? lo16 : 0u) | ((d0 + 4u < (unsigned) R ? hi16 : 0u) << 16);
 	}
+	CLO_STAMP(2);
 	__syncthreads();
-	if (tid < R4_WAVES * H) {
-		const unsigned wv = tid / H, j = tid % H;
+	CLO_STAMP(3);
+	if (tid < R4_WAVES * NW) {
+		const unsigned wv = tid / NW, j = tid % NW;
 		unsigned run = s_dstart16[j];
 		for (unsigned k = 0; k < wv; ++k) run += s_wtot[k][j];
 		s_wbase[wv][j] = run;
 	}
 	__syncthreads();
+	CLO_STAMP(4);
 	#pragma unroll
-	for (int j = 0; j < H; ++j) s_scr[j][tid] = w[j] + s_wbase[wave][j];
+	for (int j = 0; j < NW; ++j) {
+		const unsigned x = w[j] + s_wbase[wave][j];
+		if (pc2_digit(j, 0) < R) s_end[pc2_digit(j, 0) < R ? pc2_digit(j, 0) : 0][tid] = (unsigned short) (x & 0xffffu);
+		if (pc2_digit(j, 1) < R) s_end[pc2_digit(j, 1) < R ? pc2_digit(j, 1) : 0][tid] = (unsigned short) (x >> 16);
+	}
 
 	// ---- 4a. scatter into the LDS stage in digit order ----
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		if (full || tbase + i < count) {
 			const unsigned d = (unsigned) (key[i] >> shift) & mask;
-			const unsigned start = (s_scr[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
-			const unsigned pos = start + ((lrank >> (4 * i)) & 15u);
-			s_stage[pos] = key[i];
+			const unsigned pos = (unsigned) s_end[d][tid] - ((rr >> (4 * i)) & 15u);
+			s_stage[pos & (TILE - 1)] = key[i];
 		}
 	}
+	if (dbg) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	CLO_STAMP(5);
 	__syncthreads();
+	CLO_STAMP(6);
 
 	// ---- 4b. contiguous runs to HBM; 5. next digit's per-tile histogram ----
+	// A thread takes VEC consecutive positions of the digit-sorted tile (one
+	// 16-byte LDS read). Inside a digit run they go to consecutive global
+	// indices: one 16-byte store (only element alignment is guaranteed, which
+	// global memory accepts); a group that straddles two runs is stored
+	// element by element.
+	constexpr int VEC = sizeof(E) >= 8 ? 2 : 4;
+	typedef E vecE __attribute__((ext_vector_type(VEC)));
+	typedef E vecE_u __attribute__((ext_vector_type(VEC), aligned(sizeof(E))));
+	unsigned* const next_flat = &s_next[0][0][0];
+	auto count_next = [&](E e, unsigned d, unsigned gi) {
+		const unsigned row = ((gi >> LOG_TILE) << BITS) + s_comb[d];   // (digit*2 + destination tile 0/1) * R
+		atomicAdd(&next_flat[(row + ((unsigned) (e >> next_shift) & next_mask)) & (2u * R * R - 1u)], 1u);
+	};
+	const unsigned n32 = n > 0xffffffffull ? 0xffffffffu : (unsigned) n;   // global indices are 32-bit here
 	#pragma unroll
-	for (int j = 0; j < ITEMS; ++j) {
-		const unsigned p = j * R4_THREADS + tid;
-		if (full || p < count) {
-			const E e = s_stage[p];
-			const unsigned d = (unsigned) (e >> shift) & mask;
-			const unsigned gi = p + s_delta[d];
-			if ((size_t) gi < n) {
-				out[gi] = e;
+	for (int j = 0; j < ITEMS / VEC; ++j) {
+		const unsigned p = (j * R4_THREADS + tid) * VEC;
+		if (full) {
+			const vecE v = *reinterpret_cast<const vecE*>(&s_stage[p]);
+			const unsigned d0 = (unsigned) (v[0] >> shift) & mask, dl = (unsigned) (v[VEC - 1] >> shift) & mask;
+			const unsigned gi0 = p + s_delta[d0];
+			if (d0 == dl && gi0 <= n32 - VEC) {
+				*reinterpret_cast<vecE_u*>(&out[gi0]) = v;
 				if (has_next) {
-					const unsigned row = ((gi >> LOG_TILE) << BITS) + s_comb[d];   // (digit*2 + tile 0/1) * R
-					atomicAdd(&(&s_next[0][0][0])[(row + ((unsigned) (e >> next_shift) & next_mask)) & (2u * R * R - 1u)], 1u);
+					if ((gi0 >> LOG_TILE) == ((gi0 + VEC - 1) >> LOG_TILE)) {
+						// one destination tile: one row of the table
+						unsigned* const rowp = &next_flat[(((gi0 >> LOG_TILE) << BITS) + s_comb[d0]) & (2u * R * R - R)];
+						#pragma unroll
+						for (int k = 0; k < VEC; ++k) atomicAdd(&rowp[(unsigned) (v[k] >> next_shift) & next_mask & (R - 1u)], 1u);
+					} else {
+						#pragma unroll
+						for (int k = 0; k < VEC; ++k) count_next(v[k], d0, gi0 + k);
+					}
+				}
+			} else {
+				#pragma unroll
+				for (int k = 0; k < VEC; ++k) {
+					const unsigned d = (unsigned) (v[k] >> shift) & mask;
+					const unsigned gi = p + k + s_delta[d];
+					if (gi < n32) {
+						out[gi] = v[k];
+						if (has_next) count_next(v[k], d, gi);
+					}
+				}
+			}
+		} else {
+			#pragma unroll
+			for (int k = 0; k < VEC; ++k) {
+				if (p + k < count) {
+					const E e = s_stage[p + k];
+					const unsigned d = (unsigned) (e >> shift) & mask;
+					const unsigned gi = p + k + s_delta[d];
+					if (gi < n32) {
+						out[gi] = e;
+						if (has_next) count_next(e, d, gi);
+					}
 				}
 			}
 		}
 	}
+	if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	CLO_STAMP(7);
+	#undef CLO_STAMP
 	if (has_next) {
 		__syncthreads();
 		// 16 consecutive lanes = the 16 counters of one destination tile (64 B)
 		for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) {
-			const unsigned v = (&s_next[0][0][0])[i];
+			const unsigned v = next_flat[i];
 			if (v) {
 				const unsigned d = i / (2 * R), half = (i / R) & 1u, dn = i % R;
 				const unsigned first = (d * 2u * R - s_comb[d]) >> BITS;
@@ -592,7 +700,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n,
 		const unsigned shift = key_shift + done;
 		const unsigned bits = key_bits - done < (unsigned) BITS ? key_bits - done : (unsigned) BITS;
 		const unsigned mask = (1u << bits) - 1u;
-		packed4 c = { 0u, 0u };
+		packed4 c = { 0ull };
 		unsigned lrank = 0;
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
@@ -733,7 +841,7 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 						cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
 						has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
 						(const unsigned*) th, (const unsigned*) toff, th + per_pass,
-						(int) ((uintptr_t) cur_in % 16 == 0));
+						(int) ((uintptr_t) cur_in % 16 == 0), g_r4_dbg);
 			} else {
 				hipLaunchKernelGGL((clo_radix4_pass_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
 					cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
@@ -797,7 +905,7 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 		(const unsigned*) thist, tiles, (const unsigned*) partial, chunks, toff);
 	hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
 		src, dst, n, shift, R - 1u, 0, 0u, 0u, (const unsigned*) thist, (const unsigned*) toff,
-		thist + (L.tiles + 1) * R, (int) ((uintptr_t) src % 16 == 0));
+		thist + (L.tiles + 1) * R, (int) ((uintptr_t) src % 16 == 0), (unsigned long long*) nullptr);
 	return (int) hipGetLastError();
 }
 
@@ -845,6 +953,8 @@ int clo_radix4_set_log_tile(int log_tile) {
 	g_r4_log_tile4 = log_tile;
 	return 0;
 }
+
+void clo_radix4_set_debug_buffer(void* p) { g_r4_dbg = (unsigned long long*) p; }
 
 int clo_radix4_set_match(int on) {
 	g_r4_match = on != 0;

@@ -18,10 +18,10 @@ lib.clo_hip_radix_set_debug_buffer(dbg.ptr)
 s.with_device_data(q, src, dst, n); q.finish()
 lib.clo_hip_radix_set_debug_buffer(None)
 st = dbg.read(q, np.uint64, 32768 * 8).reshape(-1, 8).astype(np.int64)   # stamps of the LAST pass
-ntiles = min(32768, (n + 8191) // 8192)
+ntiles = min(32768, (n + 4095) // 4096)
 st = st[:ntiles]
 d = np.diff(st, axis=1)
-names = ["load", "next+rank", "barrierA", "hist+publish+scan", "pos+ldswrite", "lookback", "barrier+store"]
+names = ["load", "count+wave scan", "barrier", "wave bases+barrier", "scatter to LDS", "barrier", "read-out+stores"]
 print("tiles", ntiles, "clock ticks (100MHz s_memtime? see below)")
 for k, nm in enumerate(names):
     print("%-20s median %8.0f  p10 %8.0f  p90 %8.0f" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
