@@ -56,7 +56,7 @@ _sig("clo_hip_error_string", C.c_char_p, ci)
 _sig("clo_hip_scan_workspace_bytes", sz, sz, ci, ci)
 _sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_radix_workspace_bytes", sz, sz, ci, ci, ci)
-_sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, vp, sz, vp)
+_sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)
 _sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, vp, sz, vp)
 _sig("clo_hip_msd_workspace_bytes", sz, sz, ci, ci)
@@ -71,7 +71,6 @@ _sig("clo_hip_check_status", ci, vp, vp)
 _sig("clo_hip_timing_enable", ci, ci)
 _sig("clo_hip_timing_reset", ci)
 _sig("clo_hip_timing_read", ci, C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float))
-_sig("clo_hip_radix_set_variant", ci, ci)
 _sig("clo_hip_radix_set_debug_buffer", ci, vp)
 
 

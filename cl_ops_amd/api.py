@@ -20,8 +20,8 @@ CLO_TYPES = {"char": 0, "uchar": 1, "short": 2, "ushort": 3, "int": 4, "uint": 5
              "long": 6, "ulong": 7, "half": 8, "float": 9, "double": 10}
 _NP_TO_CLO = {np.dtype(np.int8): "char", np.dtype(np.uint8): "uchar", np.dtype(np.int16): "short",
               np.dtype(np.uint16): "ushort", np.dtype(np.int32): "int", np.dtype(np.uint32): "uint",
-              np.dtype(np.int64): "long", np.dtype(np.uint64): "ulong", np.dtype(np.float32): "float",
-              np.dtype(np.float64): "double"}
+              np.dtype(np.int64): "long", np.dtype(np.uint64): "ulong", np.dtype(np.float16): "half",
+              np.dtype(np.float32): "float", np.dtype(np.float64): "double"}
 CLO_TYPE_NP = {v: k for k, v in _NP_TO_CLO.items()}
 
 CL_QUEUE_PROFILING_ENABLE = 1 << 1

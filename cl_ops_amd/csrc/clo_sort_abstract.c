@@ -76,10 +76,31 @@ static int parse_number(cursor* c, unsigned long long* out) {
 
 static keyfn parse_and(cursor* c);
 
-/* primary := cast primary | '(' and ')' | 'x' */
+/* OpenCL C reinterpretation "as_<type>(": keeps the bits, so it acts like a
+ * cast to an integer of that size. Returns the size or 0. */
+static int parse_as_type(cursor* c) {
+	static const struct { const char* name; int size; } names[] = {
+		{"as_uchar", 1}, {"as_char", 1}, {"as_ushort", 2}, {"as_short", 2}, {"as_half", 2},
+		{"as_uint", 4}, {"as_int", 4}, {"as_float", 4}, {"as_ulong", 8}, {"as_long", 8}, {"as_double", 8}
+	};
+	skip_ws(c);
+	for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) {
+		size_t n = strlen(names[i].name);
+		if (strncmp(c->p, names[i].name, n) == 0) {
+			cursor t = *c;
+			t.p += n;
+			skip_ws(&t);
+			if (*t.p == '(') { *c = t; return names[i].size; }   /* the '(' is left for parse_primary */
+		}
+	}
+	return 0;
+}
+
+/* primary := cast primary | as_type '(' and ')' | '(' and ')' | 'x' */
 static keyfn parse_primary(cursor* c) {
 	keyfn f = {0, ~0ull, 0};
 	int cast = parse_cast(c);
+	if (!cast) cast = parse_as_type(c);
 	if (cast) {
 		f = parse_primary(c);
 		if (f.ok && cast < 8) f.mask &= (1ull << (8 * cast)) - 1ull;
@@ -202,13 +223,9 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_UNKNOWN_TYPE, "Unknown element or key type");
 			goto error_handler;
 		}
-		if (sorter->elem_type == CLO_HALF || sorter->key_type == CLO_HALF) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Type 'half' is not supported by the HIP build");
-			goto error_handler;
-		}
 		const int is_bitonic = strcmp(type, "sbitonic") == 0 || strcmp(type, "abitonic") == 0;
 		const int key_ok = parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)
-			&& !(ks->key_kind == 2 && (ks->key_shift != 0 || ks->key_bits != 8 * ks->key_size || ks->elem_size != ks->key_size));
+			&& !(ks->key_kind == 2 && ks->key_bits != 8 * ks->key_size);   /* a float key is the whole key type */
 		const int cmp_ok = parse_compare(compare, &ks->descending);
 		if (!key_ok || !cmp_ok) {
 			if (!is_bitonic) {

@@ -70,10 +70,18 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 	void* stream = ccl_queue_get_stream(cq_exec);
 	CCLEvent* evt = NULL;
 
-	if (ks->key_kind == 2) {
-		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "satradix sorts integer keys only");
+	/* Signed and floating-point keys: upstream's kernels order every type by
+	 * its raw bits (ref: clo_sort_satradix.cl:34-258 never look at the type), so
+	 * negative keys end up after the positive ones and upstream's own check
+	 * (benchmarks/clo_bench.c:26-65) rejects the result. Here such keys go through
+	 * an order-preserving transform inside the first and last pass; non-negative
+	 * inputs give the same output as upstream. A float key must be the whole
+	 * key type (no sub-field of a float). */
+	if (ks->key_kind == 2 && ks->key_bits != 8 * ks->key_size) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "satradix: a floating-point key must span its whole type");
 		return NULL;
 	}
+	const int key_kind = (ks->key_kind == 1 && ks->key_bits < 8 * ks->key_size) ? 0 : ks->key_kind;  /* sign bit masked off */
 	if (bytes > ccl_buffer_get_size(data_in) || (data_out && bytes > ccl_buffer_get_size(data_out))) {
 		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "numel (%zu) exceeds the size of the device buffers", numel);
 		return NULL;
@@ -104,7 +112,7 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		void* src = ccl_buffer_get_device_ptr(data_in);
 		void* dst = data_out ? ccl_buffer_get_device_ptr(data_out) : src;
 		int st = clo_hip_radix_sort(src, dst, data->tmp.ptr, numel, ks->elem_size, ks->key_shift,
-			ks->key_bits, bits_in_digit, data->workspace.ptr, data->workspace.bytes, stream);
+			ks->key_bits, key_kind, bits_in_digit, data->workspace.ptr, data->workspace.bytes, stream);
 		if (clo_hip_failed(st, err, "clo_hip_radix_sort")) return NULL;
 	}
 

@@ -214,7 +214,7 @@ int make_desc(int key_shift, int key_bits, int key_size, int key_kind, int desce
 	if (key_bits < 1 || key_bits > 8 * key_size) return CLO_HIP_EARGS;
 	if (key_shift < 0 || key_shift + key_bits > 8 * (int) sizeof(E)) return CLO_HIP_EARGS;
 	if (key_kind < 0 || key_kind > 2) return CLO_HIP_EARGS;
-	if (key_kind == 2 && ((key_size != 4 && key_size != 8) || key_bits != 8 * key_size)) return CLO_HIP_EUNSUPPORTED;
+	if (key_kind == 2 && (key_size < 2 || key_bits != 8 * key_size)) return CLO_HIP_EUNSUPPORTED;
 	kd->shift = (unsigned) key_shift;
 	kd->kind = (unsigned) key_kind;
 	kd->descending = descending ? 1u : 0u;
@@ -381,11 +381,10 @@ size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
 		const size_t v = elem_size == 8 ? 16 : 32;
 		return (256 * v + 256 * v / 32) * (size_t) elem_size;
 	}
-	if (f == "radix_hist") return 4 * 256 * sizeof(unsigned);
-	if (f == "radix_pass") {
-		const size_t R = (size_t) 1 << (param < 1 ? 1 : (param > 8 ? 8 : param));
-		const size_t tile = 512u * (elem_size == 8 ? 8 : 16);
-		return tile * (size_t) elem_size + (2 * 8 * R + 2 * R + 5) * sizeof(unsigned);
+	if (f == "radix_hist" || f == "radix_pass") {
+		const int bits = param < 1 ? 1 : (param > 8 ? 8 : param);
+		return bits <= 4 ? clo_radix4_lds_bytes(f == "radix_hist" ? "hist" : "pass", elem_size, bits)
+		                 : clo_radixw_lds_bytes(f == "radix_hist" ? "hist" : "pass", elem_size, bits);
 	}
 	if (f == "scan") return ((param > 4 ? 8 : 16) * 4 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;
 	return 0;  // bitonic_strided, bitonic_step: registers only

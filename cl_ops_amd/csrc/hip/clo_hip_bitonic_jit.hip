@@ -154,7 +154,7 @@ struct jit_sorter {
 const char* ctype_of(int clo_type) {
 	// CloType numbering (clo_common.h)
 	static const char* names[] = { "signed char", "unsigned char", "short", "unsigned short", "int", "unsigned int",
-		"long", "unsigned long", nullptr, "float", "double" };
+		"long", "unsigned long", "_Float16", "float", "double" };
 	return (clo_type >= 0 && clo_type <= 10) ? names[clo_type] : nullptr;
 }
 

@@ -27,16 +27,53 @@ struct clo_timing_scope {
 	~clo_timing_scope() { clo_timing_end(s); }
 };
 
+// Order-preserving key transform for signed / floating-point radix keys,
+// applied to the key field [shift, shift+bits) of an element when the first
+// pass reads the source and undone when the last pass stores the result:
+//   kind 1 (two's complement): flip the sign bit;
+//   kind 2 (IEEE-754): negative -> flip every key bit, else flip the sign bit.
+// kind 0 = unsigned keys, nothing to do (a wave-uniform branch).
+struct clo_keyx {
+	unsigned long long sign, field;
+	int kind;
+};
+template <typename E>
+__device__ __forceinline__ E clo_keyx_fwd(E x, const clo_keyx& k) {
+	if (k.kind == 1) return (E) (x ^ (E) k.sign);
+	if (k.kind == 2) return (E) (x ^ ((x & (E) k.sign) ? (E) k.field : (E) k.sign));
+	return x;
+}
+template <typename E>
+__device__ __forceinline__ E clo_keyx_inv(E x, const clo_keyx& k) {
+	if (k.kind == 1) return (E) (x ^ (E) k.sign);
+	if (k.kind == 2) return (E) (x ^ ((x & (E) k.sign) ? (E) k.sign : (E) k.field));
+	return x;
+}
+inline clo_keyx clo_keyx_make(int kind, int key_shift, int key_bits) {
+	clo_keyx k = { 0, 0, 0 };
+	if (kind == 1 || kind == 2) {
+		k.kind = kind;
+		k.sign = 1ull << (key_shift + key_bits - 1);
+		k.field = (key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull)) << key_shift;
+	}
+	return k;
+}
+
 // Chain-free radix path for digits of <= 4 bits (clo_hip_radix4.hip).
 size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int digit_bits);
 size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits);
 int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
 	unsigned long long* counts, void* ws, hipStream_t s);
-int clo_radix4_set_log_tile(int log_tile);
-int clo_radix4_set_match(int on);
 void clo_radix4_set_debug_buffer(void* p);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
-	int key_bits, int digit_bits, void* ws, hipStream_t s);
+	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
+
+// Chain-free radix path for digits of 5..8 bits (clo_hip_radixw.hip).
+size_t clo_radixw_workspace_bytes(size_t n, int elem_size, int digit_bits);
+size_t clo_radixw_lds_bytes(const char* kernel, int elem_size, int digit_bits);
+int clo_radixw_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
+	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
+size_t clo_radix4_lds_bytes(const char* kernel, int elem_size, int digit_bits);
 
 typedef unsigned long long clo_u64;
 

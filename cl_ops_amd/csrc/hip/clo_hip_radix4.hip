@@ -5,7 +5,7 @@
 //   per-tile digit histogram -> scan of the counters -> scatter,
 // with two changes that remove every redundant pass over the keys:
 //   * the tile-local sort + scatter of a digit is ONE kernel that reads each
-//     element once and writes it once (clo_radix4_pass_kernel);
+//     element once and writes it once (clo_radix4_pass_pc_kernel);
 //   * the per-tile histogram of the NEXT digit is accumulated by that same
 //     kernel while it scatters: an element's destination index, hence its tile
 //     in the next pass, is known when it is stored. Elements of one (tile,
@@ -28,65 +28,14 @@ namespace {
 constexpr int R4_THREADS = 512;
 constexpr int R4_WAVES = R4_THREADS / 64;
 
-// LT = log2(tile elements): 13 (16 items per thread) or 12 (8 items per thread)
+// LT = log2(tile elements) = 12: 8 items per thread (4096-element tiles measured
+// faster than 8192: occupancy)
 template <int LT> struct r4_shape {
 	static constexpr int ITEMS = (1 << LT) / R4_THREADS;
 	static constexpr int TILE = 1 << LT;
 	static constexpr int LOG_TILE = LT;
 };
 unsigned long long* g_r4_dbg = nullptr;  // developer stamps buffer, see clo_hip_radix_set_debug_buffer
-int g_r4_match = 0;      // 1: use the match-any kernels instead of the packed-counter ones (A/B runs)
-int g_r4_log_tile4 = 12;  // tile shape for 4-byte elements: 4096 measured faster than 8192 (occupancy)
-
-// Lanes of the wave holding the same digit as the caller (match-any by one
-// ballot per digit bit), restricted to `valid` lanes.
-template <int BITS>
-__device__ __forceinline__ clo_u64 match_digit(unsigned d, clo_u64 valid_mask) {
-	clo_u64 peers = valid_mask;
-	#pragma unroll
-	for (int k = 0; k < BITS; ++k) {
-		const bool bit = (d >> k) & 1u;
-		const clo_u64 b = __ballot(bit);
-		peers &= bit ? b : ~b;
-	}
-	return peers;
-}
-
-// ---------------------------------------------------------------------------
-// first digit: per-tile histogram (upstream's satradix_histogram job)
-// ---------------------------------------------------------------------------
-template <typename E, int BITS, int LT>
-__global__ __launch_bounds__(R4_THREADS)
-void clo_radix4_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
-	unsigned* __restrict__ thist) {
-	constexpr int R = 1 << BITS;
-	constexpr int ITEMS = r4_shape<LT>::ITEMS;
-	constexpr int TILE = r4_shape<LT>::TILE;
-	__shared__ unsigned s_cnt[R4_WAVES][R];
-	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const size_t base = (size_t) blockIdx.x * TILE;
-	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-	if (tid < R4_WAVES * R) (&s_cnt[0][0])[tid] = 0;
-	__syncthreads();
-	const unsigned wbase = wave * 64u * ITEMS + lane;
-	E key[ITEMS];
-	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) key[i] = (wbase + i * 64 < count) ? in[base + wbase + i * 64] : (E) 0;
-	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) {
-		const bool valid = wbase + i * 64 < count;
-		const unsigned d = (unsigned) (key[i] >> shift) & mask;
-		const clo_u64 peers = match_digit<BITS>(d, __ballot(valid));
-		if (valid && clo_mbcnt(peers) == 0) atomicAdd(&s_cnt[wave][d], (unsigned) __popcll(peers));
-	}
-	__syncthreads();
-	if (tid < (unsigned) R) {
-		unsigned h = 0;
-		#pragma unroll
-		for (int w = 0; w < R4_WAVES; ++w) h += s_cnt[w][tid];
-		thist[(size_t) blockIdx.x * R + tid] = h;
-	}
-}
 
 // ---------------------------------------------------------------------------
 // counts[tile][digit] -> offsets[tile][digit] in digit-major order:
@@ -184,147 +133,17 @@ void clo_radix4_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 }
 
 // ---------------------------------------------------------------------------
-// one digit: tile-local stable sort + scatter, and the next digit's histogram
-// ---------------------------------------------------------------------------
-template <typename E, int BITS, int LT>
-__global__ __launch_bounds__(R4_THREADS)
-void clo_radix4_pass_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
-	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
-	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff,
-	unsigned* __restrict__ thist_next) {
-
-	constexpr int R = 1 << BITS;
-	constexpr int ITEMS = r4_shape<LT>::ITEMS;
-	constexpr int TILE = r4_shape<LT>::TILE;
-	constexpr int LOG_TILE = r4_shape<LT>::LOG_TILE;
-
-	__shared__ E s_stage[TILE];
-	__shared__ unsigned s_wcnt[R4_WAVES][R];   // per-wave digit counts, then running position of (wave, digit)
-	__shared__ unsigned s_next[R][2][R];       // [digit][destination tile 0/1][next digit]
-	__shared__ unsigned s_delta[R];            // global index = tile-local position + delta[digit]
-	__shared__ unsigned s_first[R];            // first destination tile of the digit's run
-	__shared__ unsigned s_dstart[R];           // tile-local start of the digit's run
-
-	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const unsigned tile = blockIdx.x;
-	const size_t base = (size_t) tile * TILE;
-	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-	const bool full = count == (unsigned) TILE;
-	const unsigned wbase = wave * 64u * ITEMS + lane;
-
-	// ---- 1. load, wave-striped: lane l of wave w holds tile element w*64*ITEMS + i*64 + l ----
-	E key[ITEMS];
-	if (full) {
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) key[i] = in[base + wbase + i * 64];
-	} else {
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) key[i] = (wbase + i * 64 < count) ? in[base + wbase + i * 64] : (E) 0;
-	}
-
-	// tile bookkeeping from the scanned counters (upstream's offsets / counters_sum)
-	if (tid < R4_WAVES * R) (&s_wcnt[0][0])[tid] = 0;
-	for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) (&s_next[0][0][0])[i] = 0;
-	if (tid < 64) {
-		const unsigned h = tid < (unsigned) R ? thist[(size_t) tile * R + tid] : 0u;
-		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
-		if (tid < (unsigned) R) {
-			const unsigned goff = toff[(size_t) tile * R + tid];
-			s_dstart[tid] = dstart;
-			s_delta[tid] = goff - dstart;
-			s_first[tid] = goff >> LOG_TILE;
-		}
-	}
-	__syncthreads();
-
-	// ---- 2a. match: per item, the lanes of my wave holding my digit; the
-	// group's first lane adds the group size to the wave's digit count
-	// (distinct LDS addresses within one instruction: no atomic conflicts) ----
-	unsigned grp[ITEMS];
-	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) {
-		const bool valid = full || (wbase + i * 64 < count);
-		const unsigned d = (unsigned) (key[i] >> shift) & mask;
-		const clo_u64 peers = match_digit<BITS>(d, full ? ~0ull : __ballot(valid));
-		const unsigned r = clo_mbcnt(peers);
-		const unsigned c = (unsigned) __popcll(peers);
-		const unsigned leader = valid ? (unsigned) (__ffsll((long long) peers) - 1) : lane;
-		if (valid && r == 0) atomicAdd(&s_wcnt[wave][d], c);
-		grp[i] = r | (c << 8) | (leader << 16);
-	}
-	__syncthreads();
-
-	// ---- start of every (wave, digit) run inside the tile ----
-	if (tid < (unsigned) R) {
-		unsigned run = s_dstart[tid];
-		#pragma unroll
-		for (int w = 0; w < R4_WAVES; ++w) {
-			const unsigned c = s_wcnt[w][tid];
-			s_wcnt[w][tid] = run;
-			run += c;
-		}
-	}
-	__syncthreads();
-
-	// ---- 2b. rank: the group's first lane takes the group's slice of the run
-	// with a returning LDS atomic (a wave's LDS atomics execute in issue order,
-	// so slices follow item order: stable); ds_bpermute hands the start to the
-	// group. 4a. scatter into the LDS stage in digit order. ----
-	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) {
-		const bool valid = full || (wbase + i * 64 < count);
-		const unsigned d = (unsigned) (key[i] >> shift) & mask;
-		const unsigned r = grp[i] & 0xffu, c = (grp[i] >> 8) & 0xffu, leader = grp[i] >> 16;
-		unsigned start = 0;
-		if (valid && r == 0) start = atomicAdd(&s_wcnt[wave][d], c);
-		start = (unsigned) __shfl((int) start, (int) leader, 64);
-		if (valid) s_stage[start + r] = key[i];
-	}
-	__syncthreads();
-
-	// ---- 4b. contiguous runs to HBM; 5. next digit's per-tile histogram ----
-	#pragma unroll
-	for (int j = 0; j < ITEMS; ++j) {
-		const unsigned p = j * R4_THREADS + tid;
-		if (full || p < count) {
-			const E e = s_stage[p];
-			const unsigned d = (unsigned) (e >> shift) & mask;
-			const unsigned gi = p + s_delta[d];
-			if ((size_t) gi < n) {
-				out[gi] = e;
-				if (has_next) {
-					const unsigned half = ((gi >> LOG_TILE) - s_first[d]) & 1u;
-					atomicAdd(&s_next[d][half][(unsigned) (e >> next_shift) & next_mask], 1u);
-				}
-			}
-		}
-	}
-	if (has_next) {
-		__syncthreads();
-		// 16 consecutive lanes = the 16 counters of one destination tile (64 B)
-		for (unsigned i = tid; i < R * 2 * R; i += R4_THREADS) {
-			const unsigned v = (&s_next[0][0][0])[i];
-			if (v) {
-				const unsigned d = i / (2 * R), half = (i / R) & 1u, dn = i % R;
-				atomicAdd(&thist_next[(size_t) (s_first[d] + half) * R + dn], v);
-			}
-		}
-	}
-}
-
-// ---------------------------------------------------------------------------
-// Packed-counter variant of the two kernels above (the default).
+// Ranking with thread-private packed counters.
 //
-// The match-any ranking costs ~40 VALU instructions per element (one ballot
-// and a 64-bit select/and per digit bit, per element); profiling showed the
-// pass kernel VALU-bound (SQ_INSTS_VALU = 85 per element). Here each thread
-// owns ITEMS = 8 CONSECUTIVE elements and counts digits in thread-private
-// packed counters (16 digits x 4 bits in two VGPRs), which also yield each
-// element's rank among the thread's own elements. One wave64 DPP scan of the
-// widened counters (16 digits x 16 bits in 8 VGPRs: 6 v_add_dpp each) plus a
-// cross-wave step through LDS gives, per thread, the exclusive count of every
-// digit among all earlier threads of the tile. Thread order = element order,
-// so the ranking is stable.
+// Ranking by wave-wide match-any costs ~40 VALU instructions per element (one
+// ballot and a 64-bit select/and per digit bit); a pass built on it measured
+// VALU-bound (SQ_INSTS_VALU = 85 per element). Here each thread owns ITEMS = 8
+// CONSECUTIVE elements and counts digits in thread-private packed counters
+// (16 digits x 4 bits in one 64-bit register), which also yield each element's
+// rank among the thread's own elements. One wave64 DPP scan of the widened
+// counters plus a cross-wave step through LDS gives, per thread, the count of
+// every digit among all earlier threads of the tile. Thread order = element
+// order, so the ranking is stable. (45 VALU per element and pass.)
 // ---------------------------------------------------------------------------
 
 template <int CTRL, int ROW_MASK>
@@ -388,7 +207,7 @@ __device__ __forceinline__ void load_blocked(const E* __restrict__ p, E (&key)[I
 template <typename E, int BITS, int LT>
 __global__ __launch_bounds__(R4_THREADS)
 void clo_radix4_tilehist_pc_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
-	unsigned* __restrict__ thist, int aligned) {
+	unsigned* __restrict__ thist, int aligned, clo_keyx kx) {
 	constexpr int R = 1 << BITS;
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int ITEMS = r4_shape<LT>::ITEMS;
@@ -404,11 +223,11 @@ void clo_radix4_tilehist_pc_kernel(const E* __restrict__ in, size_t n, unsigned 
 		E key[ITEMS];
 		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
 		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) packed4_count<BITS>(c, (unsigned) (key[i] >> shift) & mask);
+		for (int i = 0; i < ITEMS; ++i) packed4_count<BITS>(c, (unsigned) (clo_keyx_fwd<E>(key[i], kx) >> shift) & mask);
 	} else {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
-			if (tbase + i < count) packed4_count<BITS>(c, (unsigned) (in[base + tbase + i] >> shift) & mask);
+			if (tbase + i < count) packed4_count<BITS>(c, (unsigned) (clo_keyx_fwd<E>(in[base + tbase + i], kx) >> shift) & mask);
 	}
 	unsigned w[H];
 	packed4_widen<BITS>(c, w);
@@ -428,27 +247,18 @@ void clo_radix4_tilehist_pc_kernel(const E* __restrict__ in, size_t n, unsigned 
 
 // ---- pass kernel: two-stage packed scan ----
 // The thread-private 4-bit counters first widen to 8-bit fields only (4
-// digits per VGPR): an inclusive scan inside a row of 16 lanes cannot exceed
-// 16 * 15 = 240. Only then do they widen to 16-bit fields for the two
-// cross-row steps. Field order after the two widenings: 16-bit field `half`
-// of word j holds digit pc2_digit(j, half).
-template <int BITS> struct pc2 {
-	static constexpr int R = 1 << BITS;
-	static constexpr int NB = R == 16 ? 4 : 2;   // words of 8-bit fields
-	static constexpr int NW = 2 * NB;            // words of 16-bit fields
-};
-__host__ __device__ constexpr int pc2_digit(int j, int half) {
-	return ((j >> 2) & 1) * 8 + ((j >> 1) & 1) + (j & 1) * 2 + half * 4;
-}
-
-// Inclusive scan over the wave of every digit's thread-private count.
+// digits per VGPR: even digits in one word, odd digits in the next): an
+// inclusive scan inside a row of 16 lanes cannot exceed 16 * 15 = 240. Only
+// then do they widen to 16-bit fields for the two cross-row steps; v_perm_b32
+// builds w[j] = count(2j) | count(2j+1) << 16 from one even and one odd word.
 template <int BITS>
-__device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned (&w)[pc2<BITS>::NW]) {
-	constexpr int NB = pc2<BITS>::NB;
+__device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned (&w)[pc_words<BITS>::H]) {
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int NB = (1 << BITS) == 16 ? 4 : 2;   // words of 8-bit fields
 	unsigned b[NB];
 	const unsigned lo = (unsigned) c, hi = (unsigned) (c >> 32);
-	b[0] = lo & 0x0f0f0f0fu;
-	b[1] = (lo >> 4) & 0x0f0f0f0fu;
+	b[0] = lo & 0x0f0f0f0fu;          // digits 0,2,4,6
+	b[1] = (lo >> 4) & 0x0f0f0f0fu;   // digits 1,3,5,7
 	if constexpr (NB == 4) {
 		b[2] = hi & 0x0f0f0f0fu;
 		b[3] = (hi >> 4) & 0x0f0f0f0fu;
@@ -459,12 +269,15 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned (&w
 		x = dpp_add<0x111, 0xF>(x);
 		x = dpp_add<0x112, 0xF>(x);
 		x = dpp_add<0x114, 0xF>(x);
-		x = dpp_add<0x118, 0xF>(x);
-		unsigned e = x & 0x00ff00ffu, o = (x >> 8) & 0x00ff00ffu;
-		e = dpp_add<0x142, 0xA>(e);
-		o = dpp_add<0x142, 0xA>(o);
-		w[2 * k] = dpp_add<0x143, 0xC>(e);
-		w[2 * k + 1] = dpp_add<0x143, 0xC>(o);
+		b[k] = dpp_add<0x118, 0xF>(x);
+	}
+	#pragma unroll
+	for (int j = 0; j < H; ++j) {
+		// byte (j & 3) of the even word -> bits 0..15, of the odd word -> bits 16..31
+		const unsigned sel = 0x0c040c00u + (unsigned) (j & 3) * 0x00010001u;
+		unsigned x = __builtin_amdgcn_perm(b[(j >> 2) * 2 + 1], b[(j >> 2) * 2], sel);
+		x = dpp_add<0x142, 0xA>(x);
+		w[j] = dpp_add<0x143, 0xC>(x);
 	}
 }
 
@@ -473,10 +286,10 @@ __global__ __launch_bounds__(R4_THREADS)
 void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask, int has_next, unsigned next_shift, unsigned next_mask,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff,
-	unsigned* __restrict__ thist_next, int aligned, unsigned long long* dbg) {
+	unsigned* __restrict__ thist_next, int aligned, clo_keyx kx_in, clo_keyx kx_out, unsigned long long* dbg) {
 
 	constexpr int R = 1 << BITS;
-	constexpr int NW = pc2<BITS>::NW;
+	constexpr int NW = pc_words<BITS>::H;
 	constexpr int ITEMS = r4_shape<LT>::ITEMS;
 	constexpr int TILE = r4_shape<LT>::TILE;
 	constexpr int LOG_TILE = r4_shape<LT>::LOG_TILE;
@@ -487,9 +300,9 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	CLO_STAMP(0);
 
 	__shared__ E s_stage[TILE];
-	__shared__ unsigned short s_end[R][R4_THREADS];   // [digit][thread]: tile-local END of the thread's slice of the digit;
-	                                                  // a lane only touches its own column
-	__shared__ unsigned s_wtot[R4_WAVES][NW];         // wave totals (packed like pc2_wave_scan's result)
+	__shared__ unsigned s_end[NW][R4_THREADS];        // [digit / 2][thread]: tile-local END of the thread's slice of the two
+	                                                  // digits (16-bit fields); a lane only touches its own column: conflict-free
+	__shared__ unsigned s_wtot[R4_WAVES][NW];         // wave totals (packed like the counters)
 	__shared__ unsigned s_wbase[R4_WAVES][NW];        // digit start + totals of earlier waves
 	__shared__ unsigned s_next[R][2][R];              // [digit][destination tile 0/1][next digit]
 	__shared__ unsigned s_delta[R];                   // global index = tile-local position + delta[digit]
@@ -520,6 +333,10 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	} else {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
+	}
+	if (kx_in.kind) {   // first pass of a sort on signed / floating-point keys
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
 	}
 
 	if (dbg) { asm volatile("" :: "v"((unsigned) key[ITEMS - 1])); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -552,12 +369,8 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 			s_delta[tid] = goff - dstart;
 			s_comb[tid] = tid * 2u * R - ((goff >> LOG_TILE) << BITS);
 		}
-		// gather the starts into the packed field order (lanes >= R hold the tile count: unused digits)
-		const unsigned j = lane & (NW - 1);
-		const unsigned d0 = ((j >> 2) & 1u) * 8u + ((j >> 1) & 1u) + (j & 1u) * 2u;
-		const unsigned lo16 = (unsigned) __shfl((int) dstart, (int) d0, 64);
-		const unsigned hi16 = (unsigned) __shfl((int) dstart, (int) (d0 + 4u), 64);
-		if (tid < (unsigned) NW) s_dstart16[tid] = (d0 < (unsigned) R ? lo16 : 0u) | ((d0 + 4u < (unsigned) R ? hi16 : 0u) << 16);
+		const unsigned odd = (unsigned) __shfl((int) dstart, (int) (lane | 1u), 64);
+		if (tid < (unsigned) R && (tid & 1u) == 0) s_dstart16[tid >> 1] = dstart | ((R > 1 ? odd : 0u) << 16);
 	}
 	CLO_STAMP(2);
 	__syncthreads();
@@ -571,18 +384,15 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	__syncthreads();
 	CLO_STAMP(4);
 	#pragma unroll
-	for (int j = 0; j < NW; ++j) {
-		const unsigned x = w[j] + s_wbase[wave][j];
-		if (pc2_digit(j, 0) < R) s_end[pc2_digit(j, 0) < R ? pc2_digit(j, 0) : 0][tid] = (unsigned short) (x & 0xffffu);
-		if (pc2_digit(j, 1) < R) s_end[pc2_digit(j, 1) < R ? pc2_digit(j, 1) : 0][tid] = (unsigned short) (x >> 16);
-	}
+	for (int j = 0; j < NW; ++j) s_end[j][tid] = w[j] + s_wbase[wave][j];
 
 	// ---- 4a. scatter into the LDS stage in digit order ----
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		if (full || tbase + i < count) {
 			const unsigned d = (unsigned) (key[i] >> shift) & mask;
-			const unsigned pos = (unsigned) s_end[d][tid] - ((rr >> (4 * i)) & 15u);
+			const unsigned end = (s_end[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
+			const unsigned pos = end - ((rr >> (4 * i)) & 15u);
 			s_stage[pos & (TILE - 1)] = key[i];
 		}
 	}
@@ -597,7 +407,7 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	// indices: one 16-byte store (only element alignment is guaranteed, which
 	// global memory accepts); a group that straddles two runs is stored
 	// element by element.
-	constexpr int VEC = sizeof(E) >= 8 ? 2 : 4;
+	constexpr int VEC = sizeof(E) >= 8 ? 1 : 4;
 	typedef E vecE __attribute__((ext_vector_type(VEC)));
 	typedef E vecE_u __attribute__((ext_vector_type(VEC), aligned(sizeof(E))));
 	unsigned* const next_flat = &s_next[0][0][0];
@@ -614,7 +424,12 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 			const unsigned d0 = (unsigned) (v[0] >> shift) & mask, dl = (unsigned) (v[VEC - 1] >> shift) & mask;
 			const unsigned gi0 = p + s_delta[d0];
 			if (d0 == dl && gi0 <= n32 - VEC) {
-				*reinterpret_cast<vecE_u*>(&out[gi0]) = v;
+				vecE vo = v;
+				if (kx_out.kind) {   // last pass: back to the caller's encoding
+					#pragma unroll
+					for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(v[k], kx_out);
+				}
+				*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
 				if (has_next) {
 					if ((gi0 >> LOG_TILE) == ((gi0 + VEC - 1) >> LOG_TILE)) {
 						// one destination tile: one row of the table
@@ -632,7 +447,7 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 					const unsigned d = (unsigned) (v[k] >> shift) & mask;
 					const unsigned gi = p + k + s_delta[d];
 					if (gi < n32) {
-						out[gi] = v[k];
+						out[gi] = clo_keyx_inv<E>(v[k], kx_out);
 						if (has_next) count_next(v[k], d, gi);
 					}
 				}
@@ -645,7 +460,7 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 					const unsigned d = (unsigned) (e >> shift) & mask;
 					const unsigned gi = p + k + s_delta[d];
 					if (gi < n32) {
-						out[gi] = e;
+						out[gi] = clo_keyx_inv<E>(e, kx_out);
 						if (has_next) count_next(e, d, gi);
 					}
 				}
@@ -679,7 +494,7 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 template <typename E, int BITS, int LT>
 __global__ __launch_bounds__(R4_THREADS)
 void clo_radix4_small_kernel(const E* in, E* out, unsigned n,
-	unsigned key_shift, unsigned key_bits) {
+	unsigned key_shift, unsigned key_bits, clo_keyx kx) {
 	constexpr int R = 1 << BITS;
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int ITEMS = r4_shape<LT>::ITEMS;
@@ -694,7 +509,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n,
 	const unsigned tbase = tid * ITEMS;
 	E key[ITEMS];
 	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < n) ? in[tbase + i] : (E) 0;
+	for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < n) ? clo_keyx_fwd<E>(in[tbase + i], kx) : (E) 0;
 
 	for (unsigned done = 0; done < key_bits; done += BITS) {
 		const unsigned shift = key_shift + done;
@@ -749,7 +564,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n,
 		__syncthreads();
 	}
 	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) out[tbase + i] = key[i];
+	for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) out[tbase + i] = clo_keyx_inv<E>(key[i], kx);
 }
 
 // ---------------------------------------------------------------------------
@@ -757,8 +572,6 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n,
 // ---------------------------------------------------------------------------
 
 struct r4_layout { size_t thist, toff, partial, total, tiles, chunks; };
-
-int r4_log_tile(int elem_size) { return elem_size == 8 ? 12 : g_r4_log_tile4; }
 
 r4_layout r4_make_layout(size_t n, int elem_size, int passes, int digit_bits, int log_tile) {
 	r4_layout L;
@@ -776,7 +589,7 @@ r4_layout r4_make_layout(size_t n, int elem_size, int passes, int digit_bits, in
 }
 
 template <typename E, int BITS, int LT>
-int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, void* ws, hipStream_t s) {
+int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, clo_keyx kx, void* ws, hipStream_t s) {
 	constexpr unsigned R = 1u << BITS;
 	const int passes = (key_bits + BITS - 1) / BITS;
 	const r4_layout L = r4_make_layout(n, (int) sizeof(E), passes, BITS, LT);
@@ -786,12 +599,11 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles, chunks = (unsigned) L.chunks;
 
-	if (LT == 12 && n <= ((size_t) 1 << LT)) {
-		if constexpr (LT == 12) {
-			clo_timing_scope timing("radix_small", s);
-			hipLaunchKernelGGL((clo_radix4_small_kernel<E, BITS, LT>), dim3(1), dim3(R4_THREADS), 0, s,
-				src, dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits);
-		}
+	const clo_keyx kx_none = { 0, 0, 0 };
+	if (n <= ((size_t) 1 << LT)) {
+		clo_timing_scope timing("radix_small", s);
+		hipLaunchKernelGGL((clo_radix4_small_kernel<E, BITS, LT>), dim3(1), dim3(R4_THREADS), 0, s,
+			src, dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx);
 		return (int) hipGetLastError();
 	}
 
@@ -800,17 +612,10 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	if (e != hipSuccess) return (int) e;
 
 	const unsigned bits0 = key_bits < BITS ? key_bits : BITS;
-	const bool use_pc = !g_r4_match && LT == 12;
 	{
 		clo_timing_scope timing("radix_hist", s);
-		if (use_pc) {
-			if constexpr (LT == 12)
-				hipLaunchKernelGGL((clo_radix4_tilehist_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-					src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist, (int) ((uintptr_t) src % 16 == 0));
-		} else {
-			hipLaunchKernelGGL((clo_radix4_tilehist_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-				src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist);
-		}
+		hipLaunchKernelGGL((clo_radix4_tilehist_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+			src, n, (unsigned) key_shift, (1u << bits0) - 1u, thist, (int) ((uintptr_t) src % 16 == 0), kx);
 	}
 
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
@@ -835,19 +640,11 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		}
 		{
 			clo_timing_scope timing("radix_pass", s);
-			if (use_pc) {
-				if constexpr (LT == 12)
-					hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-						cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
-						has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
-						(const unsigned*) th, (const unsigned*) toff, th + per_pass,
-						(int) ((uintptr_t) cur_in % 16 == 0), g_r4_dbg);
-			} else {
-				hipLaunchKernelGGL((clo_radix4_pass_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-					cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
-					has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
-					(const unsigned*) th, (const unsigned*) toff, th + per_pass);
-			}
+			hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+				cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
+				has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
+				(const unsigned*) th, (const unsigned*) toff, th + per_pass,
+				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, has_next ? kx_none : kx, g_r4_dbg);
 		}
 		cur_in = cur_out;
 	}
@@ -894,8 +691,9 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	hipError_t e = hipMemsetAsync(ws, 0, L.toff, s);
 	if (e != hipSuccess) return (int) e;
 	clo_timing_scope timing("msd_partition", s);
+	const clo_keyx kx_none = { 0, 0, 0 };
 	hipLaunchKernelGGL((clo_radix4_tilehist_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
-		src, n, shift, R - 1u, thist, (int) ((uintptr_t) src % 16 == 0));
+		src, n, shift, R - 1u, thist, (int) ((uintptr_t) src % 16 == 0), kx_none);
 	if (counts)
 		hipLaunchKernelGGL((clo_radix4_counts_kernel<R>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);
 	if (chunks > 1)
@@ -905,18 +703,18 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 		(const unsigned*) thist, tiles, (const unsigned*) partial, chunks, toff);
 	hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
 		src, dst, n, shift, R - 1u, 0, 0u, 0u, (const unsigned*) thist, (const unsigned*) toff,
-		thist + (L.tiles + 1) * R, (int) ((uintptr_t) src % 16 == 0), (unsigned long long*) nullptr);
+		thist + (L.tiles + 1) * R, (int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, (unsigned long long*) nullptr);
 	return (int) hipGetLastError();
 }
 
 template <typename E, int LT>
 int r4_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits, int digit_bits,
-	void* ws, hipStream_t s) {
+	clo_keyx kx, void* ws, hipStream_t s) {
 	switch (digit_bits) {
-		case 1: return r4_sort_impl<E, 1, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
-		case 2: return r4_sort_impl<E, 2, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
-		case 3: return r4_sort_impl<E, 3, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
-		case 4: return r4_sort_impl<E, 4, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, ws, s);
+		case 1: return r4_sort_impl<E, 1, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s);
+		case 2: return r4_sort_impl<E, 2, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s);
+		case 3: return r4_sort_impl<E, 3, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s);
+		case 4: return r4_sort_impl<E, 4, LT>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }
@@ -948,28 +746,23 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 	return CLO_HIP_EUNSUPPORTED;
 }
 
-int clo_radix4_set_log_tile(int log_tile) {
-	if (log_tile != 12 && log_tile != 13) return CLO_HIP_EARGS;
-	g_r4_log_tile4 = log_tile;
-	return 0;
-}
-
 void clo_radix4_set_debug_buffer(void* p) { g_r4_dbg = (unsigned long long*) p; }
 
-int clo_radix4_set_match(int on) {
-	g_r4_match = on != 0;
-	return 0;
+// static LDS of the two kernels (introspection: clo_sort_get_localmem_usage)
+size_t clo_radix4_lds_bytes(const char* kernel, int elem_size, int digit_bits) {
+	const size_t R = (size_t) 1 << digit_bits, NW = R >= 2 ? R / 2 : 1;
+	if (kernel[0] == 'h') return R4_WAVES * (R >= 2 ? R / 2 : 1) * sizeof(unsigned);
+	return ((size_t) 4096 * elem_size) + NW * R4_THREADS * sizeof(unsigned)
+		+ (2 * R4_WAVES * NW + 2 * R * R + 2 * R + NW) * sizeof(unsigned);
 }
 
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
-	int key_bits, int digit_bits, void* ws, hipStream_t s) {
-	const bool small = r4_log_tile(elem_size) == 12;
+	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s) {
 	switch (elem_size) {
-		case 1: return r4_dispatch<uint8_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
-		case 2: return r4_dispatch<uint16_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
-		case 4: return small ? r4_dispatch<uint32_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s)
-			: r4_dispatch<uint32_t, 13>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
-		case 8: return r4_dispatch<uint64_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, ws, s);
+		case 1: return r4_dispatch<uint8_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 2: return r4_dispatch<uint16_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 4: return r4_dispatch<uint32_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 8: return r4_dispatch<uint64_t, 12>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }

@@ -84,15 +84,20 @@ int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
 /* ---- LSD radix sort (replaces the per-digit loop of
  *      sort/clo_sort_satradix.c:264-313: satradix_localsort, satradix_histogram,
  *      clo_scan_with_device_data, satradix_scatter — sort/clo_sort_satradix.cl:34-258) ----
- * Stable ascending sort of `numel` elements of elem_size bytes by the unsigned
- * key field  key = (elem >> key_shift) & ((1<<key_bits)-1), digits of
+ * Stable ascending sort of `numel` elements of elem_size bytes by the key
+ * field  key = (elem >> key_shift) & ((1<<key_bits)-1), digits of
  * `digit_bits` bits (1..8; radix = 1<<digit_bits), least significant first.
+ * key_kind: 0 = unsigned (raw bit order, what upstream's kernels do for every
+ * type), 1 = two's complement, 2 = IEEE-754 (key_bits 16/32/64; -0 < +0, NaNs
+ * at the ends by sign) — kinds 1 and 2 go through an order-preserving
+ * transform on the first read and back on the last write, so negative keys
+ * land where upstream's own check (benchmarks/clo_bench.c:26-65) wants them.
  * src is read, the sorted result is written to dst; tmp is scratch of the same
  * size. dst may equal src (in place); tmp must be distinct from both. src is
  * left untouched when dst != src. Asynchronous on `stream`. */
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits);
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
-	int elem_size, int key_shift, int key_bits, int digit_bits,
+	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits,
 	void* workspace, size_t workspace_bytes, void* stream);
 
 /* MSD bucket partition used by the multi-GPU exchange (new
@@ -165,8 +170,6 @@ int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms);
  * "scan", "bitonic_tile", "bitonic_strided", "bitonic_step". */
 size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param);
 
-/* Tuning knob (benchmark/tests only): radix tile variant, 0 = default. */
-int clo_hip_radix_set_variant(int variant);
 /* Developer diagnostics: device buffer of 8 uint64 per tile (first 32768 tiles)
  * that receives s_memtime stamps of the pass kernel's phases; NULL disables. */
 int clo_hip_radix_set_debug_buffer(void* dptr);

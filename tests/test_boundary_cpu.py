@@ -230,9 +230,19 @@ def test_compare_parsing(off):
     assert e.value.code == CLO_ERROR_ARGS
 
 
-def test_half_type_is_refused(off):
-    with pytest.raises(clo.CloError):
-        clo.Sorter("sbitonic", off, "half")
+def test_half_keys_are_ieee_keys_of_16_bits(off):
+    for impl in ("sbitonic", "abitonic", "satradix"):
+        s = clo.Sorter(impl, off, "half")
+        assert s.key_spec() == (2, 2, 0, 16, 2, 0)
+        s.close()
+
+
+def test_float_key_inside_a_wider_element(off):
+    s = clo.Sorter("satradix", off, "ulong", key_type="float", get_key="as_float((uint) ((x) >> 32))")
+    assert s.key_spec() == (8, 4, 32, 32, 2, 0)
+    s.close()
+    with pytest.raises(clo.CloError):   # half of a float is not an IEEE key
+        clo.Sorter("satradix", off, "ulong", key_type="float", get_key="as_float((uint) ((x) >> 48))")
 
 
 def test_workspace_sizes_are_sane():

@@ -133,20 +133,115 @@ def test_satradix_u64_keys(gpu, n):
     assert np.array_equal(got, np.sort(a))
 
 
+@pytest.mark.parametrize("radix", [16, 256])
 @pytest.mark.parametrize("et", ["uchar", "ushort", "char", "short", "int", "long"])
-def test_satradix_other_integer_types_raw_bit_order(gpu, et):
-    """Reference ignores COMPARE and sorts by raw key bits (SURVEY §8a-6 iii)."""
+def test_satradix_other_integer_types(gpu, et, radix):
+    """Unsigned: raw bit order. Signed: numeric order — upstream's kernels
+    ignore the type and leave negative keys after the positive ones, which its
+    own check rejects (SURVEY §8a-6 iii, §8f-1); non-negative inputs must give
+    what upstream's decomposition gives."""
     import cl_ops_amd as clo
     ctx, q = gpu
     dt = clo.api.CLO_TYPE_NP[et]
     rng = np.random.default_rng(5)
     info = np.iinfo(dt)
-    a = rng.integers(info.min, info.max, 20000, dtype=np.int64).astype(dt)
-    s = clo.Sorter("satradix", ctx, et)
+    a = rng.integers(info.min, info.max, 20000, dtype=np.int64, endpoint=True).astype(dt)
+    s = clo.Sorter("satradix", ctx, et, options="radix=%d" % radix)
+    got = s.with_host_data(a, q)
+    assert got.dtype == dt and np.array_equal(got, np.sort(a))
+    ut = np.dtype("u%d" % dt.itemsize)
+    nonneg = (a.view(ut) >> ut.type(1)).view(dt)[:4096].copy()    # top bit clear
+    got = s.with_host_data(nonneg, q)
+    s.close()
+    u = nonneg.view(ut)
+    assert np.array_equal(got.view(u.dtype), O.satradix(u, radix=radix, dev_max_lws=256))
+
+
+@pytest.mark.parametrize("radix", [2, 16, 64, 256])
+@pytest.mark.parametrize("et", ["half", "float", "double"])
+def test_satradix_floating_point_keys(gpu, et, radix):
+    """IEEE keys through the order-preserving transform: negatives, both
+    zeros, infinities; the result must be the same multiset of bit patterns."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(7)
+    n = 30011
+    a = (rng.standard_normal(n) * 1000).astype(dt)
+    a[:8] = np.array([0.0, -0.0, np.inf, -np.inf, 1.0, -1.0, np.finfo(dt).tiny, -np.finfo(dt).tiny], dtype=dt)
+    s = clo.Sorter("satradix", ctx, et, options="radix=%d" % radix)
     got = s.with_host_data(a, q)
     s.close()
-    u = a.view(np.dtype("u%d" % dt.itemsize))
-    assert np.array_equal(got.view(u.dtype), np.sort(u))
+    u = np.dtype("u%d" % dt.itemsize)
+    assert np.array_equal(np.sort(got.view(u)), np.sort(a.view(u)))          # permutation of the bit patterns
+    assert np.all(got[:-1] <= got[1:])                                      # numeric order
+    z = np.flatnonzero(got == 0)
+    assert np.all(np.signbit(got[z])[:-1] >= np.signbit(got[z])[1:])        # -0 before +0
+    # positive keys: identical to upstream's raw-bit decomposition
+    pos = np.abs(a[:4096])
+    s = clo.Sorter("satradix", ctx, et, options="radix=%d" % radix)
+    got = s.with_host_data(pos, q)
+    s.close()
+    assert np.array_equal(got.view(u), np.sort(pos.view(u)))
+    if (8 * dt.itemsize) % (radix.bit_length() - 1) == 0:   # (upstream drops the last partial digit otherwise)
+        assert np.array_equal(got.view(u), O.satradix(pos.view(u), radix=radix, dev_max_lws=256))
+
+
+def test_satradix_float_key_inside_a_wider_element(gpu):
+    """float key in the high word of a ulong element (get_key), value = index: stable."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 50000
+    rng = np.random.default_rng(9)
+    k = rng.integers(-50, 50, n).astype(np.float32)
+    e = (k.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter("satradix", ctx, "ulong", key_type="float", get_key="as_float((uint) ((x) >> 32))")
+    try:
+        got = s.with_host_data(e, q)
+    except clo.CloError:
+        s.close()
+        pytest.skip("get_key form not recognised by the key parser")
+    s.close()
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(got, e[order])
+
+
+@pytest.mark.parametrize("radix", [32, 64, 128, 256])
+@pytest.mark.parametrize("n", [1, 100, 4096, 8192, 8193, 70001, (1 << 20) + 3])
+def test_satradix_wide_digits_pairs_stable(gpu, n, radix):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    rng = np.random.default_rng(n + radix)
+    keys = rng.integers(0, 5000, n, dtype=np.uint64) * np.uint64(858993)   # spread over all 32 key bits
+    keys &= np.uint64(0xFFFFFFFF)
+    e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)", options="radix=%d" % radix)
+    got = s.with_host_data(e, q)
+    s.close()
+    assert np.array_equal(got, O.stable_sort(e, key_size=4, key_shift=32))
+
+
+@pytest.mark.parametrize("radix", [32, 256])
+@pytest.mark.parametrize("et", ["uchar", "ushort", "uint", "ulong"])
+def test_satradix_wide_digits_all_element_sizes_in_place(gpu, et, radix):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    n = 123457
+    a = np.random.default_rng(3).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    s = clo.Sorter("satradix", ctx, et, options="radix=%d" % radix)
+    b = clo.Buffer(ctx, a.nbytes)
+    b.write(q, a)
+    s.with_device_data(q, b, None, n)            # in place (odd pass counts copy back)
+    assert np.array_equal(b.read(q, dt, n), np.sort(a))
+    bo = clo.Buffer(ctx, a.nbytes)
+    b.write(q, a)
+    s.with_device_data(q, b, bo, n)              # out of place: input untouched
+    assert np.array_equal(bo.read(q, dt, n), np.sort(a))
+    assert np.array_equal(b.read(q, dt, n), a)
+    for x in (b, bo):
+        x.close()
+    s.close()
 
 
 def test_satradix_degenerate_inputs(gpu):
@@ -216,7 +311,7 @@ def test_bitonic_pairs_tie_order_matches_reference_network(gpu, alg):
 
 
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
-@pytest.mark.parametrize("et", ["int", "long", "float", "double", "ushort", "uchar"])
+@pytest.mark.parametrize("et", ["int", "long", "half", "float", "double", "ushort", "uchar"])
 def test_bitonic_typed_compare(gpu, alg, et):
     import cl_ops_amd as clo
     ctx, q = gpu
@@ -224,7 +319,7 @@ def test_bitonic_typed_compare(gpu, alg, et):
     rng = np.random.default_rng(9)
     n = 1 << 14
     if np.issubdtype(dt, np.floating):
-        a = ((rng.random(n) - 0.5) * 1e6).astype(dt)
+        a = ((rng.random(n) - 0.5) * (1e4 if et == "half" else 1e6)).astype(dt)
     else:
         info = np.iinfo(dt)
         a = rng.integers(info.min, info.max, n, dtype=np.int64).astype(dt)
@@ -232,6 +327,20 @@ def test_bitonic_typed_compare(gpu, alg, et):
     got = s.with_host_data(a, q)
     s.close()
     assert np.array_equal(got, np.sort(a))
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+def test_bitonic_float_key_inside_a_wider_element(gpu, alg):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 13
+    k = ((np.random.default_rng(4).random(n) - 0.5) * 1e3).astype(np.float32)
+    e = (k.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter(alg, ctx, "ulong", key_type="float", get_key="as_float((uint) ((x) >> 32))")
+    got = s.with_host_data(e, q)
+    s.close()
+    gk = (got >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    assert np.all(gk[:-1] <= gk[1:]) and np.array_equal(np.sort(got), np.sort(e))
 
 
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
