@@ -46,6 +46,8 @@ _sig("clo_hip_memcpy_h2d_async", ci, vp, vp, sz, vp)
 _sig("clo_hip_memcpy_d2h_async", ci, vp, vp, sz, vp)
 _sig("clo_hip_memcpy_d2d_async", ci, vp, vp, sz, vp)
 _sig("clo_hip_memset_async", ci, vp, ci, sz, vp)
+_sig("clo_hip_host_register", ci, vp, sz)
+_sig("clo_hip_host_unregister", ci, vp)
 _sig("clo_hip_event_create", ci, C.POINTER(vp))
 _sig("clo_hip_event_destroy", ci, vp)
 _sig("clo_hip_event_record", ci, vp, vp)
@@ -55,6 +57,8 @@ _sig("clo_hip_stream_wait_event", ci, vp, vp)
 _sig("clo_hip_error_string", C.c_char_p, ci)
 _sig("clo_hip_scan_workspace_bytes", sz, sz, ci, ci)
 _sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
+_sig("clo_hip_scan_exclusive_carry", ci, vp, vp, sz, ci, ci, ci, vp, vp, vp, sz, vp)
+_sig("clo_hip_reduce_sum", ci, vp, sz, ci, ci, vp, vp)
 _sig("clo_hip_radix_workspace_bytes", sz, sz, ci, ci, ci)
 _sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)

@@ -304,7 +304,14 @@ typedef int (*copy_fn)(void*, const void*, size_t, void*);
 
 static CCLEvent* enqueue_copy(CCLQueue* cq, const char* name, copy_fn fn, void* dst, const void* src,
 	size_t size, cl_bool blocking, CCLEventWaitList* ewl, GError** err) {
-	if (!ccl_queue_wait_for(cq, ewl, err)) return NULL;
+	if (fn != clo_hip_memcpy_d2d_async && ewl && *ewl) {
+		/* A copy from/to (pageable) host memory holds the calling thread until it
+		 * is done, so nothing is lost by waiting for its dependencies here — and a
+		 * wait pending in the copy's stream pushes the runtime onto a slower copy
+		 * path (measured: reading back 256 MiB took 12.9 ms instead of 4.6 ms). */
+		for (size_t i = 0; i < (*ewl)->n; ++i)
+			if (hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) return NULL;
+	} else if (!ccl_queue_wait_for(cq, ewl, err)) return NULL;
 	if (ewl) ccl_event_wait_list_clear(ewl);
 	CCLEvent* e = ccl_queue_begin_command(cq, name, err);
 	if (!e) return NULL;

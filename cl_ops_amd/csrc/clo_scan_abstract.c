@@ -9,6 +9,8 @@
 #include "clo_scan.h"
 #include "clo_internal.h"
 
+#include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 
 struct clo_scan {
@@ -18,7 +20,22 @@ struct clo_scan {
 	CloType elem_type;
 	CloType sum_type;
 	void* data;
+	struct scan_pipe_res* pipe;   /* streams / buffers of the pipelined host-data path, created on first use */
 };
+
+/* Device-side resources of the pipelined clo_scan_with_host_data: creating a
+ * stream costs milliseconds, so they are made once per scanner. */
+typedef struct scan_pipe_res {
+	void* s_in_own;              /* copies in, when the caller gave one queue for both */
+	void* s_out;                 /* copies out */
+	void* in_dev[2];
+	void* out_dev[2];
+	void* carry;                 /* two device uint64: carry of even / odd chunks */
+	void* in_done[2];
+	void* scan_done[2];
+} scan_pipe_res;
+
+static void scan_pipe_res_free(scan_pipe_res* r);
 
 CloScan* clo_scan_new(const char* type, const char* options, CCLContext* ctx,
 	CloType elem_type, CloType sum_type, const char* compiler_opts, GError** err) {
@@ -84,6 +101,7 @@ error_handler:
 void clo_scan_destroy(CloScan* scan) {
 	clo_return_if_fail(scan != NULL);
 	scan->impl_def.finalize(scan);
+	scan_pipe_res_free(scan->pipe);
 	if (scan->ctx) ccl_context_unref(scan->ctx);
 	if (scan->prg) ccl_program_destroy(scan->prg);
 	free(scan);
@@ -95,6 +113,167 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
 	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
 	clo_return_val_if_fail(cq_exec != NULL, NULL);
 	return scanner->impl_def.scan_with_device_data(scanner, cq_exec, cq_comm, data_in, data_out, numel, lws_max, err);
+}
+
+/* ------------------------------------------------------------------ */
+/* Pipelined host-data scan. Upstream copies the whole
+ * array in, scans, copies the whole array out (clo_scan_abstract.c:290-339):
+ * the two PCIe directions never overlap. Here the array goes through in
+ * chunks: while chunk k is scanned (a device-resident carry links the
+ * chunks), chunk k+1 is on its way in and chunk k-1 on its way out. A copy
+ * from/to pageable host memory blocks the calling thread for its duration
+ * (measured: hipMemcpyAsync of 512 MiB returns after 9.5 ms), so the copies
+ * out are issued by a helper thread; pinning the caller's memory instead
+ * costs ~10 ms per GiB, more than the overlap gains.                     */
+/* ------------------------------------------------------------------ */
+#define CLO_SCAN_PIPE_CHUNK ((size_t) 1 << 22)   /* elements per chunk */
+#define CLO_SCAN_PIPE_MIN_CHUNKS 4               /* below this the fill/drain of the pipeline eats the gain */
+
+static void scan_pipe_res_free(scan_pipe_res* r) {
+	if (!r) return;
+	if (r->s_in_own) { clo_hip_stream_synchronize(r->s_in_own); clo_hip_stream_destroy(r->s_in_own); }
+	if (r->s_out) { clo_hip_stream_synchronize(r->s_out); clo_hip_stream_destroy(r->s_out); }
+	for (int i = 0; i < 2; ++i) {
+		clo_hip_free(r->in_dev[i]);
+		clo_hip_free(r->out_dev[i]);
+		clo_hip_event_destroy(r->in_done[i]);
+		clo_hip_event_destroy(r->scan_done[i]);
+	}
+	clo_hip_free(r->carry);
+	free(r);
+}
+
+static scan_pipe_res* scan_pipe_res_get(CloScan* scanner, size_t es, size_t ss, int* status) {
+	if (scanner->pipe) return scanner->pipe;
+	scan_pipe_res* r = (scan_pipe_res*) calloc(1, sizeof(*r));
+	int st = r ? 0 : CLO_HIP_EARGS;
+	for (int i = 0; i < 2 && st == 0; ++i) {
+		st = clo_hip_malloc(&r->in_dev[i], CLO_SCAN_PIPE_CHUNK * es);
+		if (st == 0) st = clo_hip_malloc(&r->out_dev[i], CLO_SCAN_PIPE_CHUNK * ss);
+		if (st == 0) st = clo_hip_event_create(&r->in_done[i]);
+		if (st == 0) st = clo_hip_event_create(&r->scan_done[i]);
+	}
+	if (st == 0) st = clo_hip_malloc(&r->carry, 2 * sizeof(uint64_t));
+	if (st == 0) st = clo_hip_stream_create(&r->s_out);
+	if (st == 0) st = clo_hip_stream_create(&r->s_in_own);
+	if (st != 0) { scan_pipe_res_free(r); *status = st; return NULL; }
+	scanner->pipe = r;
+	return r;
+}
+
+typedef struct {
+	int device;
+	scan_pipe_res* r;
+	char* out_host;
+	size_t sum_size, chunk, numel;
+	pthread_mutex_t mtx;
+	pthread_cond_t cv;
+	size_t posted, completed;    /* chunks handed to / finished by the helper */
+	int abort, status;
+} scan_pipe;
+
+static void* scan_pipe_copy_out(void* arg) {
+	scan_pipe* p = (scan_pipe*) arg;
+	clo_hip_set_device(p->device);
+	for (size_t k = 0; ; ++k) {
+		pthread_mutex_lock(&p->mtx);
+		while (p->posted <= k && !p->abort) pthread_cond_wait(&p->cv, &p->mtx);
+		const int stop = p->posted <= k;   /* aborted, or nothing more will come */
+		pthread_mutex_unlock(&p->mtx);
+		if (stop) break;
+		const size_t off = k * p->chunk;
+		const size_t cnt = p->numel - off < p->chunk ? p->numel - off : p->chunk;
+		int st = clo_hip_event_synchronize(p->r->scan_done[k & 1]);
+		if (st == 0) st = clo_hip_memcpy_d2h_async(p->out_host + off * p->sum_size, p->r->out_dev[k & 1], cnt * p->sum_size, p->r->s_out);
+		if (st == 0) st = clo_hip_stream_synchronize(p->r->s_out);
+		pthread_mutex_lock(&p->mtx);
+		if (st != 0 && p->status == 0) p->status = st;
+		p->completed = k + 1;
+		pthread_cond_broadcast(&p->cv);
+		pthread_mutex_unlock(&p->mtx);
+		if (off + cnt >= p->numel) break;
+	}
+	return NULL;
+}
+
+static cl_bool scan_with_host_data_pipelined(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* cq_comm,
+	const void* data_in, void* data_out, size_t numel, GError** err) {
+
+	const size_t es = clo_type_sizeof(scanner->elem_type), ss = clo_type_sizeof(scanner->sum_type);
+	const size_t chunk = CLO_SCAN_PIPE_CHUNK;
+	const size_t nchunks = (numel + chunk - 1) / chunk;
+	void* s_in = ccl_queue_get_stream(cq_comm);
+	void* s_exec = ccl_queue_get_stream(cq_exec);
+	scan_pipe p;
+	pthread_t helper;
+	int helper_started = 0, st = 0;
+	cl_bool ok = CL_FALSE;
+	const char* what = "pipeline resources (hipMalloc / hipStreamCreate)";
+
+	memset(&p, 0, sizeof(p));
+	pthread_mutex_init(&p.mtx, NULL);
+	pthread_cond_init(&p.cv, NULL);
+	p.sum_size = ss; p.chunk = chunk; p.numel = numel; p.out_host = (char*) data_out;
+	if (clo_hip_get_device(&p.device) != 0) p.device = 0;
+	scan_pipe_res* r = scan_pipe_res_get(scanner, es, ss, &st);
+	if (!r) goto finish;
+	p.r = r;
+	if (s_in == s_exec) s_in = r->s_in_own;
+	what = "hipMemsetAsync";
+	st = clo_hip_memset_async(r->carry, 0, 2 * sizeof(uint64_t), s_exec);
+	if (st != 0) goto finish;
+	if (pthread_create(&helper, NULL, scan_pipe_copy_out, &p) != 0) { st = CLO_HIP_EARGS; what = "pthread_create"; goto finish; }
+	helper_started = 1;
+
+	for (size_t k = 0; k < nchunks; ++k) {
+		const int slot = (int) (k & 1);
+		const size_t off = k * chunk;
+		const size_t cnt = numel - off < chunk ? numel - off : chunk;
+		if (k >= 2) {   /* the slot's buffers are free once chunk k-2 is back on the host */
+			pthread_mutex_lock(&p.mtx);
+			while (p.completed < k - 1 && p.status == 0) pthread_cond_wait(&p.cv, &p.mtx);
+			st = p.status;
+			pthread_mutex_unlock(&p.mtx);
+			if (st != 0) { what = "copy out"; goto finish; }
+		}
+		what = "hipMemcpyAsync(h2d)";
+		st = clo_hip_memcpy_h2d_async(r->in_dev[slot], (const char*) data_in + off * es, cnt * es, s_in);
+		if (st == 0) st = clo_hip_event_record(r->in_done[slot], s_in);
+		if (st == 0) st = clo_hip_stream_wait_event(s_exec, r->in_done[slot]);
+		if (st != 0) goto finish;
+		if (!scanner->impl_def.scan_chunk(scanner, s_exec, r->in_dev[slot], r->out_dev[slot], cnt,
+			(char*) r->carry + slot * sizeof(uint64_t), (char*) r->carry + (slot ^ 1) * sizeof(uint64_t), err)) goto finish;
+		what = "hipEventRecord";
+		st = clo_hip_event_record(r->scan_done[slot], s_exec);
+		if (st != 0) goto finish;
+		pthread_mutex_lock(&p.mtx);
+		p.posted = k + 1;
+		pthread_cond_broadcast(&p.cv);
+		pthread_mutex_unlock(&p.mtx);
+	}
+	pthread_mutex_lock(&p.mtx);
+	while (p.completed < nchunks && p.status == 0) pthread_cond_wait(&p.cv, &p.mtx);
+	st = p.status;
+	pthread_mutex_unlock(&p.mtx);
+	what = "copy out";
+	ok = st == 0;
+
+finish:
+	if (helper_started) {
+		pthread_mutex_lock(&p.mtx);
+		p.abort = 1;
+		pthread_cond_broadcast(&p.cv);
+		pthread_mutex_unlock(&p.mtx);
+		pthread_join(helper, NULL);
+	}
+	if (st != 0 && (err == NULL || *err == NULL)) clo_hip_failed(st, err, what);
+	if (!ok) {   /* leave nothing of this call in flight */
+		if (s_in) clo_hip_stream_synchronize(s_in);
+		clo_hip_stream_synchronize(s_exec);
+	}
+	pthread_mutex_destroy(&p.mtx);
+	pthread_cond_destroy(&p.cv);
+	return ok && (err == NULL || *err == NULL);
 }
 
 /* ref: clo_scan_abstract.c:255-362 */
@@ -122,6 +301,13 @@ cl_bool clo_scan_with_host_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* c
 		cq_exec = intern_queue;
 	}
 	if (cq_comm == NULL) cq_comm = cq_exec;
+
+	if (scanner->impl_def.scan_chunk != NULL && numel >= CLO_SCAN_PIPE_MIN_CHUNKS * CLO_SCAN_PIPE_CHUNK && ccl_queue_get_stream(cq_exec) != NULL
+		&& getenv("CLO_SCAN_NO_PIPELINE") == NULL) {   /* (the variable: A/B measurements only) */
+		status = scan_with_host_data_pipelined(scanner, cq_exec, cq_comm, data_in, data_out, numel, &err_internal);
+		if (err_internal) goto error_handler;
+		goto finish;
+	}
 
 	data_in_dev = ccl_buffer_new(scanner->ctx, CL_MEM_READ_ONLY, data_in_size, NULL, &err_internal);
 	if (err_internal) goto error_handler;

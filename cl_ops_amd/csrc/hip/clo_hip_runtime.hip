@@ -125,6 +125,12 @@ int clo_hip_memset_async(void* dst, int value, size_t bytes, void* stream) {
 	return (int) hipMemsetAsync(dst, value, bytes, (hipStream_t) stream);
 }
 
+int clo_hip_host_register(void* host_ptr, size_t bytes) {
+	if (!host_ptr || bytes == 0) return CLO_HIP_EARGS;
+	return (int) hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);
+}
+int clo_hip_host_unregister(void* host_ptr) { return host_ptr ? (int) hipHostUnregister(host_ptr) : 0; }
+
 int clo_hip_event_create(void** event) {
 	if (!event) return CLO_HIP_EARGS;
 	hipEvent_t ev;

@@ -152,7 +152,8 @@ __device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsi
 template <typename TIn, typename TOut, typename TSum, int ROWS>
 __global__ __launch_bounds__(SCAN_THREADS)
 void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n,
-	unsigned* hdr, clo_u64* state, clo_u64* sstate, clo_u64* sagg, clo_u64* sacc, int aligned, unsigned xflags) {
+	unsigned* hdr, clo_u64* state, clo_u64* sstate, clo_u64* sagg, clo_u64* sacc, int aligned, unsigned xflags,
+	const clo_u64* __restrict__ carry_in, clo_u64* __restrict__ carry_out, unsigned last_tile) {
 
 	constexpr int ROW_ELEMS = SCAN_THREADS * SCAN_VEC;
 	constexpr int TILE = ROW_ELEMS * ROWS;
@@ -165,6 +166,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
 	if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
+	// value carried into this call (a chunk of a longer array): added to every output
+	const TSum carry = carry_in ? (TSum) *carry_in : (TSum) 0;
 	__syncthreads();
 	const unsigned tile = s_tile;
 	const size_t base = (size_t) tile * TILE;
@@ -251,10 +254,13 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		} else if (tile == 0 && lane == 0 && (1u << SCAN_SUPER_LOG) == 1u) {
 			scan_publish<TSum, NG>(sstate, 0, CLO_LB_PREFIX, aggregate);
 		}
-		if (lane == 0) s_excl = excl;
+		if (lane == 0) {
+			s_excl = excl;
+			if (carry_out && tile == last_tile) *carry_out = (clo_u64) (TSum) (carry + excl + aggregate);
+		}
 	}
 	__syncthreads();
-	const TSum tile_excl = s_excl;
+	const TSum tile_excl = s_excl + carry;
 
 	// ---- store: exclusive value of element c = offset + inclusive(c-1) ----
 	if (full) {
@@ -284,7 +290,7 @@ constexpr size_t scan_tile_elems(int sum_size) {
 }
 
 template <typename TIn, typename TOut>
-int launch_scan(const void* in, void* out, size_t n, void* ws, hipStream_t s) {
+int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, clo_u64* carry_out, void* ws, hipStream_t s) {
 	if constexpr (sizeof(TIn) > sizeof(TOut)) {
 		return CLO_HIP_EUNSUPPORTED;
 	} else {
@@ -303,20 +309,58 @@ int launch_scan(const void* in, void* out, size_t n, void* ws, hipStream_t s) {
 		if (e != hipSuccess) return (int) e;
 		clo_timing_scope timing("scan", s);
 		hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS>), dim3((unsigned) tiles), dim3(SCAN_THREADS), 0, s,
-			(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags);
+			(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
+			carry_in, carry_out, (unsigned) (tiles - 1));
 		return (int) hipGetLastError();
 	}
 }
 
 template <typename TOut>
-int dispatch_in(const void* in, void* out, size_t n, int es, int sgn, void* ws, hipStream_t s) {
+int dispatch_in(const void* in, void* out, size_t n, int es, int sgn, const clo_u64* ci, clo_u64* co, void* ws, hipStream_t s) {
 	switch (es) {
-		case 1: return sgn ? launch_scan<int8_t, TOut>(in, out, n, ws, s) : launch_scan<uint8_t, TOut>(in, out, n, ws, s);
-		case 2: return sgn ? launch_scan<int16_t, TOut>(in, out, n, ws, s) : launch_scan<uint16_t, TOut>(in, out, n, ws, s);
-		case 4: return sgn ? launch_scan<int32_t, TOut>(in, out, n, ws, s) : launch_scan<uint32_t, TOut>(in, out, n, ws, s);
-		case 8: return launch_scan<uint64_t, TOut>(in, out, n, ws, s);
+		case 1: return sgn ? launch_scan<int8_t, TOut>(in, out, n, ci, co, ws, s) : launch_scan<uint8_t, TOut>(in, out, n, ci, co, ws, s);
+		case 2: return sgn ? launch_scan<int16_t, TOut>(in, out, n, ci, co, ws, s) : launch_scan<uint16_t, TOut>(in, out, n, ci, co, ws, s);
+		case 4: return sgn ? launch_scan<int32_t, TOut>(in, out, n, ci, co, ws, s) : launch_scan<uint32_t, TOut>(in, out, n, ci, co, ws, s);
+		case 8: return launch_scan<uint64_t, TOut>(in, out, n, ci, co, ws, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
+}
+
+// Sum of all elements mod 2^64 (sign-extended when TIn is signed): the total a
+// sharded scan hands to the later shards.
+template <typename TIn>
+__global__ __launch_bounds__(256)
+void clo_reduce_kernel(const TIn* __restrict__ in, size_t n, unsigned long long* __restrict__ total, int aligned) {
+	__shared__ unsigned long long s_w[4];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	unsigned long long acc = 0;
+	const size_t chunk = 256u * 4u;
+	for (size_t base = (size_t) blockIdx.x * chunk; base < n; base += (size_t) gridDim.x * chunk) {
+		const size_t i = base + (size_t) tid * 4;
+		if (aligned && i + 4 <= n) {
+			TIn t[4];
+			load4<TIn>(in + i, t);
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) acc += (unsigned long long) (long long) t[c];
+		} else {
+			#pragma unroll
+			for (int c = 0; c < 4; ++c) if (i + c < n) acc += (unsigned long long) (long long) in[i + c];
+		}
+	}
+	const unsigned long long w = clo_wave_reduce_sum<unsigned long long>(acc);
+	if (lane == 0) s_w[wave] = w;
+	__syncthreads();
+	if (tid == 0) atomicAdd(total, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+}
+
+template <typename TIn>
+int launch_reduce(const void* in, size_t n, uint64_t* total, hipStream_t s) {
+	size_t blocks = (n + 1023) / 1024;
+	if (blocks > 4096) blocks = 4096;
+	clo_timing_scope timing("reduce", s);
+	hipLaunchKernelGGL((clo_reduce_kernel<TIn>), dim3((unsigned) blocks), dim3(256), 0, s,
+		(const TIn*) in, n, (unsigned long long*) total, (int) ((uintptr_t) in % (4 * sizeof(TIn)) == 0));
+	return (int) hipGetLastError();
 }
 
 }  // namespace
@@ -331,11 +375,17 @@ size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
 	return CLO_WS_HEADER_BYTES + t * 16 + ((t >> SCAN_SUPER_LOG) + 1) * 48;
 }
 
-int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
+int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t numel,
 	int elem_size, int elem_signed, int sum_size,
+	const uint64_t* carry_in_dev, uint64_t* carry_out_dev,
 	void* workspace, size_t workspace_bytes, void* stream) {
 
-	if (numel == 0) return 0;
+	hipStream_t s = (hipStream_t) stream;
+	if (numel == 0) {   // nothing to scan: the carry passes through
+		if (!carry_out_dev) return 0;
+		if (carry_in_dev) return (int) hipMemcpyAsync(carry_out_dev, carry_in_dev, sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+		return (int) hipMemsetAsync(carry_out_dev, 0, sizeof(uint64_t), s);
+	}
 	if (!data_in || !data_out || !workspace) return CLO_HIP_EARGS;
 	if (sum_size < elem_size) return CLO_HIP_EUNSUPPORTED;
 	{
@@ -344,14 +394,39 @@ int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
 	}
 	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
 	if (numel / scan_tile_elems(sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
-	hipStream_t s = (hipStream_t) stream;
+	const clo_u64* ci = (const clo_u64*) carry_in_dev;
+	clo_u64* co = (clo_u64*) carry_out_dev;
 	// The sum type only matters by width: two's complement addition is the
 	// same for signed and unsigned sums.
 	switch (sum_size) {
-		case 1: return dispatch_in<uint8_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
-		case 2: return dispatch_in<uint16_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
-		case 4: return dispatch_in<uint32_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
-		case 8: return dispatch_in<uint64_t>(data_in, data_out, numel, elem_size, elem_signed, workspace, s);
+		case 1: return dispatch_in<uint8_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
+		case 2: return dispatch_in<uint16_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
+		case 4: return dispatch_in<uint32_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
+		case 8: return dispatch_in<uint64_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
+	int elem_size, int elem_signed, int sum_size,
+	void* workspace, size_t workspace_bytes, void* stream) {
+	return clo_hip_scan_exclusive_carry(data_in, data_out, numel, elem_size, elem_signed, sum_size,
+		nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int clo_hip_reduce_sum(const void* data_in, size_t numel, int elem_size, int elem_signed,
+	uint64_t* total_dev, void* stream) {
+	if (!total_dev) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	hipError_t e = hipMemsetAsync(total_dev, 0, sizeof(uint64_t), s);
+	if (e != hipSuccess) return (int) e;
+	if (numel == 0) return 0;
+	if (!data_in) return CLO_HIP_EARGS;
+	switch (elem_size) {
+		case 1: return elem_signed ? launch_reduce<int8_t>(data_in, numel, total_dev, s) : launch_reduce<uint8_t>(data_in, numel, total_dev, s);
+		case 2: return elem_signed ? launch_reduce<int16_t>(data_in, numel, total_dev, s) : launch_reduce<uint16_t>(data_in, numel, total_dev, s);
+		case 4: return elem_signed ? launch_reduce<int32_t>(data_in, numel, total_dev, s) : launch_reduce<uint32_t>(data_in, numel, total_dev, s);
+		case 8: return launch_reduce<uint64_t>(data_in, numel, total_dev, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }

@@ -56,6 +56,11 @@ int clo_hip_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* str
 int clo_hip_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream);
 int clo_hip_memcpy_d2d_async(void* dst, const void* src, size_t bytes, void* stream);
 int clo_hip_memset_async(void* dst, int value, size_t bytes, void* stream);
+/* Pin / unpin a caller's host range so that copies to and from it are true
+ * asynchronous DMA (the *_with_host_data pipelines, sort/clo_sort_abstract.c:348-395,
+ * scan/clo_scan_abstract.c:290-339). Failure is not fatal: pageable copies still work. */
+int clo_hip_host_register(void* host_ptr, size_t bytes);
+int clo_hip_host_unregister(void* host_ptr);
 
 int clo_hip_event_create(void** event);
 int clo_hip_event_destroy(void* event);
@@ -80,6 +85,19 @@ size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size);
 int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
 	int elem_size, int elem_signed, int sum_size,
 	void* workspace, size_t workspace_bytes, void* stream);
+/* The same scan as one chunk of a longer array (new: the chunked host-data
+ * pipeline of clo_scan_with_host_data and the sharded multi-GPU scan):
+ * *carry_in_dev (device uint64, low sum_size bytes used; NULL = 0) is added to
+ * every output, *carry_out_dev (NULL = not wanted) receives carry_in + the sum
+ * of the chunk, i.e. the next chunk's carry_in. */
+int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t numel,
+	int elem_size, int elem_signed, int sum_size,
+	const uint64_t* carry_in_dev, uint64_t* carry_out_dev,
+	void* workspace, size_t workspace_bytes, void* stream);
+/* Sum of the elements mod 2^64 into *total_dev (device): what a shard hands
+ * to the later shards of a multi-GPU scan. */
+int clo_hip_reduce_sum(const void* data_in, size_t numel, int elem_size, int elem_signed,
+	uint64_t* total_dev, void* stream);
 
 /* ---- LSD radix sort (replaces the per-digit loop of
  *      sort/clo_sort_satradix.c:264-313: satradix_localsort, satradix_histogram,

@@ -43,6 +43,67 @@ def test_scan_matches_serial_scan(gpu, n, types):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("types", [("uint", "uint"), ("uint", "ulong"), ("int", "long"), ("uchar", "ushort")])
+def test_scan_in_chunks_with_device_carry_and_reduce(gpu, types):
+    """clo_hip_scan_exclusive_carry over uneven chunks == one scan of the whole
+    array; clo_hip_reduce_sum == the carry out of the last chunk."""
+    import cl_ops_amd as clo
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    ctx, q = gpu
+    et, st = types
+    edt, sdt = clo.api.CLO_TYPE_NP[et], clo.api.CLO_TYPE_NP[st]
+    rng = np.random.default_rng(42)
+    n = 300000
+    info = np.iinfo(edt)
+    a = rng.integers(max(info.min, -100000), min(info.max, 100000), n, endpoint=True).astype(edt)
+    signed = int(np.issubdtype(edt, np.signedinteger))
+    src, dst = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, n * sdt.itemsize)
+    carry, total = clo.Buffer(ctx, 16), clo.Buffer(ctx, 8)
+    src.write(q, a)
+    carry.write(q, np.zeros(2, np.uint64))
+    cuts = [0, 1, 5000, 5000, 70001, 262144, n]     # includes an empty chunk
+    wsb = lib.clo_hip_scan_workspace_bytes(n, edt.itemsize, sdt.itemsize)
+    ws = clo.Buffer(ctx, wsb)
+    for k in range(len(cuts) - 1):
+        lo, hi = cuts[k], cuts[k + 1]
+        _hip.check(lib.clo_hip_scan_exclusive_carry(src.ptr + lo * edt.itemsize, dst.ptr + lo * sdt.itemsize, hi - lo,
+                                                    edt.itemsize, signed, sdt.itemsize, carry.ptr + 8 * (k & 1),
+                                                    carry.ptr + 8 * ((k + 1) & 1), ws.ptr, wsb, q.stream),
+                   "clo_hip_scan_exclusive_carry")
+    _hip.check(lib.clo_hip_reduce_sum(src.ptr, n, edt.itemsize, signed, total.ptr, q.stream), "clo_hip_reduce_sum")
+    got = dst.read(q, sdt, n)
+    wide = a.astype(np.int64) if signed else a.astype(np.uint64)
+    exp = np.concatenate((np.zeros(1, wide.dtype), np.cumsum(wide[:-1], dtype=wide.dtype))).astype(sdt)
+    assert np.array_equal(got, exp)
+    mask = np.uint64((1 << (8 * sdt.itemsize)) - 1)
+    full = np.uint64(int(wide.sum(dtype=wide.dtype)) & 0xFFFFFFFFFFFFFFFF)
+    assert total.read(q, np.uint64, 1)[0] == full
+    assert carry.read(q, np.uint64, 2)[(len(cuts) - 1) & 1] & mask == full & mask
+    for b in (src, dst, carry, total, ws):
+        b.close()
+
+
+@pytest.mark.parametrize("types", [("uint", "uint"), ("uint", "ulong")])
+@pytest.mark.parametrize("n", [1 << 24, (1 << 24) + (1 << 23) + 12345])
+def test_scan_host_data_pipelined_chunks(gpu, n, types):
+    """numel >= 2 chunks: clo_scan_with_host_data goes through the chunked
+    copy-in / scan / copy-out pipeline (helper thread for the copies out)."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, st = types
+    sdt = clo.api.CLO_TYPE_NP[st]
+    a = np.random.default_rng(n).integers(0, 128, n, dtype=np.uint32)
+    sc = clo.Scanner("blelloch", ctx, et, st)
+    for queues in ((q, None), (q, clo.Queue(ctx))):
+        got = sc.with_host_data(a, queues[0], queues[1])
+        exp = np.concatenate((np.zeros(1, np.uint64), np.cumsum(a[:-1], dtype=np.uint64))).astype(sdt)
+        assert np.array_equal(got, exp)
+        if queues[1] is not None:
+            queues[1].close()
+    sc.close()
+
+
 def test_scan_wraps_in_sum_type(gpu):
     import cl_ops_amd as clo
     ctx, q = gpu
