@@ -165,3 +165,85 @@ class ShardedSorter:
         if total > 0:
             self.ops.sort_inplace(recv, total)                            # step 4
         return recv, total
+
+
+# ---------------------------------------------------------------------------
+# Sharded exclusive scan (new functionality): rank r holds the
+# r-th contiguous piece of the array. Per scan:
+#   1. local sum of the piece                      (HIP reduce, one read)
+#   2. all-gather of the G sums                     (8 B per rank)
+#   3. local scan with carry-in = sum of the earlier ranks' sums
+#                                                   (HIP scan, one read + one write)
+# Three element streams per rank instead of four for scan-then-add. The only
+# exchange is the 8-byte all-gather; ranks never wait for each other's scan.
+# ---------------------------------------------------------------------------
+
+_SCAN_NP = {"char": (1, 1), "uchar": (1, 0), "short": (2, 1), "ushort": (2, 0), "int": (4, 1), "uint": (4, 0),
+            "long": (8, 1), "ulong": (8, 0)}
+
+
+class HipScanOps:
+    """Device-side steps of the sharded scan on torch CUDA tensors through the C-ABI."""
+
+    def __init__(self, elem_type, sum_type, device_index):
+        import torch
+        from cl_ops_amd import _hip
+        self.torch, self._hip, self.lib = torch, _hip, _hip.lib
+        self.elem_size, self.elem_signed = _SCAN_NP[elem_type]
+        self.sum_size = _SCAN_NP[sum_type][0]
+        _hip.check(self.lib.clo_hip_set_device(device_index), "hipSetDevice")
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self._ws = None
+
+    def reduce(self, t, n):
+        """Sum of t[:n] mod 2^64 as a 1-element int64 tensor on the device."""
+        total = self.torch.empty(1, dtype=self.torch.int64, device=t.device)
+        self._hip.check(self.lib.clo_hip_reduce_sum(t.data_ptr(), n, self.elem_size, self.elem_signed,
+                                                    total.data_ptr(), self.stream), "clo_hip_reduce_sum")
+        return total
+
+    def scan(self, src, dst, n, carry):
+        """dst[:n] = carry + exclusive scan of src[:n]; carry: 1-element int64 device tensor or None."""
+        need = self.lib.clo_hip_scan_workspace_bytes(n, self.elem_size, self.sum_size)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=src.device)
+        self._hip.check(self.lib.clo_hip_scan_exclusive_carry(
+            src.data_ptr(), dst.data_ptr(), n, self.elem_size, self.elem_signed, self.sum_size,
+            carry.data_ptr() if carry is not None else None, None,
+            self._ws.data_ptr(), self._ws.numel(), self.stream), "clo_hip_scan_exclusive_carry")
+
+
+class ShardedScanner:
+    """Exclusive scan of an array whose r-th contiguous piece lives on rank r."""
+
+    def __init__(self, ops, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.ops = ops
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    @staticmethod
+    def carry_of(totals, rank):
+        """Sum mod 2^64 of the totals of the ranks before `rank`, as a signed 64-bit value."""
+        c = sum(int(x) & 0xFFFFFFFFFFFFFFFF for x in totals[:rank]) & 0xFFFFFFFFFFFFFFFF
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def scan(self, local, out, n=None):
+        """out[:n] = exclusive scan of the global array restricted to this rank's piece."""
+        torch, dist = self.torch, self.dist
+        n = local.numel() if n is None else n
+        if self.world == 1:
+            self.ops.scan(local, out, n, None)
+            return out
+        total = self.ops.reduce(local, n)                                   # step 1
+        if dist.get_backend(self.group) != "nccl":
+            total = total.cpu()          # (gloo moves host tensors; RCCL needs them on the device)
+        gathered = [torch.empty_like(total) for _ in range(self.world)]
+        dist.all_gather(gathered, total, group=self.group)                  # step 2
+        totals = torch.cat(gathered).cpu().tolist()
+        carry = torch.tensor([self.carry_of(totals, self.rank)], dtype=torch.int64, device=local.device)
+        self.ops.scan(local, out, n, carry)                                 # step 3
+        return out

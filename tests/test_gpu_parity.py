@@ -628,6 +628,50 @@ def test_two_ranks_on_one_gpu_hip_ops_end_to_end(gpu, tmp_path):
     assert np.all(outs[0] >> 31 == 0) and np.all(outs[1] >> 31 == 1)
 
 
+def _two_rank_scan_worker(rank, world, port, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    from cl_ops_amd.multigpu import HipScanOps, ShardedScanner
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        a = np.random.default_rng(60 + rank).integers(0, 1 << 32, n + 17 * rank, dtype=np.uint32)
+        local = torch.from_numpy(a.view(np.int32).copy()).cuda()
+        out = torch.empty(a.size, dtype=torch.int64, device="cuda")
+        ShardedScanner(HipScanOps("uint", "ulong", 0)).scan(local, out, a.size)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), a)
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), out.cpu().numpy().view(np.uint64))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_scan_two_ranks_on_one_gpu(gpu, tmp_path):
+    """uint -> ulong scan over two pieces; the only exchange is the 8-byte all-gather of the sums."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_scan_worker, args=(2, port, 1 << 20, str(tmp_path)), nprocs=2, join=True)
+    a = np.concatenate([np.load(tmp_path / ("in_%d.npy" % r)) for r in range(2)])
+    got = np.concatenate([np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)])
+    assert np.array_equal(got, O.serial_scan(a, np.uint64))
+
+
+def test_sharded_scanner_world_size_one(gpu):
+    import torch
+    from cl_ops_amd.multigpu import HipScanOps, ShardedScanner
+    a = np.random.default_rng(1).integers(0, 128, 100001, dtype=np.uint32)
+    local = torch.from_numpy(a.view(np.int32).copy()).cuda()
+    out = torch.empty(a.size, dtype=torch.int32, device="cuda")
+    ShardedScanner(HipScanOps("uint", "uint", 0)).scan(local, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), O.serial_scan(a, np.uint32))
+
+
 # ----------------------------------------------------------------------------
 # compare / get_key outside the ahead-of-time family: compiled at run time
 # (hiprtc), as upstream compiles every sorter by OpenCL JIT

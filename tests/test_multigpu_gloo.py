@@ -94,6 +94,67 @@ def test_sharded_sort_over_gloo(tmp_path, world, elem_type, n, skew):
             assert np.all((o >> o.dtype.type(bits - b)) == r)
 
 
+class NumpyScanOps:
+    """CPU stand-in for HipScanOps with the same contract (uint elements)."""
+
+    def __init__(self, sum_dtype):
+        self.sum_dtype = np.dtype(sum_dtype)
+
+    def reduce(self, t, n):
+        import torch
+        tot = int(t.numpy()[:n].view(np.uint32).sum(dtype=np.uint64))
+        return torch.tensor([tot - (1 << 64) if tot >= (1 << 63) else tot], dtype=torch.int64)
+
+    def scan(self, src, dst, n, carry):
+        import oracle_lib as O
+        a = src.numpy()[:n].view(np.uint32)
+        c = (int(carry[0]) & 0xFFFFFFFFFFFFFFFF) if carry is not None else 0
+        ex = O.serial_scan(a, self.sum_dtype).astype(np.uint64) + np.uint64(c)
+        dst.numpy()[:n].view(self.sum_dtype)[:] = ex.astype(self.sum_dtype)
+
+
+def _scan_worker(rank, world, port, sum_dtype, sizes, big, out_dir):
+    import torch
+    import torch.distributed as dist
+    from cl_ops_amd.multigpu import ShardedScanner
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n = sizes[rank]
+        rng = np.random.default_rng(7 + rank)
+        a = rng.integers(0, 2**32 if big else 128, n, dtype=np.uint64).astype(np.uint32)
+        local = torch.from_numpy(a.view(np.int32).copy())
+        sdt = np.dtype(sum_dtype)
+        out = torch.zeros(max(n, 1), dtype=torch.int32 if sdt.itemsize == 4 else torch.int64)
+        ShardedScanner(NumpyScanOps(sdt)).scan(local, out, n)
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), a)
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), out.numpy()[:n].view(sdt).copy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sum_dtype,sizes,big", [(2, "uint32", (5000, 3001), False), (2, "uint64", (4096, 4096), True),
+                                                       (4, "uint32", (100, 0, 777, 1), True)])
+def test_sharded_scan_over_gloo(tmp_path, world, sum_dtype, sizes, big):
+    """Uneven (and empty) pieces, wrap-around in the sum type: the concatenation
+    of the ranks' outputs is the scan of the concatenated input."""
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    port = _free_port()
+    mp.spawn(_scan_worker, args=(world, port, sum_dtype, sizes, big, str(tmp_path)), nprocs=world, join=True)
+    a = np.concatenate([np.load(tmp_path / ("in_%d.npy" % r)) for r in range(world)])
+    got = np.concatenate([np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(got, O.serial_scan(a, np.dtype(sum_dtype)))
+
+
+def test_scan_carry_wraps_mod_2_64():
+    from cl_ops_amd.multigpu import ShardedScanner
+    assert ShardedScanner.carry_of([5, 7, 9], 0) == 0
+    assert ShardedScanner.carry_of([5, 7, 9], 2) == 12
+    assert ShardedScanner.carry_of([-1, 2], 2) == 1                       # (2^64 - 1) + 2 mod 2^64
+    assert ShardedScanner.carry_of([(1 << 63) - 1, 1], 2) == -(1 << 63)   # bit pattern 0x8000...
+
+
 def test_exchange_plan_is_consistent():
     from cl_ops_amd.multigpu import ShardedSorter
     m = np.array([[5, 0, 7, 1], [2, 2, 2, 2], [0, 9, 0, 0], [4, 4, 4, 4]])
