@@ -194,9 +194,9 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 	clo_return_val_if_fail(ctx != NULL, NULL);
 	clo_return_val_if_fail(elem_type != NULL, NULL);
 
-	/* ref: clo_sort_abstract.c:111-117 (gselect is outside this build). */
+	/* ref: clo_sort_abstract.c:111-117 */
 	const CloSortImplDef* impls[] = {
-		&clo_sort_sbitonic_def, &clo_sort_abitonic_def, &clo_sort_satradix_def, NULL
+		&clo_sort_sbitonic_def, &clo_sort_abitonic_def, &clo_sort_gselect_def, &clo_sort_satradix_def, NULL
 	};
 
 	CloSort* sorter = NULL;

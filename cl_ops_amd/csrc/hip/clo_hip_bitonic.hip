@@ -338,9 +338,82 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 	return tiled_run<E, 0>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
 }
 
+// ---------------------------------------------------------------------------
+// gselect: global-memory selection (rank) sort, upstream's O(n^2) baseline
+// sorter (sort/clo_sort_gselect.cl:38-58): element gid goes to position
+//   #{ i : COMPARE(key_gid, key_i)  or  (key_i == key_gid and i < gid) }.
+// Upstream's work-item reads all n keys from global memory; here a work-group
+// stages 2048 ordered keys at a time in LDS and every thread walks the stage
+// (all lanes read the same LDS word: a broadcast, no bank conflicts).
+// ---------------------------------------------------------------------------
+constexpr int GSEL_THREADS = 256;
+constexpr int GSEL_STAGE = 2048;
+
+template <typename E>
+__device__ __forceinline__ unsigned long long gsel_key(E e, const key_desc& kd) {
+	unsigned long long raw = ((unsigned long long) e >> kd.shift) & kd.mask;
+	if (kd.kind == 2 && raw == kd.signbit) e = (E) ((unsigned long long) e & ~(kd.signbit << kd.shift));  // -0 == +0, as upstream's float compare
+	return okey<E>(e, kd);
+}
+
+template <typename E>
+__global__ __launch_bounds__(GSEL_THREADS)
+void clo_gselect_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n, key_desc kd) {
+	__shared__ unsigned long long s_key[GSEL_STAGE];
+	const size_t gid = (size_t) blockIdx.x * GSEL_THREADS + threadIdx.x;
+	const E mine = gid < n ? in[gid] : (E) 0;
+	const unsigned long long km = gsel_key<E>(mine, kd);
+	size_t pos = 0;
+	for (size_t base = 0; base < n; base += GSEL_STAGE) {
+		const unsigned cnt = n - base < (size_t) GSEL_STAGE ? (unsigned) (n - base) : (unsigned) GSEL_STAGE;
+		__syncthreads();
+		for (unsigned i = threadIdx.x; i < cnt; i += GSEL_THREADS) s_key[i] = gsel_key<E>(in[base + i], kd);
+		__syncthreads();
+		// ties: only elements with a smaller index count; the stage is wholly
+		// before gid, wholly after it, or contains it
+		const unsigned before = gid <= base ? 0u : (gid - base < (size_t) cnt ? (unsigned) (gid - base) : cnt);
+		unsigned c = 0;
+		if (kd.descending) {
+			for (unsigned i = 0; i < cnt; ++i) { const unsigned long long k = s_key[i]; c += (k > km) | ((k == km) & (i < before)); }
+		} else {
+			for (unsigned i = 0; i < cnt; ++i) { const unsigned long long k = s_key[i]; c += (k < km) | ((k == km) & (i < before)); }
+		}
+		pos += c;
+	}
+	if (gid < n && pos < n) out[pos] = mine;
+}
+
+template <typename E>
+int gselect_impl(const void* src, void* dst, size_t n, int key_shift, int key_bits, int key_size, int key_kind,
+	int descending, hipStream_t s) {
+	key_desc kd;
+	E pad;
+	const int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
+	if (st != 0) return st;
+	clo_timing_scope timing("gselect", s);
+	hipLaunchKernelGGL((clo_gselect_kernel<E>), dim3((unsigned) ((n + GSEL_THREADS - 1) / GSEL_THREADS)), dim3(GSEL_THREADS), 0, s,
+		(const E*) src, (E*) dst, n, kd);
+	return (int) hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
+
+int clo_hip_gselect(const void* src, void* dst, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending, void* stream) {
+	if (numel == 0) return 0;
+	if (!src || !dst || src == dst) return CLO_HIP_EARGS;
+	if (numel > 0xffffffffull) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	switch (elem_size) {
+		case 1: return gselect_impl<uint8_t>(src, dst, numel, key_shift, key_bits, key_size, key_kind, descending, s);
+		case 2: return gselect_impl<uint16_t>(src, dst, numel, key_shift, key_bits, key_size, key_kind, descending, s);
+		case 4: return gselect_impl<uint32_t>(src, dst, numel, key_shift, key_bits, key_size, key_kind, descending, s);
+		case 8: return gselect_impl<uint64_t>(src, dst, numel, key_shift, key_bits, key_size, key_kind, descending, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
 
 size_t clo_hip_bitonic_padded_numel(size_t numel) { return nlpo2(numel ? numel : 1); }
 
@@ -386,6 +459,7 @@ size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
 		return bits <= 4 ? clo_radix4_lds_bytes(f == "radix_hist" ? "hist" : "pass", elem_size, bits)
 		                 : clo_radixw_lds_bytes(f == "radix_hist" ? "hist" : "pass", elem_size, bits);
 	}
+	if (f == "gselect") return GSEL_STAGE * sizeof(unsigned long long);
 	if (f == "scan") return ((param > 4 ? 8 : 16) * 4 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;
 	return 0;  // bitonic_strided, bitonic_step: registers only
 }

@@ -153,6 +153,12 @@ int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
 	int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, void* stream);
 
+/* ---- gselect (replaces the launch of sort/clo_sort_gselect.c:60-118 /
+ *      sort/clo_sort_gselect.cl:38-58): O(n^2) rank sort, stable, out of place
+ *      (dst != src); key description as for the bitonic sorts. ---- */
+int clo_hip_gselect(const void* src, void* dst, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending, void* stream);
+
 /* ---- bitonic sorts specialised at run time (hiprtc) for arbitrary compare /
  *      get_key expressions — what upstream does for every sorter by OpenCL JIT
  *      (sort/clo_sort_abstract.c:144-179). elem_type / key_type: CloType numbers.

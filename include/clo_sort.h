@@ -3,10 +3,9 @@
  * src/cl_ops/sort/clo_sort_abstract.in.h:43-170 (same names, argument order,
  * ownership and error behaviour), implemented over HIP.
  *
- * Algorithms registered: "sbitonic", "abitonic", "satradix"
- * (clo_sort_sbitonic.in.h:36, clo_sort_abitonic.in.h:116, clo_sort_satradix.in.h:55).
- * "gselect" is outside this build's scope: clo_sort_new reports
- * CLO_ERROR_IMPL_NOT_FOUND for it.
+ * Algorithms registered: "sbitonic", "abitonic", "gselect", "satradix"
+ * (clo_sort_sbitonic.in.h:36, clo_sort_abitonic.in.h:116, clo_sort_gselect.in.h:36,
+ * clo_sort_satradix.in.h:55).
  *
  * Divergences from upstream, all deliberate:
  *  - `compare` / `get_key` are OpenCL C macro bodies upstream (JIT). Here they
@@ -29,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CLO_SORT_IMPLS "sbitonic, abitonic, satradix"
+#define CLO_SORT_IMPLS "sbitonic, abitonic, gselect, satradix"
 
 /* clo_sort_abstract.in.h:43-110 */
 typedef struct clo_sort_impl_def {
@@ -67,12 +66,14 @@ const char* clo_sort_get_kernel_name(CloSort* sorter, cl_uint i, GError** err);
 size_t clo_sort_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max, size_t numel, GError** err);
 
 extern const CloSortImplDef clo_sort_sbitonic_def;  /* clo_sort_sbitonic.in.h:36 */
+extern const CloSortImplDef clo_sort_gselect_def;   /* clo_sort_gselect.in.h:36 */
 extern const CloSortImplDef clo_sort_abitonic_def;  /* clo_sort_abitonic.in.h:116 */
 extern const CloSortImplDef clo_sort_satradix_def;  /* clo_sort_satradix.in.h:55 */
 
 /* Kernel-name strings reported by get_kernel_name — part of the observable API
  * (clo_sort_sbitonic.in.h:33, clo_sort_satradix.in.h:42-52, clo_sort_abitonic.in.h:64-106). */
 #define CLO_SORT_SBITONIC_KNAME "sbitonic"
+#define CLO_SORT_GSELECT_KNAME "gselect"   /* clo_sort_gselect.in.h:33 */
 #define CLO_SORT_SATRADIX_NUM_KERNELS 3
 #define CLO_SORT_SATRADIX_KNAME_LOCALSORT "satradix_localsort"
 #define CLO_SORT_SATRADIX_KNAME_HISTOGRAM "satradix_histogram"

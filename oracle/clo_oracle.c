@@ -146,6 +146,39 @@ void clo_oracle_sbitonic(void* data, size_t numel, const clo_oracle_desc* d) {
 			layer_any(data, n, stage, step, d);
 }
 
+/* Typed "a == b" on raw key bits (the kernel's key_i == key_gid). */
+static inline int key_eq(uint64_t a, uint64_t b, int key_size, int kind) {
+	if (kind == CLO_ORACLE_KEY_FLOAT) {
+		if (key_size == 4) {
+			float x, y; uint32_t ua = (uint32_t) a, ub = (uint32_t) b;
+			memcpy(&x, &ua, 4); memcpy(&y, &ub, 4);
+			return x == y;
+		} else if (key_size == 8) {
+			double x, y;
+			memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+			return x == y;
+		}
+	}
+	return a == b;
+}
+
+void clo_oracle_gselect(const void* data_in, void* data_out, size_t numel, const clo_oracle_desc* d) {
+	/* ref: clo_sort_gselect.cl:38-58 — one work-item per element (gws = numel
+	 * rounded up, the kernel guards gid < size): position = number of elements
+	 * that compare before it, ties broken by index. clo_sort_gselect.c:105-116
+	 * launches it once. */
+	for (size_t gid = 0; gid < numel; ++gid) {
+		uint64_t e = ld(data_in, gid, d->elem_size);
+		uint64_t kg = key_get(e, d);
+		size_t pos = 0;
+		for (size_t i = 0; i < numel; ++i) {
+			uint64_t ki = key_get(ld(data_in, i, d->elem_size), d);
+			if (key_compare(kg, ki, d) || (key_eq(ki, kg, d->key_size, d->key_kind) && i < gid)) ++pos;
+		}
+		st(data_out, pos, d->elem_size, e);
+	}
+}
+
 /* Register network of the priv/hyb kernels: V = 2^S values, strides V/2 .. 1.
  * ref: clo_sort_abitonic.cl:163-224 (ABIT_SORT_4S16V / 3S8V / 2S4V). The values
  * sit at data[base + j*inc]. */

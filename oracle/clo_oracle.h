@@ -59,6 +59,10 @@ void clo_oracle_suggest_worksizes(size_t real_ws, size_t dev_max_lws,
  * be a power of two (reference kernels have no bounds). */
 void clo_oracle_sbitonic(void* data, size_t numel, const clo_oracle_desc* d);
 
+/* clo_sort_gselect.c:60-118 + clo_sort_gselect.cl:38-58: O(n^2) rank sort, out of
+ * place (data_out != data_in), any numel. */
+void clo_oracle_gselect(const void* data_in, void* data_out, size_t numel, const clo_oracle_desc* d);
+
 /* clo_sort_abitonic.c:58-313 (strategy), :401-432 (stage/step loop) and
  * clo_sort_abitonic.cl (any / local_sK / priv_SsVv / hyb_sK_SsVv index rules).
  * Returns the number of kernel launches (global round trips) the strategy

@@ -44,6 +44,8 @@ def lib():
         L.clo_oracle_tzc.argtypes = [C.c_int]
         L.clo_oracle_sbitonic.argtypes = [vp, sz, C.POINTER(Desc)]
         L.clo_oracle_sbitonic.restype = None
+        L.clo_oracle_gselect.argtypes = [vp, vp, sz, C.POINTER(Desc)]
+        L.clo_oracle_gselect.restype = None
         L.clo_oracle_abitonic.argtypes = [vp, sz, C.POINTER(Desc), sz, sz, C.c_uint, C.c_uint, C.c_uint]
         L.clo_oracle_abitonic.restype = C.c_int
         L.clo_oracle_satradix.argtypes = [vp, sz, C.POINTER(Desc), C.c_uint, sz, sz, vp, vp, vp]
@@ -81,6 +83,14 @@ def sbitonic(arr, **kw):
     out = np.ascontiguousarray(arr).copy()
     d = desc_for(out, **kw)
     lib().clo_oracle_sbitonic(_p(out), out.size, C.byref(d))
+    return out
+
+
+def gselect(arr, **kw):
+    a = np.ascontiguousarray(arr)
+    out = np.empty_like(a)
+    d = desc_for(a, **kw)
+    lib().clo_oracle_gselect(_p(a), _p(out), a.size, C.byref(d))
     return out
 
 

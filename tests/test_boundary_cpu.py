@@ -102,11 +102,11 @@ def off():
 
 
 def test_sort_impl_dispatch(off):
-    for alg in ("sbitonic", "abitonic", "satradix"):
+    for alg in ("sbitonic", "abitonic", "gselect", "satradix"):   # CLO_SORT_IMPLS, clo_sort_abstract.in.h:30
         s = clo.Sorter(alg, off, "uint")
         assert s.element_size == 4 and s.key_size == 4
         s.close()
-    for alg in ("gselect", "quicksort", ""):
+    for alg in ("quicksort", ""):
         with pytest.raises(clo.CloError) as e:
             clo.Sorter(alg, off, "uint")
         assert e.value.code == CLO_ERROR_IMPL_NOT_FOUND
@@ -119,6 +119,9 @@ def test_sort_impl_dispatch(off):
 def test_kernel_names_are_the_reference_ones(off):
     s = clo.Sorter("sbitonic", off, "uint")
     assert s.num_kernels() == 1 and s.kernel_name(0) == "sbitonic" and s.localmem_usage(0) == 0
+    s.close()
+    s = clo.Sorter("gselect", off, "uint")
+    assert s.num_kernels() == 1 and s.kernel_name(0) == "gselect"
     s.close()
     s = clo.Sorter("satradix", off, "uint")
     assert s.num_kernels() == 6

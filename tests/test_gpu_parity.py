@@ -673,6 +673,74 @@ def test_sharded_scanner_world_size_one(gpu):
 
 
 # ----------------------------------------------------------------------------
+# gselect: upstream's O(n^2) rank sort
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 2048, 2049, 5000])
+def test_gselect_matches_reference_kernel(gpu, n):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 50, n, dtype=np.uint64)
+    e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter("gselect", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    got = s.with_host_data(e, q)
+    s.close()
+    assert np.array_equal(got, O.gselect(e, key_size=4, key_shift=32))      # restated kernel
+    assert np.array_equal(got, O.stable_sort(e, key_size=4, key_shift=32))  # = a stable sort
+
+
+@pytest.mark.parametrize("et", ["uint", "int", "float", "short", "ulong"])
+@pytest.mark.parametrize("compare", [None, "((a) < (b))"])
+def test_gselect_types_and_descending(gpu, et, compare):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(3)
+    n = 3000
+    if np.issubdtype(dt, np.floating):
+        a = ((rng.random(n) - 0.5) * 100).astype(dt)
+        a[:4] = [0.0, -0.0, 1.0, -1.0]
+    else:
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+    s = clo.Sorter("gselect", ctx, et, compare=compare)
+    got = s.with_host_data(a, q)
+    kind = O.KEY_FLOAT if np.issubdtype(dt, np.floating) else (O.KEY_SIGNED if np.issubdtype(dt, np.signedinteger) else O.KEY_UNSIGNED)
+    exp = O.gselect(a, key_kind=kind, descending=compare is not None)
+    u = np.dtype("u%d" % dt.itemsize)
+    assert np.array_equal(got.view(u), exp.view(u))
+    s.close()
+
+
+def test_gselect_device_data_with_and_without_output_buffer(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 10000
+    a = rand_u32(np.random.default_rng(8), n)
+    s = clo.Sorter("gselect", ctx, "uint")
+    bin_, bout = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, a.nbytes)
+    bin_.write(q, a)
+    s.with_device_data(q, bin_, bout, n)
+    assert np.array_equal(bout.read(q, np.uint32, n), np.sort(a))
+    assert np.array_equal(bin_.read(q, np.uint32, n), a)
+    s.with_device_data(q, bin_, None, n)          # upstream: temporary + copy back (clo_sort_gselect.c:83-127)
+    assert np.array_equal(bin_.read(q, np.uint32, n), np.sort(a))
+    q2 = clo.Queue(ctx)
+    bin_.write(q, a)
+    q.finish()
+    s.with_device_data(q, bin_, None, n, q_comm=q2)
+    q2.finish()
+    assert np.array_equal(bin_.read(q, np.uint32, n), np.sort(a))
+    with pytest.raises(clo.CloError):
+        s.with_device_data(q, bin_, bin_, n)
+    for b in (bin_, bout):
+        b.close()
+    q2.close()
+    s.close()
+
+
+# ----------------------------------------------------------------------------
 # compare / get_key outside the ahead-of-time family: compiled at run time
 # (hiprtc), as upstream compiles every sorter by OpenCL JIT
 # ----------------------------------------------------------------------------

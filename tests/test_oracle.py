@@ -149,3 +149,23 @@ def test_typed_compare_and_descending():
     assert np.array_equal(O.abitonic(f, key_kind=O.KEY_FLOAT)[0], np.sort(f))
     u = rng.integers(0, 2**32, 1024, dtype=np.uint64).astype(np.uint32)
     assert np.array_equal(O.sbitonic(u, descending=True), np.sort(u)[::-1])
+
+
+# ---------------------------------------------------------------------------
+# gselect restatement (clo_sort_gselect.cl:38-58): a stable rank sort
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [1, 2, 17, 256, 1000])
+def test_gselect_is_a_stable_sort_by_key(n):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 20, n, dtype=np.uint64)
+    e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    got = O.gselect(e, key_size=4, key_shift=32)
+    assert np.array_equal(got, O.stable_sort(e, key_size=4, key_shift=32))
+    assert O.check_sorted(O.gselect(O.bench_rand(n, "uint", n))) == -1
+
+
+def test_gselect_descending_and_signed():
+    a = np.random.default_rng(0).integers(-1000, 1000, 500).astype(np.int32)
+    assert np.array_equal(O.gselect(a, key_kind=O.KEY_SIGNED), np.sort(a))
+    assert np.array_equal(O.gselect(a, key_kind=O.KEY_SIGNED, descending=True), np.sort(a)[::-1])
