@@ -12,8 +12,9 @@
 // it once in ONE kernel, and no kernel waits on another work-group:
 //   * digits of 1..4 bits (radix <= 16, the default): clo_hip_radix4.hip —
 //     packed-counter ranking, next digit's histogram fused into the scatter;
-//   * digits of 5..8 bits (radix 32..256): clo_hip_radixw.hip — match-any
-//     ranking, one histogram kernel per digit.
+//   * digits of 5..8 bits (radix 32..256): the digit is split in two halves
+//     that are ranked one after the other inside the work-group
+//     (clo_radix4_pair_kernel), one histogram kernel per digit (clo_hip_radixw.hip).
 // Stability per pass + LSD order give exactly the order the reference produces
 // (stable ascending by key), for any digit width.
 #include <hip/hip_runtime.h>
@@ -74,7 +75,7 @@ int clo_hip_radix_set_debug_buffer(void* dptr) {
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits) {
 	if (digit_bits < 1 || digit_bits > 8 || key_bits < 1) return 0;
 	return digit_bits <= 4 ? clo_radix4_workspace_bytes(numel, elem_size, key_bits, digit_bits)
-	                       : clo_radixw_workspace_bytes(numel, elem_size, digit_bits);
+	                       : clo_radix4_pair_workspace_bytes(numel, elem_size, digit_bits);
 }
 
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
@@ -93,7 +94,7 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	const clo_keyx kx = clo_keyx_make(key_kind, key_shift, key_bits);
 	if (digit_bits <= 4)
 		return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
-	return clo_radixw_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
+	return clo_radix4_pair_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
 }
 
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {

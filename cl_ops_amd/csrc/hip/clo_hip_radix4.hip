@@ -485,6 +485,204 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 }
 
 // ---------------------------------------------------------------------------
+// Digit pairs: TWO digit steps per trip through HBM.
+//
+// A tile is split by digit `lo` and then by digit `hi` inside the work-group
+// (two stable local splits through the LDS stage, each with the packed-counter
+// ranking above), which leaves it sorted by the combined digit D = hi:lo. The
+// global step — per-tile histogram of D (clo_hip_radixw.hip), digit-major scan
+// of the counters, scatter — then runs once for the combined digit. This is the
+// pass for digits of 5..8 bits (radix 32..256), split in two halves of <= 4
+// bits so that the packed-counter ranking applies. Stability of both local
+// splits and of the scatter makes the result the one the reference's passes
+// produce.
+// (Measured as a replacement for two single-digit passes on 4-bit digits — 12
+// element streams per 32-bit key instead of 17 — it LOSES: 0.79 ms per pair
+// against 2 x 0.46 + fused histograms, 4.38 ms against 3.94 ms for 2^28 keys.
+// The single-digit pass keeps its LDS pipe ~90 % busy (SQ_ACTIVE_INST_LDS), so
+// a second local split costs what a second pass costs. Against ranking wide
+// digits with one ballot per digit bit it wins: 0.79 ms vs 0.87 ms per 8-bit
+// pass, 0.58 vs 0.75 ms per 6-bit pass.)
+// ---------------------------------------------------------------------------
+
+// One stable local split of the tile by the digit (key >> dshift) & dmask;
+// on return (after a barrier) s_stage holds the tile in digit order. The
+// thread's elements are ITEMS consecutive positions of the tile.
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX>
+__device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
+	E* s_stage, unsigned (*s_end)[THREADS], unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], unsigned* s_dstart16) {
+	constexpr int R = 1 << BITS;
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int WAVES = THREADS / 64;
+	constexpr int TILE = THREADS * ITEMS;
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned tbase = tid * ITEMS;
+	const bool full = count == (unsigned) TILE;
+
+	// thread-private counts, LAST element first (see the pass kernel above)
+	unsigned long long c = 0;
+	unsigned rr = 0;
+	#pragma unroll
+	for (int i = ITEMS - 1; i >= 0; --i) {
+		if (full || tbase + i < count) {
+			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
+			c += 1ull << sh;
+			rr |= ((unsigned) (c >> sh) & 15u) << (4 * i);
+		}
+	}
+	unsigned w[H];
+	pc2_wave_scan<BITS>(c, w);
+	if (lane == 63) {
+		#pragma unroll
+		for (int j = 0; j < H; ++j) s_wtot[wave][j] = w[j];
+	}
+	__syncthreads();
+	if (tid < 64) {
+		// digit totals -> tile-local digit starts (exclusive scan over the digits)
+		unsigned h = 0;
+		if (tid < (unsigned) R) {
+			#pragma unroll
+			for (int wv = 0; wv < WAVES; ++wv) h += (s_wtot[wv][tid >> 1] >> ((tid & 1u) * 16u)) & 0xffffu;
+		}
+		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
+		const unsigned odd = (unsigned) __shfl((int) dstart, (int) (lane | 1u), 64);
+		if (tid < (unsigned) R && (tid & 1u) == 0) s_dstart16[tid >> 1] = dstart | ((R > 1 ? odd : 0u) << 16);
+	}
+	__syncthreads();
+	if (tid < WAVES * H) {
+		const unsigned wv = tid / H, j = tid % H;
+		unsigned run = s_dstart16[j];
+		for (unsigned k = 0; k < wv; ++k) run += s_wtot[k][j];
+		s_wbase[wv][j] = run;
+	}
+	__syncthreads();
+	#pragma unroll
+	for (int j = 0; j < H; ++j) s_end[j][tid] = w[j] + s_wbase[wave][j];
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		if (full || tbase + i < count) {
+			const unsigned d = (unsigned) (key[i] >> dshift) & dmask;
+			const unsigned end = (s_end[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
+			s_stage[(end - ((rr >> (4 * i)) & 15u)) & (TILE - 1)] = key[i];
+		}
+	}
+	__syncthreads();
+}
+
+template <typename E> struct pair_shape {
+	static constexpr int THREADS = sizeof(E) == 8 ? 512 : 1024;   // 8 items per thread: tiles of 4096 / 8192 elements,
+	static constexpr int ITEMS = 8;                               // = the tiles of clo_hip_radixw.hip's histogram
+};
+
+template <typename E, int LB, int HB>
+__global__ __launch_bounds__(pair_shape<E>::THREADS)
+void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
+	unsigned shift, unsigned mask_lo, unsigned mask_hi,
+	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
+	clo_keyx kx_in, clo_keyx kx_out) {
+
+	constexpr int THREADS = pair_shape<E>::THREADS;
+	constexpr int ITEMS = pair_shape<E>::ITEMS;
+	constexpr int TILE = THREADS * ITEMS;
+	constexpr int WAVES = THREADS / 64;
+	constexpr int R2 = 1 << (LB + HB);
+	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
+	static_assert(R2 <= 256 && R2 <= THREADS, "one thread per combined digit, scanned by the first four waves");
+
+	__shared__ E s_stage[TILE];
+	__shared__ unsigned s_end[HMAX][THREADS];
+	__shared__ unsigned s_wtot[WAVES][HMAX];
+	__shared__ unsigned s_wbase[WAVES][HMAX];
+	__shared__ unsigned s_dstart16[HMAX];
+	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
+	__shared__ unsigned s_w4[4];
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned tile = blockIdx.x;
+	const size_t base = (size_t) tile * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	const bool full = count == (unsigned) TILE;
+	const unsigned tbase = tid * ITEMS;
+	const unsigned mask2 = (mask_hi << LB) | mask_lo;
+	const unsigned n32 = n > 0xffffffffull ? 0xffffffffu : (unsigned) n;   // global indices are 32-bit here
+
+	// the tile's counters (upstream's counters / counters_sum), requested before the keys
+	unsigned h2 = 0, goff = 0;
+	if (tid < (unsigned) R2) {
+		h2 = thist[(size_t) tile * R2 + tid];
+		goff = toff[(size_t) tile * R2 + tid];
+	}
+	E key[ITEMS];
+	if (full) {
+		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
+	}
+	if (kx_in.kind) {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
+	}
+	// tile-local start of every combined digit: exclusive scan of the tile's histogram
+	const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
+	if (lane == 63 && wave < 4) s_w4[wave] = incl2;
+
+	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase, s_dstart16);
+
+	if (tid < (unsigned) R2) {
+		unsigned dstart2 = incl2 - h2;
+		#pragma unroll
+		for (unsigned w = 0; w < 4; ++w) if (w < wave) dstart2 += s_w4[w];
+		s_delta[tid] = goff - dstart2;
+	}
+	if (mask_hi != 0) {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) if (full || tbase + i < count) key[i] = s_stage[tbase + i];
+		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase, s_dstart16);
+	} else {
+		__syncthreads();
+	}
+
+	// contiguous runs to HBM: a thread takes VEC consecutive positions of the
+	// sorted tile; inside a run they go out as one 16-byte store
+	constexpr int VEC = sizeof(E) >= 8 ? 1 : 4;
+	typedef E vecE __attribute__((ext_vector_type(VEC)));
+	typedef E vecE_u __attribute__((ext_vector_type(VEC), aligned(sizeof(E))));
+	#pragma unroll
+	for (int j = 0; j < ITEMS / VEC; ++j) {
+		const unsigned p = (j * THREADS + tid) * VEC;
+		if (full) {
+			const vecE v = *reinterpret_cast<const vecE*>(&s_stage[p]);
+			const unsigned d0 = (unsigned) (v[0] >> shift) & mask2, dl = (unsigned) (v[VEC - 1] >> shift) & mask2;
+			const unsigned gi0 = p + s_delta[d0];
+			if (d0 == dl && gi0 <= n32 - VEC) {
+				vecE vo = v;
+				if (kx_out.kind) {
+					#pragma unroll
+					for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(v[k], kx_out);
+				}
+				*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
+			} else {
+				#pragma unroll
+				for (int k = 0; k < VEC; ++k) {
+					const unsigned gi = p + k + s_delta[(unsigned) (v[k] >> shift) & mask2];
+					if (gi < n32) out[gi] = clo_keyx_inv<E>(v[k], kx_out);
+				}
+			}
+		} else {
+			#pragma unroll
+			for (int k = 0; k < VEC; ++k) {
+				if (p + k < count) {
+					const E e = s_stage[p + k];
+					const unsigned gi = p + k + s_delta[(unsigned) (e >> shift) & mask2];
+					if (gi < n32) out[gi] = clo_keyx_inv<E>(e, kx_out);
+				}
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Arrays of at most one tile: every digit pass inside ONE work-group, one
 // launch for the whole sort (upstream's harness sweeps sizes from 2^4 up; a
 // multi-kernel sort costs ~25 dependent launches however small the array).
@@ -707,6 +905,92 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	return (int) hipGetLastError();
 }
 
+// Wide digits on the host side: per pass, histogram of the digit -> counter
+// scan -> pair kernel (the digit split in two halves of <= 4 bits).
+
+struct rp_layout { size_t thist, toff, partial, total, tiles; };
+
+rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {
+	rp_layout L;
+	const size_t R2 = (size_t) 1 << pass_bits;
+	const size_t tile = clo_radixw_tile_elems(elem_size);
+	L.tiles = (n + tile - 1) / tile;
+	if (L.tiles == 0) L.tiles = 1;
+	const size_t per = L.tiles * R2 * sizeof(unsigned);
+	L.thist = CLO_WS_HEADER_BYTES;
+	L.toff = L.thist + per;
+	L.partial = L.toff + per;
+	L.total = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
+	return L;
+}
+
+template <typename E, int LB, int HB>
+int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, clo_keyx kx, void* ws, hipStream_t s) {
+	constexpr int PB = LB + HB;   // key bits per trip through HBM
+	const int passes = (key_bits + PB - 1) / PB;
+	const rp_layout L = rp_make_layout(n, (int) sizeof(E), PB);
+	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
+	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
+	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
+	const unsigned tiles = (unsigned) L.tiles;
+	const clo_keyx kx_none = { 0, 0, 0 };
+
+	hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES, s);   // status word
+	if (e != hipSuccess) return (int) e;
+
+	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
+	const E* cur_in = src;
+	for (int p = 0; p < passes; ++p) {
+		E* cur_out;
+		if (inplace_odd) cur_out = (p % 2 == 0) ? tmp : dst;
+		else cur_out = ((passes - 1 - p) % 2 == 0) ? dst : tmp;
+		const int rem = key_bits - p * PB;
+		const int bits = rem < PB ? rem : PB;
+		const int lo_bits = bits < LB ? bits : LB, hi_bits = bits - lo_bits;
+		const unsigned shift = (unsigned) (key_shift + p * PB);
+		const unsigned mask_lo = (1u << lo_bits) - 1u, mask_hi = (1u << hi_bits) - 1u;
+		{
+			clo_timing_scope timing("radix_hist", s);
+			const int st = clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
+				thist, tiles, p == 0 ? kx : kx_none, s);
+			if (st != 0) return st;
+		}
+		{
+			clo_timing_scope timing("radix_offsets", s);
+			const int st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, s);
+			if (st != 0) return st;
+		}
+		{
+			clo_timing_scope timing("radix_pass", s);
+			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s,
+				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
+				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
+		}
+		cur_in = cur_out;
+	}
+	e = hipGetLastError();
+	if (e != hipSuccess) return (int) e;
+	if (inplace_odd) {
+		e = hipMemcpyAsync(dst, tmp, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+		if (e != hipSuccess) return (int) e;
+	}
+	return 0;
+}
+
+template <typename E>
+int rp_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits, int digit_bits,
+	clo_keyx kx, void* ws, hipStream_t s) {
+	#define CLO_RP(LB, HB) return rp_sort_impl<E, LB, HB>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s)
+	switch (digit_bits) {
+		case 5: CLO_RP(3, 2);
+		case 6: CLO_RP(3, 3);
+		case 7: CLO_RP(4, 3);
+		case 8: CLO_RP(4, 4);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+	#undef CLO_RP
+}
+
 template <typename E, int LT>
 int r4_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits, int digit_bits,
 	clo_keyx kx, void* ws, hipStream_t s) {
@@ -754,6 +1038,27 @@ size_t clo_radix4_lds_bytes(const char* kernel, int elem_size, int digit_bits) {
 	if (kernel[0] == 'h') return R4_WAVES * (R >= 2 ? R / 2 : 1) * sizeof(unsigned);
 	return ((size_t) 4096 * elem_size) + NW * R4_THREADS * sizeof(unsigned)
 		+ (2 * R4_WAVES * NW + 2 * R * R + 2 * R + NW) * sizeof(unsigned);
+}
+
+size_t clo_radix4_pair_workspace_bytes(size_t n, int elem_size, int digit_bits) {
+	return rp_make_layout(n, elem_size, digit_bits).total;
+}
+
+size_t clo_radix4_pair_lds_bytes(int elem_size, int digit_bits) {
+	const size_t threads = elem_size == 8 ? 512 : 1024, hmax = digit_bits >= 7 ? 8 : 4;
+	return threads * 8 * (size_t) elem_size + hmax * threads * sizeof(unsigned)
+		+ (2 * (threads / 64) * hmax + hmax + ((size_t) 1 << digit_bits) + 4) * sizeof(unsigned);
+}
+
+int clo_radix4_pair_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
+	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s) {
+	switch (elem_size) {
+		case 1: return rp_dispatch<uint8_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 2: return rp_dispatch<uint16_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 4: return rp_dispatch<uint32_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 8: return rp_dispatch<uint64_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
 }
 
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,

@@ -32,7 +32,8 @@ def test_harnesses_build_and_fail_loudly_without_a_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("alg,opts,typ", [("sbitonic", "", "uint"), ("abitonic", "", "uint"), ("satradix", "", "uint"),
                                           ("satradix", "radix=256", "ulong"), ("abitonic", "maxps=2", "int"),
-                                          ("satradix", "", "ushort")])
+                                          ("satradix", "", "ushort"), ("satradix", "radix=64", "int"),
+                                          ("satradix", "", "float"), ("satradix", "", "long")])
 def test_sort_harness_on_gpu(alg, opts, typ, tmp_path):
     _build()
     out = tmp_path / "ns.tsv"
@@ -64,7 +65,7 @@ def test_scan_harness_on_gpu(types):
 @pytest.mark.gpu
 def test_harness_reports_api_errors():
     _build()
-    r = subprocess.run([os.path.join(BIN, "clo_hip_sort_bench"), "-a", "gselect", "-n", "8"], capture_output=True, text=True)
+    r = subprocess.run([os.path.join(BIN, "clo_hip_sort_bench"), "-a", "quicksort", "-n", "8"], capture_output=True, text=True)
     assert r.returncode == 5 and "was not found" in r.stderr       # CLO_ERROR_IMPL_NOT_FOUND
     r = subprocess.run([os.path.join(BIN, "clo_hip_sort_bench"), "-a", "satradix", "-g", "radix=12", "-n", "8"],
                        capture_output=True, text=True)
