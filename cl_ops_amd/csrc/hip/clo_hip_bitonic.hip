@@ -143,12 +143,16 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 	const size_t gbase = (size_t) blockIdx.x << kl;
 	auto phys = [](unsigned i) { return i + (i >> 5); };
 
-	// global -> LDS, coalesced
-	for (unsigned i = tid; i < tile; i += 256) s[phys(i)] = data[gbase + i];
-	__syncthreads();
-
 	// The thread's V values stay in VGPRs across consecutive step groups that
-	// use the same register bits (all of stages 1..Q, for one).
+	// use the same register bits (all of stages 1..Q, for one). The first group
+	// is loaded straight from global memory and the last one stored straight
+	// back (its register bits are the lowest Q: V consecutive elements, 16-byte
+	// vectors); LDS only carries the exchanges between groups. (In an exchange a
+	// thread overwrites exactly the LDS slots it last read — each layout
+	// partitions the tile among the threads — so one barrier per exchange.)
+	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));   // element alignment is all a caller guarantees
+	constexpr int PER = 16 / (int) sizeof(E);
+	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
 	E v[V];
 	int cur_b0 = -1;
 	unsigned base = 0;
@@ -169,8 +173,25 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 				}
 				base = ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u));
 				if (tid < nthr) {
-					#pragma unroll
-					for (int j = 0; j < V; ++j) v[j] = s[phys(base + ((unsigned) j << b0))];
+					if (cur_b0 < 0) {
+						// first group: from global memory (b0 == 0: V consecutive elements;
+						// b0 >= 6 or a single wave: lanes read adjacent elements)
+						if (b0 == 0) {
+							const vec16* src = reinterpret_cast<const vec16*>(data + gbase + base);
+							#pragma unroll
+							for (int k = 0; k < V / PER; ++k) {
+								const vec16 t = src[k];
+								#pragma unroll
+								for (int q = 0; q < PER; ++q) v[k * PER + q] = t[q];
+							}
+						} else {
+							#pragma unroll
+							for (int j = 0; j < V; ++j) v[j] = data[gbase + base + ((unsigned) j << b0)];
+						}
+					} else {
+						#pragma unroll
+						for (int j = 0; j < V; ++j) v[j] = s[phys(base + ((unsigned) j << b0))];
+					}
 				}
 				cur_b0 = (int) b0;
 			}
@@ -178,15 +199,17 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 			p = b0;
 		}
 	}
-	if (cur_b0 >= 0) {
-		if (tid < nthr) {
+	// every schedule ends on steps Q..1, i.e. with b0 == 0: V consecutive elements per thread
+	if (tid < nthr) {
+		vec16* dst = reinterpret_cast<vec16*>(data + gbase + base);
+		#pragma unroll
+		for (int k = 0; k < V / PER; ++k) {
+			vec16 t;
 			#pragma unroll
-			for (int j = 0; j < V; ++j) s[phys(base + ((unsigned) j << cur_b0))] = v[j];
+			for (int q = 0; q < PER; ++q) t[q] = v[k * PER + q];
+			dst[k] = t;
 		}
 	}
-	__syncthreads();
-
-	for (unsigned i = tid; i < tile; i += 256) data[gbase + i] = s[phys(i)];
 }
 
 // ---- pad the tail [numel, padded) with elements that sort last ----
@@ -303,15 +326,22 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	for (unsigned stage = kl + 1; stage <= T; ++stage) {
 		unsigned p = stage;
 		while (p > kl) {
+			// register bits of a strided pass: one or two more than the tile kernel's
+			// (identity keys, <= 4 bytes: 128 values per thread, 412 VGPRs, one wave per
+			// SIMD — these passes only stream, 19 of them instead of 24 at 2^26; the
+			// general compare needs more temporaries and would spill at that size)
+			constexpr int QS = MODE == 0 ? Q + 1 : Q + 2;
 			unsigned ns = p - kl;
-			if (ns > (unsigned) Q) ns = Q;
+			if (ns > (unsigned) QS) ns = QS;
 			switch (ns) {
 				case 1: launch_strided<E, 1, MODE>(data, n, stage, p, kd, s); break;
 				case 2: launch_strided<E, 2, MODE>(data, n, stage, p, kd, s); break;
 				case 3: launch_strided<E, 3, MODE>(data, n, stage, p, kd, s); break;
 				case 4: launch_strided<E, 4, MODE>(data, n, stage, p, kd, s); break;
+				case 5: launch_strided<E, 5, MODE>(data, n, stage, p, kd, s); break;
+				case 6: launch_strided<E, 6, MODE>(data, n, stage, p, kd, s); break;
 				default:
-					if constexpr (Q >= 5) launch_strided<E, 5, MODE>(data, n, stage, p, kd, s);
+					if constexpr (QS >= 7) launch_strided<E, 7, MODE>(data, n, stage, p, kd, s);
 					break;
 			}
 			++count;
