@@ -161,6 +161,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 
 	__shared__ unsigned s_tile;
 	__shared__ TSum s_part[ROWS][SCAN_WAVES];
+	__shared__ TSum s_off[ROWS][SCAN_WAVES];
 	__shared__ TSum s_excl;
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -206,20 +207,20 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	}
 	__syncthreads();
 
-	// ---- offsets of (row, wave) pieces inside the tile; tile aggregate ----
-	TSum run = 0;
-	#pragma unroll
-	for (int r = 0; r < ROWS; ++r) {
-		TSum mine = 0;
-		#pragma unroll
-		for (int w = 0; w < SCAN_WAVES; ++w) {
-			const TSum t = s_part[r][w];
-			if ((unsigned) w == wave) mine = run;
-			run += t;
-		}
-		lane_excl[r] += mine;
+	// ---- offsets of the (row, wave) pieces inside the tile; tile aggregate:
+	// one wave-wide scan of the ROWS * SCAN_WAVES piece totals (row-major =
+	// element order) by wave 0, which needs the aggregate for the look-back
+	// anyway; the other waves pick their offsets up after the look-back barrier.
+	// (Every thread summing the pieces itself kept 64 more values live: 171
+	// VGPRs, two work-groups per CU; now 108, four.) ----
+	static_assert(ROWS * SCAN_WAVES <= 64, "one lane per piece");
+	TSum aggregate = 0;
+	if (wave == 0) {
+		const TSum piece = lane < (unsigned) (ROWS * SCAN_WAVES) ? (&s_part[0][0])[lane] : (TSum) 0;
+		const TSum incl = clo_wave_scan_inclusive<TSum>(piece, lane);
+		if (lane < (unsigned) (ROWS * SCAN_WAVES)) (&s_off[0][0])[lane] = incl - piece;
+		aggregate = __shfl(incl, 63, 64);
 	}
-	const TSum aggregate = run;
 
 	// ---- prefix of the tile (wave 0): two-level decoupled look-back ----
 	if (wave == 0) {
@@ -261,6 +262,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	}
 	__syncthreads();
 	const TSum tile_excl = s_excl + carry;
+	#pragma unroll
+	for (int r = 0; r < ROWS; ++r) lane_excl[r] += s_off[r][wave];
 
 	// ---- store: exclusive value of element c = offset + inclusive(c-1) ----
 	if (full) {

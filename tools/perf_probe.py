@@ -76,10 +76,15 @@ def probe_scan(ctx, q, logn, st="uint"):
     q.finish()
     ms = timed(lambda: sc.with_device_data(q, src, dst, n), q, reps=10)
     best = min(ms)
-    print("scan uint->%s 2^%d: %.4f ms (%s) -> %.0f MValues/s, %.2f TB/s"
-          % (st, logn, best, ["%.4f" % x for x in ms[:5]], n / best / 1e3, n * (4 + sdt.itemsize) / (best * 1e-3) / 1e12), flush=True)
+    lib.clo_hip_timing_enable(1)
+    lib.clo_hip_timing_reset()
+    timed(lambda: sc.with_device_data(q, src, dst, n), q, reps=10)
+    kc, kt = _hip.timing_read("scan")
+    lib.clo_hip_timing_enable(0)
+    print("scan uint->%s 2^%d: %.4f ms (%s) -> %.0f MValues/s, %.2f TB/s; kernel alone %.4f ms"
+          % (st, logn, best, ["%.4f" % x for x in ms[:5]], n / best / 1e3, n * (4 + sdt.itemsize) / (best * 1e-3) / 1e12, kt / max(kc, 1)), flush=True)
     got = dst.read(q, sdt, n)
-    exp = np.concatenate(([0], np.cumsum(a.astype(np.uint64))[:-1])).astype(sdt)
+    exp = np.concatenate((np.zeros(1, np.uint64), np.cumsum(a.astype(np.uint64))[:-1])).astype(sdt)
     print("   correct:", bool(np.array_equal(got, exp)))
     for b in (src, dst):
         b.close()
