@@ -490,7 +490,7 @@ size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
 		return f == "radix_hist" ? clo_radixw_lds_bytes(bits) : clo_radix4_pair_lds_bytes(elem_size, bits);
 	}
 	if (f == "gselect") return GSEL_STAGE * sizeof(unsigned long long);
-	if (f == "scan") return ((param > 4 ? 8 : 16) * 4 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;
+	if (f == "scan") return (2 * (param > 4 ? 8 : 16) * 16 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;   // 1024-thread shape
 	return 0;  // bitonic_strided, bitonic_step: registers only
 }
 

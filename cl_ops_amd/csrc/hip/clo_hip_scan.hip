@@ -27,9 +27,7 @@
 
 namespace {
 
-constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_VEC = 4;
-constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 
 // 4 consecutive elements as one aligned vector access where possible.
 template <typename T>
@@ -149,12 +147,13 @@ __device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsi
 // TIn/TOut: memory types; TSum: 32- or 64-bit accumulator (sums narrower than
 // 32 bits are computed mod 2^32 and truncated on store, which is the same
 // residue).
-template <typename TIn, typename TOut, typename TSum, int ROWS>
+template <typename TIn, typename TOut, typename TSum, int ROWS, int SCAN_THREADS>
 __global__ __launch_bounds__(SCAN_THREADS)
 void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n,
 	unsigned* hdr, clo_u64* state, clo_u64* sstate, clo_u64* sagg, clo_u64* sacc, int aligned, unsigned xflags,
 	const clo_u64* __restrict__ carry_in, clo_u64* __restrict__ carry_out, unsigned last_tile) {
 
+	constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 	constexpr int ROW_ELEMS = SCAN_THREADS * SCAN_VEC;
 	constexpr int TILE = ROW_ELEMS * ROWS;
 	constexpr int NG = sizeof(TSum) > 4 ? 2 : 1;
@@ -166,7 +165,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-	if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
+	if (tid == 0) s_tile = (xflags & 2u) ? blockIdx.x : atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
 	// value carried into this call (a chunk of a longer array): added to every output
 	const TSum carry = carry_in ? (TSum) *carry_in : (TSum) 0;
 	__syncthreads();
@@ -213,12 +212,24 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	// anyway; the other waves pick their offsets up after the look-back barrier.
 	// (Every thread summing the pieces itself kept 64 more values live: 171
 	// VGPRs, two work-groups per CU; now 108, four.) ----
-	static_assert(ROWS * SCAN_WAVES <= 64, "one lane per piece");
+	constexpr int PIECES = ROWS * SCAN_WAVES;
+	constexpr int PPL = (PIECES + 63) / 64;   // pieces per lane of wave 0
+	static_assert(PIECES % PPL == 0, "whole pieces per lane");
 	TSum aggregate = 0;
 	if (wave == 0) {
-		const TSum piece = lane < (unsigned) (ROWS * SCAN_WAVES) ? (&s_part[0][0])[lane] : (TSum) 0;
-		const TSum incl = clo_wave_scan_inclusive<TSum>(piece, lane);
-		if (lane < (unsigned) (ROWS * SCAN_WAVES)) (&s_off[0][0])[lane] = incl - piece;
+		TSum piece[PPL], mine = 0;
+		#pragma unroll
+		for (int k = 0; k < PPL; ++k) {
+			piece[k] = lane * PPL + k < (unsigned) PIECES ? (&s_part[0][0])[lane * PPL + k] : (TSum) 0;
+			mine += piece[k];
+		}
+		const TSum incl = clo_wave_scan_inclusive<TSum>(mine, lane);
+		TSum run = incl - mine;
+		#pragma unroll
+		for (int k = 0; k < PPL; ++k) {
+			if (lane * PPL + k < (unsigned) PIECES) (&s_off[0][0])[lane * PPL + k] = run;
+			run += piece[k];
+		}
 		aggregate = __shfl(incl, 63, 64);
 	}
 
@@ -288,8 +299,17 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 
 unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never set in production
 
-constexpr size_t scan_tile_elems(int sum_size) {
-	return (size_t) SCAN_THREADS * SCAN_VEC * (sum_size > 4 ? 8 : 16);
+// Work-group shape by array size. Every work-group draws a ticket from one
+// counter (HIP promises no dispatch order, so tile ids cannot come from
+// blockIdx: a tile may only wait for tiles already handed out), and same-address
+// atomics complete one per ~12 ns: with 256-thread groups a 2^26 scan spends 49
+// us of its 120 in that queue. Large arrays therefore use 1024-thread groups —
+// four times fewer tickets and look-back entries (2^26 uint -> ulong: 0.207 ->
+// 0.182 ms) — and small ones 256-thread groups, which spread over more CUs.
+constexpr size_t SCAN_BIG_NUMEL = (size_t) 1 << 24;
+constexpr int scan_threads(size_t numel) { return numel >= SCAN_BIG_NUMEL ? 1024 : 256; }
+constexpr size_t scan_tile_elems(size_t numel, int sum_size) {
+	return (size_t) scan_threads(numel) * SCAN_VEC * (sum_size > 4 ? 8 : 16);
 }
 
 template <typename TIn, typename TOut>
@@ -299,7 +319,7 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 	} else {
 		typedef typename std::conditional<(sizeof(TOut) > 4), uint64_t, uint32_t>::type TSum;
 		constexpr int ROWS = sizeof(TOut) > 4 ? 8 : 16;
-		const size_t tile = scan_tile_elems((int) sizeof(TOut));
+		const size_t tile = scan_tile_elems(n, (int) sizeof(TOut));
 		const size_t tiles = (n + tile - 1) / tile;
 		unsigned* hdr = (unsigned*) ws;
 		clo_u64* state = (clo_u64*) ((char*) ws + CLO_WS_HEADER_BYTES);
@@ -311,9 +331,14 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16 + supers * 48, s);
 		if (e != hipSuccess) return (int) e;
 		clo_timing_scope timing("scan", s);
-		hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS>), dim3((unsigned) tiles), dim3(SCAN_THREADS), 0, s,
-			(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
-			carry_in, carry_out, (unsigned) (tiles - 1));
+		if (scan_threads(n) == 1024)
+			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS, 1024>), dim3((unsigned) tiles), dim3(1024), 0, s,
+				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
+				carry_in, carry_out, (unsigned) (tiles - 1));
+		else
+			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS, 256>), dim3((unsigned) tiles), dim3(256), 0, s,
+				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
+				carry_in, carry_out, (unsigned) (tiles - 1));
 		return (int) hipGetLastError();
 	}
 }
@@ -372,7 +397,8 @@ extern "C" {
 
 size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
 	(void) elem_size;
-	const size_t tile = scan_tile_elems(sum_size);
+	// sized for the small work-group shape, so that the size grows with numel
+	const size_t tile = scan_tile_elems(0, sum_size);
 	const size_t tiles = (numel + tile - 1) / tile;
 	const size_t t = tiles ? tiles : 1;
 	return CLO_WS_HEADER_BYTES + t * 16 + ((t >> SCAN_SUPER_LOG) + 1) * 48;
@@ -396,7 +422,7 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
 		g_scan_xflags = x ? (unsigned) atoi(x) : 0u;
 	}
 	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
-	if (numel / scan_tile_elems(sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
+	if (numel / scan_tile_elems(numel, sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
 	const clo_u64* ci = (const clo_u64*) carry_in_dev;
 	clo_u64* co = (clo_u64*) carry_out_dev;
 	// The sum type only matters by width: two's complement addition is the
