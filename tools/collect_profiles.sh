@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): bench lines, rocprofv3 kernel stats and the two
+# PMC passes for the HBM traffic of the headline workload. Raw output goes to
+# gpurun_out/$TAG/; tools/summarize_profiles.py turns it into the files under profiles/.
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r01'
+set -o pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic sbitonic; do
+	python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
+	echo "bench $w done"
+done
+for w in satradix_u32 satradix_pairs scan abitonic; do
+	rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" --output-format csv -- \
+		python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_$w.json" 2> "$OUT/trace_$w.log" || exit 1
+	echo "trace $w done"
+done
+# HBM traffic of the headline workload: one counter per run, kernel trace only
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" --output-format csv -- \
+	python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/fetch.json" 2> "$OUT/fetch.log" || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" --output-format csv -- \
+	python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/write.json" 2> "$OUT/write.log" || exit 1
+echo "pmc done"

@@ -1,0 +1,73 @@
+"""Turns gpurun_out/<tag>/ (made by tools/collect_profiles.sh on the GPU box) into the
+tracked files under profiles/: bench JSON lines, rocprofv3 kernel stats, and the
+PMC-derived HBM traffic per launch of the headline kernel (FETCH_SIZE x2 per the
+gfx950 note in MI355X_MICROARCH.md, calibrated on the histogram kernel of the same run).
+usage: python tools/summarize_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+
+for f in glob.glob(os.path.join(src, "bench_*.json")):
+    line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
+    open(os.path.join(dst, "%s_%s" % (tag, os.path.basename(f))), "w").write(line + "\n")
+
+names = {"satradix_u32": "satradix_u32_2p28", "satradix_pairs": "satradix_pairs", "scan": "scan", "abitonic": "abitonic"}
+for w, out in names.items():
+    st = glob.glob(os.path.join(src, "trace_" + w, "*", "*kernel_stats.csv"))
+    if st:
+        shutil.copy(max(st, key=os.path.getmtime), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, out)))
+
+
+def pmc(kind):
+    f = max(glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
+
+
+fetch, write = pmc("fetch"), pmc("write")
+
+
+def short(k):
+    k = k.replace("void ", "").replace("(anonymous namespace)::", "")
+    return k.split("(")[0].strip()
+
+
+rows = []
+for k in fetch:
+    n, f = fetch[k]
+    w = write.get(k, (0, 0.0))[1]
+    rows.append((short(k), n, f, w, int((2 * f + w) * 1024)))
+rows.sort(key=lambda r: -r[4] * r[1])
+hist = [r for r in rows if "tilehist" in r[0] and "unsigned int" in r[0]]
+pas = [r for r in rows if "pass_pc" in r[0] and "unsigned int" in r[0]]
+n_keys = 1 << 28
+calib = (n_keys * 4 / 1024) / hist[0][2] if hist else float("nan")
+path = os.path.join(dst, "%s_satradix_u32_2p28_pmc_hbm_traffic.csv" % tag)
+with open(path, "w") as o:
+    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs, each with --kernel-trace only) of\n")
+    o.write("#   python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (satradix, 2^28 uint32 keys, radix 16), MI355X\n")
+    o.write("# Counter unit: KB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests as 64 B, i.e.\n")
+    o.write("# reports 1/2 of a coalesced streaming read. Calibration in this very run: the histogram kernel reads exactly\n")
+    o.write("# 2^28*4 B = 1048576 KB and reports %.0f KB -> factor %.3f (2.0 used). WRITE_SIZE is taken as is.\n" % (hist[0][2] if hist else 0, calib))
+    o.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+    for r in rows:
+        o.write("%s,%d,%.0f,%.0f,%d\n" % r)
+if pas:
+    json.dump({"kernel": pas[0][0], "hbm_bytes_per_launch": pas[0][4], "fetch_size_kb": pas[0][2], "write_size_kb": pas[0][3],
+               "correction": "FETCH_SIZE x2 (gfx950; calibrated on the histogram kernel in the same run: factor %.3f), WRITE_SIZE as is" % calib,
+               "source": "profiles/" + os.path.basename(path)},
+              open(os.path.join(dst, "traffic_satradix_u32.json"), "w"), indent=1)
+print("profiles/ refreshed from", src)
+for r in rows[:6]:
+    print(r)
