@@ -570,6 +570,48 @@ def test_full_size_abitonic_2p26(gpu):
     assert bool(np.all(got[:-1] <= got[1:])) and _xor_sum(got) == _xor_sum(a)
 
 
+def test_indices_above_2p31_satradix_and_scan(gpu):
+    """3*2^30 + 5 elements: global indices use bit 31 (positions are 32-bit, as
+    upstream's uint gid; numel < 2^32). Inputs are generated and the results
+    checked on the device (torch) so that the host never holds the 12 GiB."""
+    import torch
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    if torch.cuda.get_device_properties(0).total_memory < (96 << 30):
+        pytest.skip("needs ~60 GiB of device memory")
+    n = 3 * (1 << 30) + 5
+    g = torch.Generator(device="cuda").manual_seed(31)
+    a = torch.randint(-(1 << 31), 1 << 31, (n,), dtype=torch.int32, device="cuda", generator=g)
+    sum_in = int(a.sum(dtype=torch.int64))
+    sq_in = int((a.to(torch.int64) * 0x9E3779B1).bitwise_and(0xFFFFFFFF).sum())
+    torch.cuda.synchronize()
+    buf = clo.Buffer(ctx, n * 4, device_ptr=a.data_ptr())
+    s = clo.Sorter("satradix", ctx, "uint")
+    s.with_device_data(q, buf, None, n)
+    q.finish()
+    b = a ^ (-(1 << 31))                         # unsigned order as signed order
+    assert bool((b[1:] >= b[:-1]).all())
+    del b
+    assert int(a.sum(dtype=torch.int64)) == sum_in
+    assert int((a.to(torch.int64) * 0x9E3779B1).bitwise_and(0xFFFFFFFF).sum()) == sq_in
+    s.close()
+    # scan of ones-and-twos into uint sums: out[i] = (sum of a[:i]) mod 2^32
+    a.copy_((a & 1) + 1)
+    out = torch.empty_like(a)
+    torch.cuda.synchronize()
+    bout = clo.Buffer(ctx, n * 4, device_ptr=out.data_ptr())
+    sc = clo.Scanner("blelloch", ctx, "uint", "uint")
+    sc.with_device_data(q, buf, bout, n)
+    q.finish()
+    assert int(out[0]) == 0
+    d = out[1:] - out[:-1]                       # wraps like the sum type
+    assert bool((d == a[:-1]).all())
+    assert (int(out[-1]) + int(a[-1])) % (1 << 32) == int(a.sum(dtype=torch.int64)) % (1 << 32)
+    sc.close()
+    for x in (buf, bout):
+        x.close()
+
+
 # ----------------------------------------------------------------------------
 # two ranks sharing the one GPU of this box: HipLocalOps end to end. RCCL
 # refuses two ranks on one device, so this test (and only this test) stages the
