@@ -446,10 +446,16 @@ cl_bool ccl_prof_calc(CCLProf* prof, GError** err) {
 		}
 		if (!cq->events) continue;
 		if (hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize")) return CL_FALSE;
-		float ms = 0.f;
-		if (hip_failed(clo_hip_event_elapsed_ms(cq->first->start, cq->events->end, &ms), err, "hipEventElapsedTime"))
-			return CL_FALSE;
-		prof->duration_ns += (cl_ulong) ((double) ms * 1e6);
+		/* Sum of the commands' own durations: on an in-order queue that is the
+		 * time the device spent on them, idle gaps between commands (a chunked
+		 * pipeline waiting for its next copy) excluded — cf4ocl2's aggregate
+		 * event time. */
+		for (struct ccl_event* e = cq->events; e != NULL; e = e->next) {
+			float ms = 0.f;
+			if (!e->start) continue;
+			if (hip_failed(clo_hip_event_elapsed_ms(e->start, e->end, &ms), err, "hipEventElapsedTime")) return CL_FALSE;
+			prof->duration_ns += (cl_ulong) ((double) ms * 1e6);
+		}
 		/* cf4ocl2 releases the queue's events once profiled. */
 		ccl_queue_gc(cq);
 	}

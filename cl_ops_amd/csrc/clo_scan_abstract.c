@@ -241,7 +241,7 @@ static cl_bool scan_with_host_data_pipelined(CloScan* scanner, CCLQueue* cq_exec
 		if (st == 0) st = clo_hip_event_record(r->in_done[slot], s_in);
 		if (st == 0) st = clo_hip_stream_wait_event(s_exec, r->in_done[slot]);
 		if (st != 0) goto finish;
-		if (!scanner->impl_def.scan_chunk(scanner, s_exec, r->in_dev[slot], r->out_dev[slot], cnt,
+		if (!scanner->impl_def.scan_chunk(scanner, cq_exec, r->in_dev[slot], r->out_dev[slot], cnt,
 			(char*) r->carry + slot * sizeof(uint64_t), (char*) r->carry + (slot ^ 1) * sizeof(uint64_t), err)) goto finish;
 		what = "hipEventRecord";
 		st = clo_hip_event_record(r->scan_done[slot], s_exec);

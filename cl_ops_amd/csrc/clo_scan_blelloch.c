@@ -63,9 +63,10 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 }
 
 /* One chunk of a longer scan, on raw device pointers (clo_scan.h: scan_chunk). */
-static cl_bool clo_scan_blelloch_scan_chunk(CloScan* scanner, void* stream, const void* in_dev, void* out_dev,
+static cl_bool clo_scan_blelloch_scan_chunk(CloScan* scanner, CCLQueue* cq_exec, const void* in_dev, void* out_dev,
 	size_t numel, const void* carry_in_dev, void* carry_out_dev, GError** err) {
 	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scanner);
+	void* stream = ccl_queue_get_stream(cq_exec);
 	const int es = (int) clo_scan_get_element_size(scanner);
 	const int ss = (int) clo_scan_get_sum_size(scanner);
 	if (data->last_stream && data->last_stream != stream)
@@ -73,10 +74,13 @@ static cl_bool clo_scan_blelloch_scan_chunk(CloScan* scanner, void* stream, cons
 	data->last_stream = stream;
 	if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, clo_hip_scan_workspace_bytes(numel, es, ss)), err,
 		"hipMalloc(scan workspace)")) return CL_FALSE;
+	CCLEvent* evt = ccl_queue_begin_command(cq_exec, "clo_scan_blelloch_wgscan", err);
+	if (!evt) return CL_FALSE;
 	int st = clo_hip_scan_exclusive_carry(in_dev, out_dev, numel, es,
 		clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 		(const uint64_t*) carry_in_dev, (uint64_t*) carry_out_dev, data->workspace.ptr, data->workspace.bytes, stream);
-	return clo_hip_failed(st, err, "clo_hip_scan_exclusive_carry") ? CL_FALSE : CL_TRUE;
+	if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_carry")) return CL_FALSE;
+	return ccl_queue_end_command(cq_exec, evt, err) ? CL_TRUE : CL_FALSE;
 }
 
 /* ref: clo_scan_blelloch.c:219-249 — options must be empty. */
