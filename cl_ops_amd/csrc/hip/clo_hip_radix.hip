@@ -19,6 +19,8 @@
 // (stable ascending by key), for any digit width.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
 
@@ -74,8 +76,9 @@ int clo_hip_radix_set_debug_buffer(void* dptr) {
 
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits) {
 	if (digit_bits < 1 || digit_bits > 8 || key_bits < 1) return 0;
-	return digit_bits <= 4 ? clo_radix4_workspace_bytes(numel, elem_size, key_bits, digit_bits)
-	                       : clo_radix4_pair_workspace_bytes(numel, elem_size, digit_bits);
+	const size_t a = digit_bits <= 4 ? clo_radix4_workspace_bytes(numel, elem_size, key_bits, digit_bits) : 0;
+	const size_t b = clo_radix4_pair_workspace_bytes(numel, elem_size, digit_bits);
+	return a > b ? a : b;
 }
 
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
@@ -92,7 +95,8 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	if (workspace_bytes < clo_hip_radix_workspace_bytes(numel, elem_size, key_bits, digit_bits)) return CLO_HIP_EWORKSPACE;
 	hipStream_t s = (hipStream_t) stream;
 	const clo_keyx kx = clo_keyx_make(key_kind, key_shift, key_bits);
-	if (digit_bits <= 4)
+	const char* pairs = getenv("CLO_RADIX_PAIRS");   // developer A/B switch
+	if (digit_bits <= 4 && (numel <= 4096 || (pairs && pairs[0] == '0')))
 		return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
 	return clo_radix4_pair_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
 }

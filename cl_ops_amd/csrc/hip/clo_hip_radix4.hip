@@ -310,8 +310,15 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 	__shared__ unsigned s_dstart16[NW];               // tile-local digit starts, packed like the counters
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const unsigned tile = blockIdx.x;
+	// Work-groups are dealt round-robin over the 8 XCDs (observed, not promised —
+	// used for speed only: any mapping is correct, tiles are independent). Giving
+	// each residue class of blockIdx a contiguous range of tiles puts neighbouring
+	// tiles, whose digit runs share their boundary cache lines in the output,
+	// behind the same L2.
+	const unsigned per_xcd = (unsigned) ((n + (size_t) TILE * 8 - 1) / ((size_t) TILE * 8));
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	const size_t base = (size_t) tile * TILE;
+	if (base >= n) return;
 	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
 	const bool full = count == (unsigned) TILE;
 	const unsigned tbase = tid * ITEMS;
@@ -598,8 +605,11 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	__shared__ unsigned s_w4[4];
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const unsigned tile = blockIdx.x;
+	// neighbouring tiles behind the same L2 (see clo_radix4_pass_pc_kernel)
+	const unsigned per_xcd = (unsigned) ((n + (size_t) TILE * 8 - 1) / ((size_t) TILE * 8));
+	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
 	const size_t base = (size_t) tile * TILE;
+	if (base >= n) return;
 	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
 	const bool full = count == (unsigned) TILE;
 	const unsigned tbase = tid * ITEMS;
@@ -838,7 +848,7 @@ int r4_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		}
 		{
 			clo_timing_scope timing("radix_pass", s);
-			hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+			hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3((tiles + 7u) / 8u * 8u), dim3(R4_THREADS), 0, s,
 				cur_in, cur_out, n, (unsigned) (key_shift + p * BITS), (1u << bits) - 1u,
 				has_next, (unsigned) (key_shift + (p + 1) * BITS), (1u << nbits) - 1u,
 				(const unsigned*) th, (const unsigned*) toff, th + per_pass,
@@ -899,7 +909,7 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 			(const unsigned*) thist, tiles, partial);
 	hipLaunchKernelGGL((clo_radix4_offsets_kernel<R>), dim3(chunks), dim3(OFF_CHUNK), 0, s,
 		(const unsigned*) thist, tiles, (const unsigned*) partial, chunks, toff);
-	hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3(tiles), dim3(R4_THREADS), 0, s,
+	hipLaunchKernelGGL((clo_radix4_pass_pc_kernel<E, BITS, LT>), dim3((tiles + 7u) / 8u * 8u), dim3(R4_THREADS), 0, s,
 		src, dst, n, shift, R - 1u, 0, 0u, 0u, (const unsigned*) thist, (const unsigned*) toff,
 		thist + (L.tiles + 1) * R, (int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, (unsigned long long*) nullptr);
 	return (int) hipGetLastError();
@@ -962,7 +972,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		}
 		{
 			clo_timing_scope timing("radix_pass", s);
-			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s,
+			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E>::THREADS), 0, s,
 				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
 				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
 		}
@@ -982,6 +992,10 @@ int rp_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, 
 	clo_keyx kx, void* ws, hipStream_t s) {
 	#define CLO_RP(LB, HB) return rp_sort_impl<E, LB, HB>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s)
 	switch (digit_bits) {
+		case 1: CLO_RP(1, 1);
+		case 2: CLO_RP(2, 2);
+		case 3: CLO_RP(3, 3);
+		case 4: CLO_RP(4, 4);
 		case 5: CLO_RP(3, 2);
 		case 6: CLO_RP(3, 3);
 		case 7: CLO_RP(4, 3);
@@ -1041,7 +1055,7 @@ size_t clo_radix4_lds_bytes(const char* kernel, int elem_size, int digit_bits) {
 }
 
 size_t clo_radix4_pair_workspace_bytes(size_t n, int elem_size, int digit_bits) {
-	return rp_make_layout(n, elem_size, digit_bits).total;
+	return rp_make_layout(n, elem_size, digit_bits <= 4 ? 2 * digit_bits : digit_bits).total;
 }
 
 size_t clo_radix4_pair_lds_bytes(int elem_size, int digit_bits) {
