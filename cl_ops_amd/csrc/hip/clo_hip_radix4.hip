@@ -19,6 +19,7 @@
 // HBM traffic per element and digit: one read + one write (upstream: ~5 element
 // streams + 6 counter streams).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
@@ -518,7 +519,6 @@ void clo_radix4_pass_pc_kernel(const E* __restrict__ in, E* __restrict__ out, si
 template <typename E, int BITS, int THREADS, int ITEMS, int HMAX>
 __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
 	E* s_stage, unsigned (*s_end)[THREADS], unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], unsigned* s_dstart16) {
-	constexpr int R = 1 << BITS;
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
 	constexpr int TILE = THREADS * ITEMS;
@@ -544,23 +544,43 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		for (int j = 0; j < H; ++j) s_wtot[wave][j] = w[j];
 	}
 	__syncthreads();
-	if (tid < 64) {
-		// digit totals -> tile-local digit starts (exclusive scan over the digits)
-		unsigned h = 0;
-		if (tid < (unsigned) R) {
-			#pragma unroll
-			for (int wv = 0; wv < WAVES; ++wv) h += (s_wtot[wv][tid >> 1] >> ((tid & 1u) * 16u)) & 0xffffu;
+	if (wave == 0) {
+		// Wave 0 turns the wave totals into every wave's base, per digit: lane
+		// (q, wv) = (lane / 16, lane % 16) takes word 4r + q of wave wv; a DPP scan
+		// inside rows of 16 lanes runs over the waves, lane 15 of a row ends up with
+		// the digit totals of its word, and a 16-step serial prefix over those
+		// (wave-uniform values) gives the digit starts. One barrier later every
+		// thread has its bases.
+		static_assert(WAVES <= 16, "one row of 16 lanes spans the waves");
+		constexpr int ROUNDS = (H + 3) / 4;
+		const unsigned wv = lane & 15u, q = lane >> 4;
+		unsigned excl[ROUNDS], tot[ROUNDS];
+		#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+			const unsigned j = r * 4 + q;
+			const unsigned x = (j < (unsigned) H && wv < (unsigned) WAVES) ? s_wtot[wv][j] : 0u;
+			unsigned incl = dpp_add<0x111, 0xF>(x);
+			incl = dpp_add<0x112, 0xF>(incl);
+			incl = dpp_add<0x114, 0xF>(incl);
+			incl = dpp_add<0x118, 0xF>(incl);
+			excl[r] = incl - x;
+			tot[r] = incl;
 		}
-		const unsigned dstart = clo_wave_scan_inclusive<unsigned>(h, lane) - h;
-		const unsigned odd = (unsigned) __shfl((int) dstart, (int) (lane | 1u), 64);
-		if (tid < (unsigned) R && (tid & 1u) == 0) s_dstart16[tid >> 1] = dstart | ((R > 1 ? odd : 0u) << 16);
-	}
-	__syncthreads();
-	if (tid < WAVES * H) {
-		const unsigned wv = tid / H, j = tid % H;
-		unsigned run = s_dstart16[j];
-		for (unsigned k = 0; k < wv; ++k) run += s_wtot[k][j];
-		s_wbase[wv][j] = run;
+		unsigned run = 0, dstart16[H];
+		#pragma unroll
+		for (int j = 0; j < H; ++j) {
+			const unsigned t = (unsigned) __shfl((int) tot[j / 4], (j % 4) * 16 + 15, 64);   // packed totals of digits 2j, 2j+1
+			dstart16[j] = run | ((run + (t & 0xffffu)) << 16);
+			run += (t & 0xffffu) + (t >> 16);
+		}
+		#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+			unsigned mine = dstart16[r * 4];
+			#pragma unroll
+			for (int k = 1; k < 4; ++k) if (r * 4 + k < H && q == (unsigned) k) mine = dstart16[r * 4 + k];
+			const unsigned j = r * 4 + q;
+			if (j < (unsigned) H && wv < (unsigned) WAVES) s_wbase[wv][j] = mine + excl[r];
+		}
 	}
 	__syncthreads();
 	#pragma unroll
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(pair_shape<E>::THREADS)
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
-	clo_keyx kx_in, clo_keyx kx_out) {
+	clo_keyx kx_in, clo_keyx kx_out, unsigned xf) {
 
 	constexpr int THREADS = pair_shape<E>::THREADS;
 	constexpr int ITEMS = pair_shape<E>::ITEMS;
@@ -637,7 +657,8 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
 	if (lane == 63 && wave < 4) s_w4[wave] = incl2;
 
-	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase, s_dstart16);
+	if (!(xf & 4u)) pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase, s_dstart16);
+	else { for (int i = 0; i < ITEMS; ++i) s_stage[tbase + i] = key[i]; __syncthreads(); }
 
 	if (tid < (unsigned) R2) {
 		unsigned dstart2 = incl2 - h2;
@@ -645,9 +666,20 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		for (unsigned w = 0; w < 4; ++w) if (w < wave) dstart2 += s_w4[w];
 		s_delta[tid] = goff - dstart2;
 	}
-	if (mask_hi != 0) {
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) if (full || tbase + i < count) key[i] = s_stage[tbase + i];
+	if (mask_hi != 0 && !(xf & 1u)) {
+		if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)
+			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
+			typedef E vec16 __attribute__((ext_vector_type(PER)));
+			#pragma unroll
+			for (int k = 0; k < ITEMS / PER; ++k) {
+				const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) key[k * PER + q] = t[q];
+			}
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
+		}
 		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase, s_dstart16);
 	} else {
 		__syncthreads();
@@ -664,8 +696,8 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		if (full) {
 			const vecE v = *reinterpret_cast<const vecE*>(&s_stage[p]);
 			const unsigned d0 = (unsigned) (v[0] >> shift) & mask2, dl = (unsigned) (v[VEC - 1] >> shift) & mask2;
-			const unsigned gi0 = p + s_delta[d0];
-			if (d0 == dl && gi0 <= n32 - VEC) {
+			const unsigned gi0 = (xf & 2u) ? (unsigned) base + p : p + s_delta[d0];
+			if (((xf & 2u) || d0 == dl) && gi0 <= n32 - VEC) {
 				vecE vo = v;
 				if (kx_out.kind) {
 					#pragma unroll
@@ -974,7 +1006,8 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			clo_timing_scope timing("radix_pass", s);
 			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E>::THREADS), 0, s,
 				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
-				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
+				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none,
+				(unsigned) (getenv("CLO_RP_XF") ? atoi(getenv("CLO_RP_XF")) : 0));
 		}
 		cur_in = cur_out;
 	}

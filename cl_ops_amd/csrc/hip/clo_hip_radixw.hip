@@ -38,9 +38,9 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	constexpr int R = 1 << BITS;
 	constexpr int ITEMS = rw_shape<E>::ITEMS;
 	constexpr int TILE = rw_shape<E>::TILE;
-	constexpr int VECS = ITEMS * (int) sizeof(E) / 16;   // 16-byte loads per thread
-	constexpr int PER = 16 / (int) sizeof(E);
-	static_assert(VECS >= 1, "a thread's slice is at least one 16-byte vector");
+	constexpr int VB = ITEMS * (int) sizeof(E) >= 16 ? 16 : ITEMS * (int) sizeof(E);   // bytes per vector load
+	constexpr int VECS = ITEMS * (int) sizeof(E) / VB;
+	constexpr int PER = VB / (int) sizeof(E);
 	__shared__ unsigned s_cnt[RW_WAVES][R];
 	const unsigned tid = threadIdx.x, wave = tid >> 6;
 	const size_t base = (size_t) blockIdx.x * TILE;
@@ -49,7 +49,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	__syncthreads();
 	const unsigned tbase = tid * ITEMS;
 	if (count == (unsigned) TILE && aligned) {
-		typedef E vecE __attribute__((ext_vector_type(PER)));
+		typedef E vecE __attribute__((ext_vector_type(PER)));   // (`aligned`: the source is 16-byte aligned)
 		const vecE* p = reinterpret_cast<const vecE*>(in + base + tbase);
 		vecE v[VECS];
 		#pragma unroll
