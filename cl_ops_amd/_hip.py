@@ -75,7 +75,6 @@ _sig("clo_hip_check_status", ci, vp, vp)
 _sig("clo_hip_timing_enable", ci, ci)
 _sig("clo_hip_timing_reset", ci)
 _sig("clo_hip_timing_read", ci, C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float))
-_sig("clo_hip_radix_set_debug_buffer", ci, vp)
 
 
 class HipError(RuntimeError):

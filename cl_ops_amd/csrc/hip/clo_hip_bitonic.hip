@@ -486,8 +486,7 @@ size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
 	}
 	if (f == "radix_hist" || f == "radix_pass") {
 		const int bits = param < 1 ? 1 : (param > 8 ? 8 : param);
-		if (bits <= 4) return clo_radix4_lds_bytes(f == "radix_hist" ? "hist" : "pass", elem_size, bits);
-		return f == "radix_hist" ? clo_radixw_lds_bytes(bits) : clo_radix4_pair_lds_bytes(elem_size, bits);
+		return f == "radix_hist" ? clo_radixw_lds_bytes(bits <= 4 ? 2 * bits : bits) : clo_radix4_lds_bytes(elem_size, bits);
 	}
 	if (f == "gselect") return GSEL_STAGE * sizeof(unsigned long long);
 	if (f == "scan") return (2 * (param > 4 ? 8 : 16) * 16 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;   // 1024-thread shape

@@ -59,22 +59,16 @@ inline clo_keyx clo_keyx_make(int kind, int key_shift, int key_bits) {
 	return k;
 }
 
-// Chain-free radix path for digits of <= 4 bits (clo_hip_radix4.hip).
-size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int key_bits, int digit_bits);
+// Radix passes (clo_hip_radix4.hip) and their histogram / counter-scan steps
+// (clo_hip_radixw.hip).
+size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int digit_bits);
 size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits);
 int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
 	unsigned long long* counts, void* ws, hipStream_t s);
-void clo_radix4_set_debug_buffer(void* p);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
 	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
-
-// Histogram / counter-scan steps for digits of 5..8 bits (clo_hip_radixw.hip).
+size_t clo_radix4_lds_bytes(int elem_size, int digit_bits);
 size_t clo_radixw_lds_bytes(int digit_bits);
-size_t clo_radix4_pair_lds_bytes(int elem_size, int digit_bits);
-size_t clo_radix4_lds_bytes(const char* kernel, int elem_size, int digit_bits);
-size_t clo_radix4_pair_workspace_bytes(size_t n, int elem_size, int digit_bits);
-int clo_radix4_pair_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
-	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
 size_t clo_radixw_tile_elems(int elem_size);
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
 	unsigned* thist, unsigned tiles, clo_keyx kx, hipStream_t s);

@@ -7,19 +7,15 @@
 // num_wgs*radix counters, satradix_scatter (sort/clo_sort_satradix.cl:34-258) —
 // about 5 element streams plus 6 counter streams through HBM per digit.
 //
-// Here a digit pass keeps that decomposition (per-tile histogram -> counters
-// scan -> stable tile sort + scatter) but reads every element once and writes
-// it once in ONE kernel, and no kernel waits on another work-group:
-//   * digits of 1..4 bits (radix <= 16, the default): clo_hip_radix4.hip —
-//     packed-counter ranking, next digit's histogram fused into the scatter;
-//   * digits of 5..8 bits (radix 32..256): the digit is split in two halves
-//     that are ranked one after the other inside the work-group
-//     (clo_radix4_pair_kernel), one histogram kernel per digit (clo_hip_radixw.hip).
-// Stability per pass + LSD order give exactly the order the reference produces
-// (stable ascending by key), for any digit width.
+// Here a pass keeps that decomposition (per-tile histogram -> counters scan ->
+// stable tile sort + scatter) but handles two digits of <= 4 bits per trip
+// through HBM (two local splits inside the work-group), reads every element
+// twice and writes it once per pass, and no kernel waits on another
+// work-group: clo_hip_radix4.hip (ranking, pass kernel, small arrays, host
+// side), clo_hip_radixw.hip (histogram and counter scan). Stability per pass +
+// LSD order give exactly the order the reference produces (stable ascending by
+// key), for any digit width.
 #include <hip/hip_runtime.h>
-
-#include <cstdlib>
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
@@ -69,16 +65,9 @@ int msd_hist_impl(const void* src, size_t n, unsigned shift, unsigned mask, uint
 
 extern "C" {
 
-int clo_hip_radix_set_debug_buffer(void* dptr) {
-	clo_radix4_set_debug_buffer(dptr);
-	return 0;
-}
-
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits) {
 	if (digit_bits < 1 || digit_bits > 8 || key_bits < 1) return 0;
-	const size_t a = digit_bits <= 4 ? clo_radix4_workspace_bytes(numel, elem_size, key_bits, digit_bits) : 0;
-	const size_t b = clo_radix4_pair_workspace_bytes(numel, elem_size, digit_bits);
-	return a > b ? a : b;
+	return clo_radix4_workspace_bytes(numel, elem_size, digit_bits);
 }
 
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
@@ -95,10 +84,7 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	if (workspace_bytes < clo_hip_radix_workspace_bytes(numel, elem_size, key_bits, digit_bits)) return CLO_HIP_EWORKSPACE;
 	hipStream_t s = (hipStream_t) stream;
 	const clo_keyx kx = clo_keyx_make(key_kind, key_shift, key_bits);
-	const char* pairs = getenv("CLO_RADIX_PAIRS");   // developer A/B switch
-	if (digit_bits <= 4 && (numel <= 4096 || (pairs && pairs[0] == '0')))
-		return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
-	return clo_radix4_pair_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
+	return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
 }
 
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {

@@ -194,10 +194,6 @@ int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms);
  * "scan", "bitonic_tile", "bitonic_strided", "bitonic_step". */
 size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param);
 
-/* Developer diagnostics: device buffer of 8 uint64 per tile (first 32768 tiles)
- * that receives s_memtime stamps of the pass kernel's phases; NULL disables. */
-int clo_hip_radix_set_debug_buffer(void* dptr);
-
 #ifdef __cplusplus
 }
 #endif
