@@ -79,9 +79,10 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 // counts[tile][digit] -> offsets[tile][digit] in digit-major order:
 //   off[t][d] = sum_{d'<d} total[d'] + sum_{t'<t} cnt[t'][d]
 // (exactly upstream's exclusive scan of counters[num_wgs*d + wg]). A row of R
-// counters is contiguous, thread = digit: every access is coalesced. Two
-// kernels over chunks of RW_CHUNK tiles; G = 256 / R thread groups share a
-// chunk when R < 256.
+// counters is contiguous, thread = digit: every access is coalesced. Three
+// small kernels: sums of chunks of RW_CHUNK tiles, a one-work-group scan of the
+// chunk sums, the walk over each chunk's tiles; G = 256 / R thread groups share
+// the work when R < 256.
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(256)
@@ -104,51 +105,66 @@ void clo_radixw_chunksum_kernel(const unsigned* __restrict__ thist, unsigned til
 	}
 }
 
+// Chunk sums -> for every (chunk, digit) the offset of the chunk's first tile:
+// digit base (exclusive scan of the digit totals over the digits) + count of
+// the digit in earlier chunks. ONE work-group: thread (g, d) walks every G-th
+// chunk serially (a few hundred coalesced loads per thread), the groups are
+// combined through LDS. In place: partial[c][d] becomes that offset.
+template <int R>
+__global__ __launch_bounds__(256)
+void clo_radixw_chunkscan_kernel(unsigned* __restrict__ partial, unsigned chunks) {
+	constexpr int G = 256 / R;
+	__shared__ unsigned s_g[G][R], s_w[4];
+	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
+	// group g owns the contiguous range of chunks [c0, c1)
+	const unsigned per = (chunks + G - 1) / G;
+	const unsigned c0 = g * per < chunks ? g * per : chunks, c1 = c0 + per < chunks ? c0 + per : chunks;
+	unsigned sum = 0;
+	#pragma unroll 8
+	for (unsigned c = c0; c < c1; ++c) sum += partial[(size_t) c * R + d];
+	s_g[g][d] = sum;
+	__syncthreads();
+	unsigned before = 0, tot = 0;
+	#pragma unroll
+	for (int k = 0; k < G; ++k) {
+		const unsigned v = s_g[k][d];
+		if ((unsigned) k < g) before += v;
+		tot += v;
+	}
+	// exclusive scan of the digit totals over the digits (threads 0..R-1 carry them)
+	const unsigned t = tid < (unsigned) R ? tot : 0u;
+	const unsigned incl = clo_wave_scan_inclusive<unsigned>(t, lane);
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	unsigned dbase = incl - t;
+	#pragma unroll
+	for (unsigned w = 0; w < 4; ++w) if (w < wave) dbase += s_w[w];
+	__syncthreads();
+	if (tid < (unsigned) R) s_g[0][tid] = dbase;   // (s_g[0] is free again: every thread has read it)
+	__syncthreads();
+	unsigned run = s_g[0][d] + before;
+	#pragma unroll 8
+	for (unsigned c = c0; c < c1; ++c) {
+		const unsigned v = partial[(size_t) c * R + d];
+		partial[(size_t) c * R + d] = run;
+		run += v;
+	}
+}
+
+// Offsets of the tiles of one chunk: thread (g, d) walks SUB consecutive tiles.
 template <int R>
 __global__ __launch_bounds__(256)
 void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tiles,
-	const unsigned* __restrict__ partial, unsigned chunks, unsigned* __restrict__ toff) {
+	const unsigned* __restrict__ cbase, unsigned* __restrict__ toff) {
 	constexpr int G = 256 / R;
 	constexpr int SUB = RW_CHUNK / G;   // tiles per thread group
-	__shared__ unsigned s_a[G][R], s_b[G][R], s_base[R], s_w[4];
-	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
-
-	// 1. digit d: count in earlier chunks and in all chunks (every block
-	// re-derives its starting point from the chunk sums: no chain)
-	{
-		unsigned before = 0, total = 0;
-		for (unsigned c = g; c < chunks; c += G) {
-			const unsigned v = partial[(size_t) c * R + d];
-			total += v;
-			if (c < blockIdx.x) before += v;
-		}
-		s_a[g][d] = before;
-		s_b[g][d] = total;
-	}
-	__syncthreads();
-	unsigned bef = 0, tot = 0;
-	if (tid < (unsigned) R) {
-		#pragma unroll
-		for (int k = 0; k < G; ++k) { bef += s_a[k][tid]; tot += s_b[k][tid]; }
-	}
-	// 2. exclusive scan of the digit totals over the digits
-	const unsigned incl = clo_wave_scan_inclusive<unsigned>(tot, lane);
-	if (lane == 63) s_w[wave] = incl;
-	__syncthreads();
-	if (tid < (unsigned) R) {
-		unsigned add = 0;
-		#pragma unroll
-		for (unsigned w = 0; w < 4; ++w) if (w < wave) add += s_w[w];
-		s_base[tid] = incl - tot + add + bef;
-	}
-	__syncthreads();
-
-	// 3. walk the chunk: group g takes SUB consecutive tiles
+	__shared__ unsigned s_a[G][R];
+	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R;
 	const unsigned t0 = blockIdx.x * RW_CHUNK;
 	const unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
 	const unsigned ts = t0 + g * SUB < tend ? t0 + g * SUB : tend;
 	const unsigned te = ts + SUB < tend ? ts + SUB : tend;
-	unsigned run = s_base[d];
+	unsigned run = cbase[(size_t) blockIdx.x * R + d];
 	if (G > 1) {
 		unsigned own = 0;
 		#pragma unroll 8
@@ -200,7 +216,8 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
 	#define CLO_RW_OFF(B) case B: \
 		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, partial); \
-		hipLaunchKernelGGL((clo_radixw_offsets_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, (const unsigned*) partial, chunks, toff); break
+		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(256), 0, s, partial, chunks); \
+		hipLaunchKernelGGL((clo_radixw_offsets_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, (const unsigned*) partial, toff); break
 	switch (bits) {
 		CLO_RW_OFF(1); CLO_RW_OFF(2); CLO_RW_OFF(3); CLO_RW_OFF(4); CLO_RW_OFF(5); CLO_RW_OFF(6); CLO_RW_OFF(7); CLO_RW_OFF(8);
 		default: return CLO_HIP_EUNSUPPORTED;
