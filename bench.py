@@ -17,11 +17,18 @@ all-to-all(v) over xGMI -> local satradix (cl_ops_amd/multigpu.py).
 value = all keys of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line. Besides the contract's fields it carries
-  roofline:     the dominant kernel (the per-digit pass kernel) against the HBM
-                peak: ALGORITHMIC bytes per launch (3*s bytes per
-                element and digit = read for histogram + read for scatter +
-                write) / average launch duration measured live with HIP events
-                on the kernel's own stream.
+  roofline:     the dominant kernel (the pass kernel) against the HBM peak:
+                ALGORITHMIC bytes per launch / average launch duration measured
+                live with HIP events on the kernel's own stream. SURVEY.md §8d
+                prices a digit at 3*s bytes per element (read for histogram +
+                read for scatter + write); the histogram read is a kernel of its
+                own here, so the pass kernel is credited with the other two
+                streams, and a launch handles TWO 4-bit digits of every
+                element: 2 digits * 2*s * N. "moved_GBps" is what the kernel
+                must move at least (one read + one write per launch),
+                "traffic" what the PMC counters saw, and
+                "algorithmic_GBps_per_step" the whole sort at the contract's
+                3*s per digit (all kernels).
   cpu_baseline: the CPU oracle (a port of the reference decomposition,
                 oracle/clo_oracle.c, OpenMP) on a bounded sample of the same
                 workload, on this box's host cores.
@@ -287,7 +294,15 @@ def main():
         cnt, tot_ms = _hip.timing_read(label)
         avg_ms = tot_ms / cnt if cnt else float("nan")
         per_launch_elems = n  # every launch of the dominant kernel sweeps the local array once
+        digits_per_launch = 1
+        if workload.startswith("satradix") and cnt:
+            # the pass kernel handles several digit steps per launch (two 4-bit digits at radix 16)
+            key_bits = 64 if workload == "satradix_u64" else 32
+            digits = key_bits // int(np.log2(args.radix))
+            digits_per_launch = max(1, round(digits * args.steps / cnt))
+            per_launch_B = 2 * es * digits_per_launch   # scatter read + write, per digit step
         achieved = per_launch_B * per_launch_elems / (avg_ms * 1e-3) if cnt else float("nan")
+        moved = 2 * es * per_launch_elems / (avg_ms * 1e-3) if cnt and workload.startswith("satradix") else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
         if os.path.exists(tpath):
@@ -324,6 +339,8 @@ def main():
                          "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_B * per_launch_elems,
+                         "digit_steps_per_launch": digits_per_launch,
+                         "moved_GBps": round(moved / 1e9, 1) if moved else None,
                          "note": "per-launch durations from HIP events on the kernel's stream over %d extra steps "
                                  "run right after the timed region" % args.steps},
         }
