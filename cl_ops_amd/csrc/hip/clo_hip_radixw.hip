@@ -111,9 +111,9 @@ void clo_radixw_chunksum_kernel(const unsigned* __restrict__ thist, unsigned til
 // chunk serially (a few hundred coalesced loads per thread), the groups are
 // combined through LDS. In place: partial[c][d] becomes that offset.
 template <int R>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void clo_radixw_chunkscan_kernel(unsigned* __restrict__ partial, unsigned chunks) {
-	constexpr int G = 256 / R;
+	constexpr int G = 1024 / R;   // thread groups: each walks chunks / G chunks
 	__shared__ unsigned s_g[G][R], s_w[4];
 	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
 	// group g owns the contiguous range of chunks [c0, c1)
@@ -134,7 +134,7 @@ void clo_radixw_chunkscan_kernel(unsigned* __restrict__ partial, unsigned chunks
 	// exclusive scan of the digit totals over the digits (threads 0..R-1 carry them)
 	const unsigned t = tid < (unsigned) R ? tot : 0u;
 	const unsigned incl = clo_wave_scan_inclusive<unsigned>(t, lane);
-	if (lane == 63) s_w[wave] = incl;
+	if (lane == 63 && wave < 4) s_w[wave] = incl;   // R <= 256: the digits sit in the first four waves
 	__syncthreads();
 	unsigned dbase = incl - t;
 	#pragma unroll
@@ -216,7 +216,7 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
 	#define CLO_RW_OFF(B) case B: \
 		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, partial); \
-		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(256), 0, s, partial, chunks); \
+		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(1024), 0, s, partial, chunks); \
 		hipLaunchKernelGGL((clo_radixw_offsets_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, (const unsigned*) partial, toff); break
 	switch (bits) {
 		CLO_RW_OFF(1); CLO_RW_OFF(2); CLO_RW_OFF(3); CLO_RW_OFF(4); CLO_RW_OFF(5); CLO_RW_OFF(6); CLO_RW_OFF(7); CLO_RW_OFF(8);

@@ -50,7 +50,7 @@ for k in fetch:
     rows.append((short(k), n, f, w, int((2 * f + w) * 1024)))
 rows.sort(key=lambda r: -r[4] * r[1])
 hist = [r for r in rows if "tilehist" in r[0] and "unsigned int" in r[0]]
-pas = [r for r in rows if "pass_pc" in r[0] and "unsigned int" in r[0]]
+pas = [r for r in rows if "pair_kernel" in r[0] and "unsigned int" in r[0]]
 n_keys = 1 << 28
 calib = (n_keys * 4 / 1024) / hist[0][2] if hist else float("nan")
 path = os.path.join(dst, "%s_satradix_u32_2p28_pmc_hbm_traffic.csv" % tag)
