@@ -181,6 +181,49 @@ void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 	}
 }
 
+// Up to RW_CHUNK tiles (one chunk): the three steps above in one launch of one
+// work-group — arrays of 2^13 .. 2^20 elements are launch-bound.
+template <int R>
+__global__ __launch_bounds__(256)
+void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned* __restrict__ toff) {
+	constexpr int G = 256 / R;
+	constexpr int SUB = RW_CHUNK / G;
+	__shared__ unsigned s_a[G][R], s_base[R], s_w[4];
+	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
+	const unsigned ts = g * SUB < tiles ? g * SUB : tiles;
+	const unsigned te = ts + SUB < tiles ? ts + SUB : tiles;
+	unsigned own = 0;
+	#pragma unroll 8
+	for (unsigned t = ts; t < te; ++t) own += thist[(size_t) t * R + d];
+	s_a[g][d] = own;
+	__syncthreads();
+	unsigned before = 0, tot = 0;
+	#pragma unroll
+	for (int k = 0; k < G; ++k) {
+		const unsigned v = s_a[k][d];
+		if ((unsigned) k < g) before += v;
+		tot += v;
+	}
+	const unsigned t0 = tid < (unsigned) R ? tot : 0u;
+	const unsigned incl = clo_wave_scan_inclusive<unsigned>(t0, lane);
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned dbase = incl - t0;
+		#pragma unroll
+		for (unsigned w = 0; w < 4; ++w) if (w < wave) dbase += s_w[w];
+		s_base[tid] = dbase;
+	}
+	__syncthreads();
+	unsigned run = s_base[d] + before;
+	#pragma unroll 8
+	for (unsigned t = ts; t < te; ++t) {
+		const unsigned c = thist[(size_t) t * R + d];
+		toff[(size_t) t * R + d] = run;
+		run += c;
+	}
+}
+
 }  // namespace
 
 // ---- the histogram / counter-scan steps for any digit width 1..8 (used by
@@ -214,6 +257,15 @@ int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits
 
 int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff, hipStream_t s) {
 	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
+	#define CLO_RW_OFF1(B) case B: hipLaunchKernelGGL((clo_radixw_offsets1_kernel<(1 << B)>), dim3(1), dim3(256), 0, s, thist, tiles, toff); break
+	if (chunks == 1) {
+		switch (bits) {
+			CLO_RW_OFF1(1); CLO_RW_OFF1(2); CLO_RW_OFF1(3); CLO_RW_OFF1(4); CLO_RW_OFF1(5); CLO_RW_OFF1(6); CLO_RW_OFF1(7); CLO_RW_OFF1(8);
+			default: return CLO_HIP_EUNSUPPORTED;
+		}
+		return (int) hipGetLastError();
+	}
+	#undef CLO_RW_OFF1
 	#define CLO_RW_OFF(B) case B: \
 		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, partial); \
 		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(1024), 0, s, partial, chunks); \
