@@ -48,6 +48,11 @@ _sig("clo_hip_memcpy_d2d_async", ci, vp, vp, sz, vp)
 _sig("clo_hip_memset_async", ci, vp, ci, sz, vp)
 _sig("clo_hip_host_register", ci, vp, sz)
 _sig("clo_hip_host_unregister", ci, vp)
+_sig("clo_hip_graph_capture_begin", ci, vp)
+_sig("clo_hip_graph_capture_end", ci, vp, C.POINTER(vp))
+_sig("clo_hip_graph_launch", ci, vp, vp)
+_sig("clo_hip_graph_destroy", ci, vp)
+_sig("clo_hip_timing_enabled", ci)
 _sig("clo_hip_event_create", ci, C.POINTER(vp))
 _sig("clo_hip_event_destroy", ci, vp)
 _sig("clo_hip_event_record", ci, vp, vp)

@@ -93,7 +93,7 @@ static const char* clo_sort_abitonic_init(CloSort* sorter, const char* options, 
 static void clo_sort_abitonic_finalize(CloSort* sorter) {
 	clo_sort_abitonic_data* data = (clo_sort_abitonic_data*) clo_sort_get_data(sorter);
 	if (data) {
-		clo_devbuf_release(&data->state.padded);
+		clo_bitonic_state_release(&data->state);
 		free(data);
 	}
 	clo_sort_set_data(sorter, NULL);

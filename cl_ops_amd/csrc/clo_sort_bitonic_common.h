@@ -8,7 +8,17 @@
 typedef struct {
 	clo_devbuf padded;   /* used only when numel is not a power of two */
 	void* last_stream;
+	/* The launch sequence of a sort depends only on (buffer, numel, stream):
+	 * when a call repeats the previous one's, it is captured into a graph and
+	 * replayed from then on (sbitonic: 136 launches for 2^16 elements). */
+	void* graph;         /* executable graph, or NULL */
+	void* g_ptr;
+	void* g_stream;
+	size_t g_numel;
+	int g_tiled, g_launches, g_seen;
 } clo_bitonic_state;
+
+void clo_bitonic_state_release(clo_bitonic_state* state);
 
 /* Runs one of the two HIP schedules on (data_in -> data_out | in place).
  * tiled = 0: one launch per step (sbitonic); 1: LDS/register tiles (abitonic).

@@ -27,7 +27,7 @@ static const char* clo_sort_sbitonic_init(CloSort* sorter, const char* options, 
 static void clo_sort_sbitonic_finalize(CloSort* sorter) {
 	clo_bitonic_state* state = (clo_bitonic_state*) clo_sort_get_data(sorter);
 	if (state) {
-		clo_devbuf_release(&state->padded);
+		clo_bitonic_state_release(state);
 		free(state);
 	}
 	clo_sort_set_data(sorter, NULL);

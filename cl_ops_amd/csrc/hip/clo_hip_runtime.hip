@@ -37,6 +37,8 @@ void clo_timing_end(hipStream_t s) {
 
 extern "C" {
 
+int clo_hip_timing_enabled(void) { return g_timing_on ? 1 : 0; }
+
 int clo_hip_timing_enable(int on) {
 	std::lock_guard<std::mutex> lk(g_timing_mu);
 	g_timing_on = on != 0;
@@ -148,6 +150,32 @@ int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
 }
 int clo_hip_stream_wait_event(void* stream, void* event) {
 	return (int) hipStreamWaitEvent((hipStream_t) stream, (hipEvent_t) event, 0);
+}
+
+int clo_hip_graph_capture_begin(void* stream) {
+	return (int) hipStreamBeginCapture((hipStream_t) stream, hipStreamCaptureModeThreadLocal);
+}
+
+int clo_hip_graph_capture_end(void* stream, void** graph_exec) {
+	if (!graph_exec) return CLO_HIP_EARGS;
+	*graph_exec = nullptr;
+	hipGraph_t graph = nullptr;
+	hipError_t e = hipStreamEndCapture((hipStream_t) stream, &graph);
+	if (e != hipSuccess) return (int) e;
+	hipGraphExec_t exec = nullptr;
+	e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+	(void) hipGraphDestroy(graph);
+	if (e != hipSuccess) return (int) e;
+	*graph_exec = exec;
+	return 0;
+}
+
+int clo_hip_graph_launch(void* graph_exec, void* stream) {
+	return graph_exec ? (int) hipGraphLaunch((hipGraphExec_t) graph_exec, (hipStream_t) stream) : CLO_HIP_EARGS;
+}
+
+int clo_hip_graph_destroy(void* graph_exec) {
+	return graph_exec ? (int) hipGraphExecDestroy((hipGraphExec_t) graph_exec) : 0;
 }
 
 const char* clo_hip_error_string(int status) {

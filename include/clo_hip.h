@@ -71,6 +71,15 @@ int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms);
  * sort/clo_sort_sbitonic.c:86-95). */
 int clo_hip_stream_wait_event(void* stream, void* event);
 
+/* Stream capture into an executable graph: a launch-bound sequence (sbitonic
+ * makes one launch per (stage, step): 136 for 2^16 elements) is recorded once
+ * and replayed with one call. begin/end bracket the launches on `stream`;
+ * end instantiates the graph. */
+int clo_hip_graph_capture_begin(void* stream);
+int clo_hip_graph_capture_end(void* stream, void** graph_exec);
+int clo_hip_graph_launch(void* graph_exec, void* stream);
+int clo_hip_graph_destroy(void* graph_exec);
+
 const char* clo_hip_error_string(int status);
 
 /* ---- exclusive prefix sum (replaces the three launches of
@@ -185,6 +194,7 @@ int clo_hip_check_status(void* workspace, void* stream);
  * `label` since the last reset ("radix_pass", "radix_hist", "scan",
  * "bitonic_tile", "bitonic_strided", "bitonic_step"). */
 int clo_hip_timing_enable(int on);
+int clo_hip_timing_enabled(void);
 int clo_hip_timing_reset(void);
 int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms);
 

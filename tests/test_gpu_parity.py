@@ -404,6 +404,43 @@ def test_bitonic_float_key_inside_a_wider_element(gpu, alg):
     assert np.all(gk[:-1] <= gk[1:]) and np.array_equal(np.sort(got), np.sort(e))
 
 
+def test_sbitonic_graph_replay_sees_new_data_and_new_buffers(gpu):
+    """From the third call with the same (buffer, numel, queue) on, sbitonic
+    replays its 136 launches from a captured graph: new contents, another
+    buffer, another size and a profiling run in between must all come out sorted."""
+    import cl_ops_amd as clo
+    from cl_ops_amd._hip import lib
+    ctx, q = gpu
+    n = 1 << 16
+    s = clo.Sorter("sbitonic", ctx, "uint")
+    b1, b2 = clo.Buffer(ctx, 4 * n), clo.Buffer(ctx, 4 * n)
+    rng = np.random.default_rng(77)
+    for rep in range(5):                       # calls 3.. replay the graph
+        a = rand_u32(rng, n)
+        b1.write(q, a)
+        s.with_device_data(q, b1, None, n)
+        assert np.array_equal(b1.read(q, np.uint32, n), np.sort(a)), rep
+    for buf, m in ((b2, n), (b2, n), (b2, n), (b1, n >> 1), (b1, n >> 1), (b1, n >> 1), (b1, n)):
+        a = rand_u32(rng, m)
+        buf.write(q, a)
+        s.with_device_data(q, buf, None, m)
+        assert np.array_equal(buf.read(q, np.uint32, m), np.sort(a))
+    lib.clo_hip_timing_enable(1)               # per-kernel timing needs real launches
+    lib.clo_hip_timing_reset()
+    for _ in range(2):
+        a = rand_u32(rng, n)
+        b1.write(q, a)
+        s.with_device_data(q, b1, None, n)
+        assert np.array_equal(b1.read(q, np.uint32, n), np.sort(a))
+    from cl_ops_amd import _hip
+    assert _hip.timing_read("bitonic_step")[0] == 2 * 136
+    lib.clo_hip_timing_enable(0)
+    lib.clo_hip_timing_reset()
+    for b in (b1, b2):
+        b.close()
+    s.close()
+
+
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
 def test_bitonic_descending_compare(gpu, alg):
     import cl_ops_amd as clo
