@@ -62,3 +62,39 @@ int clo_parse_options(const char* options, clo_option_cb cb, void* user, const c
 	free(copy);
 	return ok;
 }
+
+/* ---- cached launch sequences (clo_internal.h) ---- */
+
+void clo_graph_cache_release(clo_graph_cache* gc) {
+	if (!gc) return;
+	clo_hip_graph_destroy(gc->exec);
+	gc->exec = NULL;
+	gc->seen = 0;
+}
+
+int clo_graph_cache_run(clo_graph_cache* gc, int allowed, const void* k0, const void* k1, size_t n, int variant,
+	void* stream, clo_enqueue_fn enqueue, void* user) {
+	const int same = gc->k0 == k0 && gc->k1 == k1 && gc->n == n && gc->variant == variant && gc->stream == stream;
+	allowed = allowed && !clo_hip_timing_enabled();
+	if (!same) {
+		clo_graph_cache_release(gc);
+		gc->k0 = k0; gc->k1 = k1; gc->n = n; gc->variant = variant; gc->stream = stream;
+	}
+	if (allowed && same && gc->exec != NULL) return clo_hip_graph_launch(gc->exec, stream);
+	if (allowed && same && gc->seen >= 1) {
+		int st = clo_hip_graph_capture_begin(stream);
+		if (st != 0) return st;
+		st = enqueue(user, stream);
+		void* exec = NULL;
+		const int st2 = clo_hip_graph_capture_end(stream, &exec);
+		if (st != 0 || st2 != 0) {
+			clo_hip_graph_destroy(exec);
+			gc->seen = 0;   /* do not try again for this key */
+			return st != 0 ? st : st2;
+		}
+		gc->exec = exec;
+		return clo_hip_graph_launch(exec, stream);   /* capturing recorded the launches, it did not run them */
+	}
+	gc->seen += 1;
+	return enqueue(user, stream);
+}

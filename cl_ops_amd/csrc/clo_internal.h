@@ -40,6 +40,26 @@ typedef struct {
 int clo_devbuf_reserve(clo_devbuf* b, size_t bytes);
 void clo_devbuf_release(clo_devbuf* b);
 
+/* A launch sequence that depends only on its arguments (buffers, size,
+ * stream), cached as an executable hipGraph: the FIRST call with a given key
+ * launches normally, a second consecutive call with the same key captures the
+ * sequence and replays it, later ones replay. Any other key drops the graph.
+ * Never used while per-kernel timing is on (its event pairs need real
+ * launches). `enqueue` puts the whole sequence on `stream` and returns a
+ * clo_hip status. */
+typedef struct {
+	void* exec;
+	const void* k0;
+	const void* k1;
+	void* stream;
+	size_t n;
+	int variant, seen;
+} clo_graph_cache;
+typedef int (*clo_enqueue_fn)(void* user, void* stream);
+int clo_graph_cache_run(clo_graph_cache* gc, int allowed, const void* k0, const void* k1, size_t n, int variant,
+	void* stream, clo_enqueue_fn enqueue, void* user);
+void clo_graph_cache_release(clo_graph_cache* gc);
+
 /* Set *err from a clo_hip_* status (domain CCL_HIP_ERROR); returns 1 if st != 0. */
 int clo_hip_failed(int st, GError** err, const char* what);
 

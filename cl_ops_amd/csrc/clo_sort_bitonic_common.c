@@ -8,9 +8,24 @@
 
 void clo_bitonic_state_release(clo_bitonic_state* state) {
 	if (!state) return;
-	clo_hip_graph_destroy(state->graph);
-	state->graph = NULL;
+	clo_graph_cache_release(&state->graph);
 	clo_devbuf_release(&state->padded);
+}
+
+typedef struct {
+	const CloSortKeySpec* ks;
+	void* work;
+	size_t numel;
+	int tiled;
+	int* launches;
+} bitonic_call;
+
+static int bitonic_enqueue(void* user, void* stream) {
+	bitonic_call* c = (bitonic_call*) user;
+	const CloSortKeySpec* ks = c->ks;
+	return c->tiled
+		? clo_hip_bitonic_tiled(c->work, c->numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, c->launches, stream)
+		: clo_hip_bitonic_simple(c->work, c->numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, c->launches, stream);
 }
 
 CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, const char* evt_name,
@@ -86,46 +101,13 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 			work = state->padded.ptr;
 			use_pad = 1;
 		}
-		int launches = 0, st = 0;
-		/* graph replay: same buffer, size, schedule and stream as the previous call
-		 * (never while per-kernel timing is on: its event pairs need real launches) */
-		const int same = !use_pad && state->g_ptr == work && state->g_numel == numel && state->g_stream == stream
-			&& state->g_tiled == tiled;
-		/* (only for the one-launch-per-step schedule: abitonic's 33 launches of ~0.1 ms measured no gain) */
-		const int graphs_ok = !tiled && !use_pad && !clo_hip_timing_enabled();
-		if (same && graphs_ok && state->graph != NULL) {
-			st = clo_hip_graph_launch(state->graph, stream);
-			launches = state->g_launches;
-			if (clo_hip_failed(st, err, "hipGraphLaunch")) return NULL;
-		} else {
-			const int capture = same && graphs_ok && state->g_seen >= 1 && state->graph == NULL;
-			if (!same) {
-				clo_hip_graph_destroy(state->graph);
-				state->graph = NULL;
-				state->g_seen = 0;
-			}
-			if (capture && clo_hip_failed(clo_hip_graph_capture_begin(stream), err, "hipStreamBeginCapture")) return NULL;
-			st = tiled
-				? clo_hip_bitonic_tiled(work, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, &launches, stream)
-				: clo_hip_bitonic_simple(work, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, &launches, stream);
-			if (capture) {
-				void* exec = NULL;
-				const int st2 = clo_hip_graph_capture_end(stream, &exec);
-				if (st == 0 && st2 == 0) {
-					state->graph = exec;
-					state->g_launches = launches;
-					st = clo_hip_graph_launch(exec, stream);   /* capturing recorded the launches, it did not run them */
-				} else {
-					clo_hip_graph_destroy(exec);
-					if (st == 0) st = st2;
-				}
-			}
-			if (clo_hip_failed(st, err, tiled ? "clo_hip_bitonic_tiled" : "clo_hip_bitonic_simple")) return NULL;
-			if (!use_pad) {
-				state->g_ptr = work; state->g_numel = numel; state->g_stream = stream; state->g_tiled = tiled;
-				state->g_seen += 1;
-			}
-		}
+		/* graph replay only for the one-launch-per-step schedule (abitonic's 33
+		 * launches of ~0.1 ms measured no gain) and only in place of the caller's buffer */
+		int launches = state->launches;
+		bitonic_call call = { ks, work, numel, tiled, &launches };
+		int st = clo_graph_cache_run(&state->graph, !tiled && !use_pad, work, NULL, numel, tiled, stream, bitonic_enqueue, &call);
+		if (clo_hip_failed(st, err, tiled ? "clo_hip_bitonic_tiled" : "clo_hip_bitonic_simple")) return NULL;
+		state->launches = launches;
 		clo_debug("%s: numel=%zu padded=%zu launches=%d", evt_name, numel, padded, launches);
 		if (use_pad)
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) return NULL;

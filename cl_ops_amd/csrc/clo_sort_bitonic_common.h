@@ -11,11 +11,8 @@ typedef struct {
 	/* The launch sequence of a sort depends only on (buffer, numel, stream):
 	 * when a call repeats the previous one's, it is captured into a graph and
 	 * replayed from then on (sbitonic: 136 launches for 2^16 elements). */
-	void* graph;         /* executable graph, or NULL */
-	void* g_ptr;
-	void* g_stream;
-	size_t g_numel;
-	int g_tiled, g_launches, g_seen;
+	clo_graph_cache graph;
+	int launches;
 } clo_bitonic_state;
 
 void clo_bitonic_state_release(clo_bitonic_state* state);

@@ -404,6 +404,29 @@ def test_bitonic_float_key_inside_a_wider_element(gpu, alg):
     assert np.all(gk[:-1] <= gk[1:]) and np.array_equal(np.sort(got), np.sort(e))
 
 
+@pytest.mark.parametrize("n", [5000, 1 << 16, (1 << 20) + 7])
+def test_satradix_repeated_calls_changing_buffers_and_sizes(gpu, n):
+    """Repeated calls on the same and on changing buffers, in place / out of
+    place, with a different size in between (the cached aux buffers and
+    workspace are reused across all of them)."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    s = clo.Sorter("satradix", ctx, "uint")
+    b1, b2, b3 = (clo.Buffer(ctx, 4 * n) for _ in range(3))
+    rng = np.random.default_rng(n)
+    plan = [(b1, b2, n)] * 4 + [(b1, None, n)] * 3 + [(b3, b2, n)] * 3 + [(b1, b2, n // 2)] * 3 + [(b1, b2, n)] * 3
+    for src, dst, m in plan:
+        a = rand_u32(rng, m)
+        src.write(q, a)
+        s.with_device_data(q, src, dst, m)
+        assert np.array_equal((dst or src).read(q, np.uint32, m), np.sort(a))
+        if dst is not None:
+            assert np.array_equal(src.read(q, np.uint32, m), a)
+    for b in (b1, b2, b3):
+        b.close()
+    s.close()
+
+
 def test_sbitonic_graph_replay_sees_new_data_and_new_buffers(gpu):
     """From the third call with the same (buffer, numel, queue) on, sbitonic
     replays its 136 launches from a captured graph: new contents, another
