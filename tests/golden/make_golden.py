@@ -85,6 +85,32 @@ def main():
         out["scan_wrap_%d_in" % n] = w_in
         out["scan_wrap_%d_out" % n] = exp
 
+    # --- gselect (clo_sort_gselect.cl:38-58): a stable rank sort, any numel
+    for n in (1, 17, 1000):
+        rng = np.random.default_rng(100 + n)
+        keys = rng.integers(0, 5, n, dtype=np.uint64)
+        pairs = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        exp = stable_by_key(pairs, keys)
+        assert np.array_equal(O.gselect(pairs, key_size=4, key_shift=32), exp), ("gselect", n)
+        out["gselect_pairs_%d_in" % n] = pairs
+        out["gselect_pairs_%d_out" % n] = exp
+
+    # --- typed keys (signed / IEEE): numeric order, with negatives, both zeros and infinities.
+    # Upstream's radix kernels order raw bits (its own typed check rejects that for negative
+    # keys); the typed compare of its bitonic and gselect kernels gives this order. Expected =
+    # numpy, cross-checked with the oracle's typed gselect.
+    rng = np.random.default_rng(5)
+    i32 = rng.integers(-2**31, 2**31 - 1, 1024, dtype=np.int64).astype(np.int32)
+    f32 = (rng.standard_normal(1024) * 100).astype(np.float32)
+    f32[:6] = [0.0, -0.0, np.inf, -np.inf, 1.5, -1.5]
+    f64 = (rng.standard_normal(1024) * 1e6).astype(np.float64)
+    for name, a, kind in (("i32", i32, O.KEY_SIGNED), ("f32", f32, O.KEY_FLOAT), ("f64", f64, O.KEY_FLOAT)):
+        exp = np.sort(a, kind="stable")
+        got = O.gselect(a, key_kind=kind)
+        assert np.array_equal(got, exp), name           # numeric equality (-0 == +0)
+        out["typed_%s_in" % name] = a
+        out["typed_%s_out" % name] = exp
+
     # --- one digit pass of satradix, structural fixture (N=1024, L=64)
     a = O.bench_rand(1, "uint", 1024)
     srt, offs, cnt, cs = O.satradix(a, radix=16, lws_max=64, dev_max_lws=64, debug=True)

@@ -775,6 +775,74 @@ def test_sharded_scanner_world_size_one(gpu):
 
 
 # ----------------------------------------------------------------------------
+# the committed golden vectors (tests/golden/make_golden.py) through the HIP path
+# ----------------------------------------------------------------------------
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sortscan_golden.npz"))
+
+
+def test_golden_vectors_through_the_hip_path(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    sorters = {}
+
+    def sorter(alg, et, **kw):
+        key = (alg, et, tuple(sorted(kw.items())))
+        if key not in sorters:
+            sorters[key] = clo.Sorter(alg, ctx, et, **kw)
+        return sorters[key]
+
+    checked = 0
+    for name in GOLD.files:
+        if name.startswith("sort_") and name.endswith("_in"):
+            a, exp = GOLD[name], GOLD[name[:-3] + "_out"]
+            et = "uint" if a.dtype == np.uint32 else "ulong"
+            for alg in ("satradix", "sbitonic", "abitonic", "gselect"):
+                if alg == "gselect" and a.size > 1024:
+                    continue
+                assert np.array_equal(sorter(alg, et).with_host_data(a, q), exp), (name, alg)
+                checked += 1
+        elif name.startswith("pairs_") and name.endswith("_in"):
+            a = GOLD[name]
+            kw = dict(key_type="uint", get_key="(uint) ((x) >> 32)")
+            assert np.array_equal(sorter("satradix", "ulong", **kw).with_host_data(a, q), GOLD[name[:-3] + "_out"]), name
+            for alg in ("sbitonic", "abitonic"):      # tie order = the reference network's
+                assert np.array_equal(sorter(alg, "ulong", **kw).with_host_data(a, q), GOLD[name[:-3] + "_bitonic_out"]), (name, alg)
+            checked += 3
+        elif name.startswith("gselect_pairs_") and name.endswith("_in"):
+            kw = dict(key_type="uint", get_key="(uint) ((x) >> 32)")
+            for alg in ("gselect", "satradix"):
+                assert np.array_equal(sorter(alg, "ulong", **kw).with_host_data(GOLD[name], q), GOLD[name[:-3] + "_out"]), (name, alg)
+            checked += 2
+        elif name.startswith("typed_") and name.endswith("_in"):
+            a, exp = GOLD[name], GOLD[name[:-3] + "_out"]
+            et = {"int32": "int", "float32": "float", "float64": "double"}[a.dtype.name]
+            for alg in ("satradix", "sbitonic", "abitonic", "gselect"):
+                got = sorter(alg, et).with_host_data(a, q)
+                assert np.array_equal(got, exp), (name, alg)      # numeric equality
+                checked += 1
+        elif name.startswith("scan_") and name.endswith("_in"):
+            a = GOLD[name]
+            tag = name[:-3]
+            if tag.startswith("scan_wrap"):
+                sc = clo.Scanner("blelloch", ctx, "uint", "uint")
+                assert np.array_equal(sc.with_host_data(a, q), GOLD[tag + "_out"]), name
+                sc.close()
+                checked += 1
+            else:
+                n = tag.split("_")[1]
+                for st, t in (("uint", "u32"), ("ulong", "u64")):
+                    sc = clo.Scanner("blelloch", ctx, "uint", st)
+                    assert np.array_equal(sc.with_host_data(a, q), GOLD["scan_%s_%s_out" % (t, n)]), (name, st)
+                    sc.close()
+                    checked += 1
+    assert np.array_equal(sorter("satradix", "uint").with_host_data(GOLD["structural_in"], q), GOLD["structural_out"])
+    for s_ in sorters.values():
+        s_.close()
+    assert checked >= 140
+
+
+# ----------------------------------------------------------------------------
 # gselect: upstream's O(n^2) rank sort
 # ----------------------------------------------------------------------------
 
