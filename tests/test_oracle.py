@@ -169,3 +169,20 @@ def test_gselect_descending_and_signed():
     a = np.random.default_rng(0).integers(-1000, 1000, 500).astype(np.int32)
     assert np.array_equal(O.gselect(a, key_kind=O.KEY_SIGNED), np.sort(a))
     assert np.array_equal(O.gselect(a, key_kind=O.KEY_SIGNED, descending=True), np.sort(a)[::-1])
+
+
+@pytest.mark.parametrize("n", [1, 17, 1000])
+def test_gselect_matches_golden(n):
+    a, exp = GOLD["gselect_pairs_%d_in" % n], GOLD["gselect_pairs_%d_out" % n]
+    assert np.array_equal(O.gselect(a, key_size=4, key_shift=32), exp)
+    assert np.array_equal(O.stable_sort(a, key_size=4, key_shift=32), exp)
+
+
+@pytest.mark.parametrize("name,kind", [("i32", O.KEY_SIGNED), ("f32", O.KEY_FLOAT), ("f64", O.KEY_FLOAT)])
+def test_typed_compare_matches_golden(name, kind):
+    """The typed compare (clo_bench.c:26-65; CLO_SORT_COMPARE on the key type) in the
+    oracle's bitonic and gselect restatements: numeric order, negatives included."""
+    a, exp = GOLD["typed_%s_in" % name], GOLD["typed_%s_out" % name]
+    assert np.array_equal(O.gselect(a, key_kind=kind), exp)
+    assert np.array_equal(O.sbitonic(a, key_kind=kind), exp)
+    assert np.array_equal(O.abitonic(a, key_kind=kind)[0], exp)
