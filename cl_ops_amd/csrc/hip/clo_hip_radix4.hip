@@ -105,20 +105,20 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 	E* s_stage, unsigned (*s_end)[THREADS], unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX]) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
-	constexpr int TILE = THREADS * ITEMS;
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const unsigned tbase = tid * ITEMS;
-	const bool full = count == (unsigned) TILE;
+	const bool full = count == (unsigned) (THREADS * ITEMS);
 
 	// thread-private counts, LAST element first (see the pass kernel above)
 	unsigned long long c = 0;
-	unsigned rr = 0;
+	unsigned rr[ITEMS];   // 1 + number of LATER elements of the thread with the same digit
 	#pragma unroll
 	for (int i = ITEMS - 1; i >= 0; --i) {
+		rr[i] = 0;
 		if (full || tbase + i < count) {
 			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
 			c += 1ull << sh;
-			rr |= ((unsigned) (c >> sh) & 15u) << (4 * i);
+			rr[i] = (unsigned) (c >> sh) & 15u;
 		}
 	}
 	unsigned w[H];
@@ -174,7 +174,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		if (full || tbase + i < count) {
 			const unsigned d = (unsigned) (key[i] >> dshift) & dmask;
 			const unsigned end = (s_end[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
-			s_stage[(end - ((rr >> (4 * i)) & 15u)) & (TILE - 1)] = key[i];
+			s_stage[end - rr[i]] = key[i];   // (counts of these very elements: always inside the tile)
 		}
 	}
 	__syncthreads();
