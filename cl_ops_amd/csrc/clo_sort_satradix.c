@@ -6,7 +6,7 @@
  * introspection (:478-675) and the in-place contract (:680). The per-digit
  * launch loop (:264-313: localsort, histogram, scan, scatter) is replaced by
  * one call into the C-ABI, clo_hip_radix_sort (include/clo_hip.h), which runs
- * one fused HIP kernel per digit.
+ * histogram -> counter scan -> one sort-and-scatter kernel per PAIR of digits.
  *
  * Differences from upstream, on purpose:
  *  - passes cover the KEY bits only: upstream loops over elem_size*8/bits
@@ -18,8 +18,9 @@
  *  - aux buffers live in the sorter and are reused (upstream @todo at :239);
  *  - data_out != NULL gives the sorted array in data_out and leaves data_in
  *    untouched; numel need not be a power of two;
- *  - COMPARE is ignored exactly as upstream (ascending order of the raw key
- *    bits, also for signed key types); floating point keys are refused.
+ *  - COMPARE is ignored exactly as upstream (always ascending); signed and
+ *    floating-point keys come out in numeric order (upstream: raw-bit order,
+ *    which its own typed check rejects for negative keys).
  */
 #include "clo_sort.h"
 #include "clo_scan.h"
@@ -35,7 +36,7 @@ typedef struct {
 	char* scan_opts;
 	CloScan* scanner;
 	clo_devbuf tmp;       /* ping-pong partner of the array being sorted */
-	clo_devbuf workspace; /* histograms + look-back state */
+	clo_devbuf workspace; /* per-tile histograms, offsets, chunk sums */
 	void* last_stream;
 } clo_sort_satradix_data;
 

@@ -181,18 +181,21 @@ void clo_hip_bitonic_jit_destroy(void* handle);
 /* In place, numel a power of two. tiled: 0 = sbitonic schedule, 1 = abitonic. */
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream);
 
-/* ---- status word of the bounded spins (decoupled look-back) ----
- * Every kernel that polls another work-group's state bounds its spin; on
- * give-up it sets a word in the workspace and finishes. This reads it back
- * (synchronises `stream`). Returns 0, CLO_HIP_ETIMEOUT or a hip error. */
+/* ---- status word of the bounded spins ----
+ * The scan is the one kernel that polls other work-groups' state (decoupled
+ * look-back); it bounds every spin and on give-up sets a word in its workspace
+ * and finishes. This reads the word back (synchronises `stream`). Returns 0,
+ * CLO_HIP_ETIMEOUT or a hip error. (The sorts never wait on another
+ * work-group; their workspaces carry the word, always 0, for uniformity.) */
 int clo_hip_check_status(void* workspace, void* stream);
 
 /* ---- per-kernel device timing (measurement only; bench.py's roofline leg) ----
  * While enabled, every kernel launch made by this library is bracketed by a
  * pair of HIP events recorded on the stream the kernel runs on.
  * clo_hip_timing_read sums the elapsed time of the launches recorded under
- * `label` since the last reset ("radix_pass", "radix_hist", "scan",
- * "bitonic_tile", "bitonic_strided", "bitonic_step"). */
+ * `label` since the last reset ("radix_pass", "radix_hist", "radix_offsets",
+ * "radix_small", "msd_partition", "scan", "reduce", "bitonic_presort",
+ * "bitonic_tile", "bitonic_strided", "bitonic_step", "gselect"). */
 int clo_hip_timing_enable(int on);
 int clo_hip_timing_enabled(void);
 int clo_hip_timing_reset(void);
