@@ -77,6 +77,9 @@ _sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER
 _sig("clo_hip_bitonic_jit_destroy", None, vp)
 _sig("clo_hip_bitonic_jit_sort", ci, vp, vp, sz, ci, C.POINTER(ci), vp)
 _sig("clo_hip_check_status", ci, vp, vp)
+_sig("clo_hip_radix_jit_create", ci, ci, ci, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
+_sig("clo_hip_radix_jit_destroy", None, vp)
+_sig("clo_hip_radix_jit_sort", ci, vp, vp, vp, vp, vp, sz, ci, vp, sz, vp)
 _sig("clo_hip_timing_enable", ci, ci)
 _sig("clo_hip_timing_reset", ci)
 _sig("clo_hip_timing_read", ci, C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float))

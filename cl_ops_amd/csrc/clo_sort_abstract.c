@@ -21,7 +21,8 @@ struct clo_sort {
 	CloType key_type;
 	void* data;
 	CloSortKeySpec spec;
-	void* jit;  /* hiprtc-specialised bitonic kernels, or NULL */
+	void* jit;  /* hiprtc-specialised kernels (bitonic network / satradix key extraction), or NULL */
+	int jit_is_radix;
 };
 
 /* ------------------------------------------------------------------ */
@@ -226,20 +227,33 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 		const int is_bitonic = strcmp(type, "sbitonic") == 0 || strcmp(type, "abitonic") == 0;
 		const int key_ok = parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)
 			&& !(ks->key_kind == 2 && ks->key_bits != 8 * ks->key_size);   /* a float key is the whole key type */
-		const int cmp_ok = parse_compare(compare, &ks->descending);
+		int cmp_ok = parse_compare(compare, &ks->descending);
+		const int is_satradix = strcmp(type, "satradix") == 0;
+		if (is_satradix && !cmp_ok) {
+			/* upstream's radix kernels never expand CLO_SORT_COMPARE (always ascending):
+			 * whatever the string says is accepted and ignored */
+			cmp_ok = 1;
+			ks->descending = 0;
+		}
 		if (!key_ok || !cmp_ok) {
-			if (!is_bitonic) {
+			if (!is_bitonic && !(is_satradix && !key_ok)) {
 				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
 					"Unsupported %s expression '%s' for %s (supported ahead of time: x, shifts, low-bit masks, "
 					"integer casts; ((a) > (b)), ((a) < (b)))", key_ok ? "compare" : "get_key",
 					key_ok ? compare : (get_key ? get_key : "(x)"), type);
 				goto error_handler;
 			}
-			/* what upstream does for every sorter: paste the two macro bodies into
-			 * the kernel source and build it (clo_sort_abstract.c:144-179) */
+			/* what upstream does for every sorter: paste the macro bodies into the
+			 * kernel source and build it (clo_sort_abstract.c:144-179) */
 			char* log = NULL;
-			int st = clo_hip_bitonic_jit_create((int) sorter->elem_type, (int) sorter->key_type, compare, get_key,
-				&sorter->jit, &log);
+			int st;
+			if (is_satradix) {
+				st = clo_hip_radix_jit_create((int) sorter->elem_type, (int) sorter->key_type, get_key, &sorter->jit, &log);
+				sorter->jit_is_radix = 1;
+			} else {
+				st = clo_hip_bitonic_jit_create((int) sorter->elem_type, (int) sorter->key_type, compare, get_key,
+					&sorter->jit, &log);
+			}
 			if (st != 0) {
 				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
 					"Could not build kernels for compare '%s' / get_key '%s': %s%s%.300s",
@@ -274,7 +288,7 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 error_handler:
 	if (sorter) {
 		/* finalize only what init created */
-		if (sorter->jit) clo_hip_bitonic_jit_destroy(sorter->jit);
+		if (sorter->jit) { if (sorter->jit_is_radix) clo_hip_radix_jit_destroy(sorter->jit); else clo_hip_bitonic_jit_destroy(sorter->jit); }
 		if (sorter->data) sorter->impl_def.finalize(sorter);
 		ccl_context_unref(sorter->ctx);
 		ccl_program_destroy(sorter->prg);
@@ -286,7 +300,7 @@ error_handler:
 void clo_sort_destroy(CloSort* sorter) {
 	clo_return_if_fail(sorter != NULL);
 	sorter->impl_def.finalize(sorter);
-	if (sorter->jit) clo_hip_bitonic_jit_destroy(sorter->jit);
+	if (sorter->jit) { if (sorter->jit_is_radix) clo_hip_radix_jit_destroy(sorter->jit); else clo_hip_bitonic_jit_destroy(sorter->jit); }
 	if (sorter->ctx) ccl_context_unref(sorter->ctx);
 	if (sorter->prg) ccl_program_destroy(sorter->prg);
 	free(sorter);

@@ -37,6 +37,7 @@ typedef struct {
 	CloScan* scanner;
 	clo_devbuf tmp;       /* ping-pong partner of the array being sorted */
 	clo_devbuf workspace; /* per-tile histograms, offsets, chunk sums */
+	clo_devbuf pairs;     /* (ordered key, index) pairs of a run-time compiled get_key */
 	void* last_stream;
 } clo_sort_satradix_data;
 
@@ -101,9 +102,11 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		if (data->last_stream && data->last_stream != stream)
 			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
 		data->last_stream = stream;
-		const size_t ws_bytes = clo_hip_radix_workspace_bytes(numel, ks->elem_size, ks->key_bits, bits_in_digit);
-		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, bytes), err, "hipMalloc(satradix aux)")) return NULL;
+		const int jit = clo_sort_get_jit(sorter) != NULL;   /* then (key, index) pairs of 8 bytes are what gets sorted */
+		const size_t ws_bytes = clo_hip_radix_workspace_bytes(numel, jit ? 8 : ks->elem_size, jit ? 32 : ks->key_bits, bits_in_digit);
+		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, jit ? numel * 8 : bytes), err, "hipMalloc(satradix aux)")) return NULL;
 		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws_bytes), err, "hipMalloc(satradix workspace)")) return NULL;
+		if (jit && clo_hip_failed(clo_devbuf_reserve(&data->pairs, numel * 8), err, "hipMalloc(satradix key pairs)")) return NULL;
 	}
 
 	evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
@@ -112,8 +115,13 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 	if (numel > 0) {
 		void* src = ccl_buffer_get_device_ptr(data_in);
 		void* dst = data_out ? ccl_buffer_get_device_ptr(data_out) : src;
-		int st = clo_hip_radix_sort(src, dst, data->tmp.ptr, numel, ks->elem_size, ks->key_shift,
-			ks->key_bits, key_kind, bits_in_digit, data->workspace.ptr, data->workspace.bytes, stream);
+		int st;
+		if (clo_sort_get_jit(sorter) != NULL)
+			st = clo_hip_radix_jit_sort(clo_sort_get_jit(sorter), src, dst, data->pairs.ptr, data->tmp.ptr, numel,
+				bits_in_digit, data->workspace.ptr, data->workspace.bytes, stream);
+		else
+			st = clo_hip_radix_sort(src, dst, data->tmp.ptr, numel, ks->elem_size, ks->key_shift,
+				ks->key_bits, key_kind, bits_in_digit, data->workspace.ptr, data->workspace.bytes, stream);
 		if (clo_hip_failed(st, err, "clo_hip_radix_sort")) return NULL;
 	}
 
@@ -169,6 +177,7 @@ static void satradix_free(clo_sort_satradix_data* data) {
 	if (data->scanner) clo_scan_destroy(data->scanner);
 	clo_devbuf_release(&data->tmp);
 	clo_devbuf_release(&data->workspace);
+	clo_devbuf_release(&data->pairs);
 	free(data);
 }
 

@@ -181,6 +181,17 @@ void clo_hip_bitonic_jit_destroy(void* handle);
 /* In place, numel a power of two. tiled: 0 = sbitonic schedule, 1 = abitonic. */
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream);
 
+/* ---- satradix specialised at run time (hiprtc) for a get_key expression
+ *      outside the ahead-of-time family: the key is materialised as
+ *      (ordered key bits << 32 | index) pairs by a compiled kernel, the pairs are
+ *      radix-sorted, the elements gathered. Key types of up to 4 bytes.
+ *      pairs / pairs_tmp: numel * 8 bytes each; workspace as for
+ *      clo_hip_radix_workspace_bytes(numel, 8, 32, digit_bits). ---- */
+int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, void** handle, char** log);
+void clo_hip_radix_jit_destroy(void* handle);
+int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs, void* pairs_tmp, size_t numel,
+	int digit_bits, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- status word of the bounded spins ----
  * The scan is the one kernel that polls other work-groups' state (decoupled
  * look-back); it bounds every spin and on give-up sets a word in its workspace

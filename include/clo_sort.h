@@ -11,9 +11,10 @@
  *  - `compare` / `get_key` are OpenCL C macro bodies upstream (JIT). Here they
  *    are parsed into a fixed family: get_key = x, (x) >> N, ((x) >> N) & MASK,
  *    optional casts; compare = ((a) > (b)) or ((a) < (b)) select ahead-of-time
- *    kernels. Any other expression: the bitonic sorters compile it at run time
- *    with hiprtc (as upstream does with the OpenCL JIT); satradix, which needs
- *    the key's bit layout, answers CLO_ERROR_ARGS.
+ *    kernels. Any other expression is compiled at run time with hiprtc (as
+ *    upstream does with the OpenCL JIT): into the bitonic kernels themselves,
+ *    or, for satradix, into a kernel that materialises the keys (key types of
+ *    up to 4 bytes). gselect answers CLO_ERROR_ARGS.
  *  - data_out != NULL works (upstream sorts data_in regardless,
  *    clo_sort_satradix.c:276,305 / clo_sort_abitonic.c:388) and leaves data_in
  *    untouched; numel need not be a power of two.

@@ -8,6 +8,8 @@ import pytest
 
 import oracle_lib as O
 
+CLO_ERROR_ARGS = 2
+
 pytestmark = pytest.mark.gpu
 
 
@@ -914,6 +916,57 @@ def test_gselect_device_data_with_and_without_output_buffer(gpu):
 # compare / get_key outside the ahead-of-time family: compiled at run time
 # (hiprtc), as upstream compiles every sorter by OpenCL JIT
 # ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", [
+    ("uint", "uint", "(x) % 1000u", lambda a: a % 1000),
+    ("uint", "uint", "((x) >> 3) * 7u", lambda a: ((a >> 3) * 7) & 0xFFFFFFFF),
+    ("uint", "int", "(int) (x) / 2 - 1000", lambda a: (a.view(np.int32) / 2).astype(np.int32) - 1000),   # C division truncates
+    ("ulong", "ushort", "(ushort) (((x) >> 7) ^ (x))", lambda a: ((a >> 7) ^ a).astype(np.uint16)),
+    ("uint", "float", "(float) (x) * -0.5f", lambda a: a.astype(np.float32) * np.float32(-0.5)),
+    ("float", "float", "fabsf(x)", lambda a: np.abs(a)),
+])
+@pytest.mark.parametrize("n", [1000, 100003])
+def test_satradix_jit_get_key(gpu, case, n):
+    """get_key expressions outside the parsed family: compiled at run time, the
+    key materialised, result = stable sort by the computed key (upstream: OpenCL
+    JIT of the same macro body, clo_sort_abstract.c:144-179)."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, kt, expr, fn = case
+    dt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(n)
+    if np.issubdtype(dt, np.floating):
+        a = ((rng.random(n) - 0.5) * 1e4).astype(dt)
+    else:
+        a = rng.integers(0, min(np.iinfo(dt).max, 2**31 - 1), n, dtype=np.int64).astype(dt)
+    keys = fn(a)
+    s = clo.Sorter("satradix", ctx, et, key_type=kt, get_key=expr)
+    got = s.with_host_data(a, q)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(got.view(np.dtype("u%d" % dt.itemsize)), a[order].view(np.dtype("u%d" % dt.itemsize)))
+    # in place on device data, and a compare string is accepted and ignored (as upstream)
+    b = clo.Buffer(ctx, a.nbytes)
+    b.write(q, a)
+    s.with_device_data(q, b, None, n)
+    assert np.array_equal(b.read(q, dt, n).view(np.dtype("u%d" % dt.itemsize)), a[order].view(np.dtype("u%d" % dt.itemsize)))
+    b.close()
+    s.close()
+
+
+def test_satradix_jit_refuses_wide_keys_and_bad_expressions(gpu):
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    with pytest.raises(clo.CloError) as e:
+        clo.Sorter("satradix", ctx, "ulong", get_key="(x) * 3")          # 8-byte key: no room for the index
+    assert e.value.code == CLO_ERROR_ARGS
+    with pytest.raises(clo.CloError) as e:
+        clo.Sorter("satradix", ctx, "uint", get_key="((x) >> 4")         # does not compile
+    assert e.value.code == CLO_ERROR_ARGS and "get_key" in e.value.message
+    s = clo.Sorter("satradix", ctx, "uint", compare="((a) >= (b)) /* ignored */")
+    a = rand_u32(np.random.default_rng(1), 5000)
+    assert np.array_equal(s.with_host_data(a, q), np.sort(a))
+    s.close()
+
 
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
 def test_jit_get_key_division_equals_shift(gpu, alg):
