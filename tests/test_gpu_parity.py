@@ -632,6 +632,33 @@ def test_full_size_abitonic_2p26(gpu):
     assert bool(np.all(got[:-1] <= got[1:])) and _xor_sum(got) == _xor_sum(a)
 
 
+@pytest.mark.parametrize("et,radix", [("float", 16), ("int", 256), ("double", 64)])
+def test_full_size_typed_radix_keys_2p26(gpu, et, radix):
+    """2^26 signed / IEEE keys (negatives included) through the transform in the
+    first and last pass: numeric order, same multiset of bit patterns, idempotent."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    n = 1 << 26
+    rng = np.random.default_rng(26)
+    if np.issubdtype(dt, np.floating):
+        a = (rng.standard_normal(n) * 1e3).astype(dt)
+    else:
+        a = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int64).astype(dt)
+    s = clo.Sorter("satradix", ctx, et, options="radix=%d" % radix)
+    buf = clo.Buffer(ctx, a.nbytes)
+    buf.write(q, a)
+    s.with_device_data(q, buf, None, n)
+    got = buf.read(q, dt, n)
+    u = np.dtype("u%d" % dt.itemsize)
+    assert bool(np.all(got[:-1] <= got[1:]))
+    assert _xor_sum(got.view(u)) == _xor_sum(a.view(u))
+    s.with_device_data(q, buf, None, n)
+    assert np.array_equal(buf.read(q, dt, n).view(u), got.view(u))
+    buf.close()
+    s.close()
+
+
 def test_indices_above_2p31_satradix_and_scan(gpu):
     """3*2^30 + 5 elements: global indices use bit 31 (positions are 32-bit, as
     upstream's uint gid; numel < 2^32). Inputs are generated and the results
