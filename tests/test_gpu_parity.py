@@ -632,6 +632,23 @@ def test_full_size_abitonic_2p26(gpu):
     assert bool(np.all(got[:-1] <= got[1:])) and _xor_sum(got) == _xor_sum(a)
 
 
+@pytest.mark.parametrize("radix", [2, 16, 64, 256])
+def test_satradix_large_degenerate_keys_keep_input_order(gpu, radix):
+    """2^22 (key, index) pairs whose keys are all equal / take two values: every
+    digit histogram has one or two huge bins; a stable sort returns the input
+    order inside each key."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = (1 << 22) + 321
+    idx = np.arange(n, dtype=np.uint64)
+    s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)", options="radix=%d" % radix)
+    same = (np.uint64(0xA5A5A5A5) << np.uint64(32)) | idx
+    assert np.array_equal(s.with_host_data(same, q), same)
+    two = (np.where(idx % 3 == 0, np.uint64(0xFFFFFFFF), np.uint64(0)) << np.uint64(32)) | idx
+    assert np.array_equal(s.with_host_data(two, q), O.stable_sort(two, key_size=4, key_shift=32))
+    s.close()
+
+
 @pytest.mark.parametrize("et,radix", [("float", 16), ("int", 256), ("double", 64)])
 def test_full_size_typed_radix_keys_2p26(gpu, et, radix):
     """2^26 signed / IEEE keys (negatives included) through the transform in the
