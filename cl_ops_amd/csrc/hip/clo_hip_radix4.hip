@@ -67,8 +67,11 @@ __device__ __forceinline__ void load_blocked(const E* __restrict__ p, E (&key)[I
 // inclusive scan inside a row of 16 lanes cannot exceed 16 * 15 = 240. Only
 // then do they widen to 16-bit fields for the two cross-row steps; v_perm_b32
 // builds w[j] = count(2j) | count(2j+1) << 16 from one even and one odd word.
-template <int BITS>
-__device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned (&w)[pc_words<BITS>::H]) {
+// TWO: the thread counted in two packed counters (up to 16 elements): their
+// 8-bit images are added first, and since 16 lanes * 16 could reach 256 the
+// last in-row step (row_shr:8) runs on the 16-bit fields.
+template <int BITS, bool TWO>
+__device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned long long c2, unsigned (&w)[pc_words<BITS>::H]) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int NB = (1 << BITS) == 16 ? 4 : 2;   // words of 8-bit fields
 	unsigned b[NB];
@@ -79,19 +82,29 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned (&w
 		b[2] = hi & 0x0f0f0f0fu;
 		b[3] = (hi >> 4) & 0x0f0f0f0fu;
 	}
+	if constexpr (TWO) {
+		const unsigned lo2 = (unsigned) c2, hi2 = (unsigned) (c2 >> 32);
+		b[0] += lo2 & 0x0f0f0f0fu;
+		b[1] += (lo2 >> 4) & 0x0f0f0f0fu;
+		if constexpr (NB == 4) {
+			b[2] += hi2 & 0x0f0f0f0fu;
+			b[3] += (hi2 >> 4) & 0x0f0f0f0fu;
+		}
+	}
 	#pragma unroll
 	for (int k = 0; k < NB; ++k) {
 		unsigned x = b[k];
 		x = dpp_add<0x111, 0xF>(x);
 		x = dpp_add<0x112, 0xF>(x);
 		x = dpp_add<0x114, 0xF>(x);
-		b[k] = dpp_add<0x118, 0xF>(x);
+		b[k] = TWO ? x : dpp_add<0x118, 0xF>(x);
 	}
 	#pragma unroll
 	for (int j = 0; j < H; ++j) {
 		// byte (j & 3) of the even word -> bits 0..15, of the odd word -> bits 16..31
 		const unsigned sel = 0x0c040c00u + (unsigned) (j & 3) * 0x00010001u;
 		unsigned x = __builtin_amdgcn_perm(b[(j >> 2) * 2 + 1], b[(j >> 2) * 2], sel);
+		if constexpr (TWO) x = dpp_add<0x118, 0xF>(x);
 		x = dpp_add<0x142, 0xA>(x);
 		w[j] = dpp_add<0x143, 0xC>(x);
 	}
@@ -109,20 +122,39 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 	const unsigned tbase = tid * ITEMS;
 	const bool full = count == (unsigned) (THREADS * ITEMS);
 
-	// thread-private counts, LAST element first (see the pass kernel above)
-	unsigned long long c = 0;
-	unsigned rr[ITEMS];   // 1 + number of LATER elements of the thread with the same digit
+	// thread-private counts, LAST element first: rr = 1 + the number of LATER
+	// elements of the thread with the same digit, so that the element's position
+	// is (end of the thread's slice of that digit) - rr. More than 8 elements
+	// per thread: two counters (4-bit fields hold up to 15).
+	static_assert(ITEMS == 8 || ITEMS == 16, "one or two packed counters");
+	unsigned long long c = 0, c2 = 0;
+	// ITEMS == 8: one register per rank; ITEMS == 16: (rank - 1) packed 4 bits each (register budget)
+	unsigned rr[ITEMS == 8 ? 8 : 2];
 	#pragma unroll
-	for (int i = ITEMS - 1; i >= 0; --i) {
-		rr[i] = 0;
+	for (int k = 0; k < (ITEMS == 8 ? 8 : 2); ++k) rr[k] = 0;
+	#pragma unroll
+	for (int i = ITEMS - 1; i >= 8; --i) {   // (ITEMS == 16 only)
 		if (full || tbase + i < count) {
 			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
-			c += 1ull << sh;
-			rr[i] = (unsigned) (c >> sh) & 15u;
+			rr[1] |= ((unsigned) (c2 >> sh) & 15u) << (4 * (i - 8));   // count BEFORE this element = rank - 1
+			c2 += 1ull << sh;
+		}
+	}
+	#pragma unroll
+	for (int i = 7; i >= 0; --i) {
+		if (full || tbase + i < count) {
+			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
+			if (ITEMS == 8) {
+				c += 1ull << sh;
+				rr[i] = (unsigned) (c >> sh) & 15u;
+			} else {
+				rr[0] |= ((((unsigned) (c >> sh) & 15u) + ((unsigned) (c2 >> sh) & 15u)) & 15u) << (4 * i);   // <= 15
+				c += 1ull << sh;
+			}
 		}
 	}
 	unsigned w[H];
-	pc2_wave_scan<BITS>(c, w);
+	pc2_wave_scan<BITS, (ITEMS > 8)>(c, c2, w);
 	if (lane == 63) {
 		#pragma unroll
 		for (int j = 0; j < H; ++j) s_wtot[wave][j] = w[j];
@@ -174,7 +206,8 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		if (full || tbase + i < count) {
 			const unsigned d = (unsigned) (key[i] >> dshift) & dmask;
 			const unsigned end = (s_end[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
-			s_stage[end - rr[i]] = key[i];   // (counts of these very elements: always inside the tile)
+			const unsigned back = ITEMS == 8 ? rr[i] : ((rr[i >> 3] >> (4 * (i & 7))) & 15u) + 1u;
+			s_stage[end - back] = key[i];   // (counts of these very elements: always inside the tile)
 		}
 	}
 	__syncthreads();
@@ -198,12 +231,12 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 // 2^28 8-byte elements 1.84 -> 0.86 ms per pass, 4-byte 0.79 -> 0.69 ms.
 // ---------------------------------------------------------------------------
 template <typename E> struct pair_shape {
-	static constexpr int THREADS = sizeof(E) == 8 ? 512 : 1024;   // 8 items per thread: tiles of 4096 / 8192 elements,
-	static constexpr int ITEMS = 8;                               // = the tiles of clo_hip_radixw.hip's histogram
+	static constexpr int THREADS = 512;                           // tiles of 8192 (<= 4-byte elements) / 4096 elements,
+	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;         // = the tiles of clo_hip_radixw.hip's histogram
 };
 
 template <typename E, int LB, int HB>
-__global__ __launch_bounds__(pair_shape<E>::THREADS)
+__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
@@ -541,7 +574,7 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 
 // static LDS of the pass kernel (introspection: clo_sort_get_localmem_usage)
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
-	const size_t threads = elem_size == 8 ? 512 : 1024;
+	const size_t threads = 512;
 	const int half = digit_bits <= 4 ? digit_bits : (digit_bits + 1) / 2;   // the wider of the two local digits
 	const size_t hmax = half >= 4 ? 8 : (half == 3 ? 4 : (half == 2 ? 2 : 1));
 	const size_t pass_bits = digit_bits <= 4 ? 2 * digit_bits : digit_bits;
