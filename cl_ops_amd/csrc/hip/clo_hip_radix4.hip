@@ -20,7 +20,7 @@
 // §4.1 has the numbers): chained look-back passes (latency-bound, 6.4 ms) ->
 // one digit per pass with the next digit's histogram fused into the scatter
 // (match-any ranking 5.3 ms, packed counters 3.94 ms) -> digit pairs with the
-// tile -> XCD mapping below (3.43 ms).
+// tile -> XCD mapping below (3.43 ms; 16 elements per thread 2.94 ms).
 #include <hip/hip_runtime.h>
 
 #include "clo_hip.h"
