@@ -94,6 +94,45 @@ __device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, 
 	}
 }
 
+// The same network when the direction bit is above every index bit the wave
+// (or work-group) spans: `dir` is then one scalar, and for whole-element integer
+// keys the exchange is a bare min/max pair under a scalar branch.
+template <typename E, int V, int MODE, bool UP>
+__device__ __forceinline__ void reg_network_minmax(E (&v)[V], int nsteps) {
+	typedef typename std::make_signed<E>::type S;
+	#pragma unroll
+	for (int half = V / 2; half >= 1; half /= 2) {
+		if (half < (1 << nsteps)) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j)
+				if ((j & half) == 0) {
+					E &a = v[j], &b = v[j + half];
+					const bool lt = MODE == 1 ? (a < b) : ((S) a < (S) b);
+					const E lo = lt ? a : b, hi = lt ? b : a;
+					a = UP ? lo : hi;
+					b = UP ? hi : lo;
+				}
+		}
+	}
+}
+template <typename E, int V, int MODE>
+__device__ __forceinline__ void reg_network_uniform(E (&v)[V], int nsteps, unsigned dir, const key_desc& kd) {
+	if (MODE == 0) {
+		#pragma unroll
+		for (int half = V / 2; half >= 1; half /= 2) {
+			if (half < (1 << nsteps)) {
+				#pragma unroll
+				for (int j = 0; j < V; ++j)
+					if ((j & half) == 0) cmpxch<E, 0>(v[j], v[j + half], dir, kd);
+			}
+		}
+	} else if ((dir ^ kd.descending) == 0) {
+		reg_network_minmax<E, V, MODE, true>(v, nsteps);
+	} else {
+		reg_network_minmax<E, V, MODE, false>(v, nsteps);
+	}
+}
+
 // ---- one launch per step (sbitonic.cl:38-69 / abit_any) ----
 template <typename E>
 __global__ __launch_bounds__(256)
@@ -121,7 +160,8 @@ void clo_bitonic_strided_kernel(E* __restrict__ data, size_t n, unsigned stage, 
 	E v[V];
 	#pragma unroll
 	for (int j = 0; j < V; ++j) v[j] = data[base + ((size_t) j << b0)];
-	reg_network<E, V, MODE>(v, NS, base, b0, stage, kd);
+	// bit `stage` of base is bit stage-NS >= b0 >= 6 of t: the same for the 64 lanes
+	reg_network_uniform<E, V, MODE>(v, NS, __builtin_amdgcn_readfirstlane((unsigned) ((base >> stage) & 1)), kd);
 	#pragma unroll
 	for (int j = 0; j < V; ++j) data[base + ((size_t) j << b0)] = v[j];
 }
@@ -153,6 +193,14 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));   // element alignment is all a caller guarantees
 	constexpr int PER = 16 / (int) sizeof(E);
 	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
+	// Whole-element integer keys, all stages of a tile (mode 1): an element whose
+	// stage direction is "down" is held COMPLEMENTED for that stage (the direction
+	// is a bit of the element's own index, so every thread agrees, also across the
+	// LDS exchanges), which makes every exchange of the stage an ascending min/max.
+	// The complement state moves at each stage's first group and is undone at the
+	// end. Any network gives the same result for these keys: equal keys are equal
+	// elements.
+	constexpr bool CPL = MODE != 0;
 	E v[V];
 	int cur_b0 = -1;
 	unsigned base = 0;
@@ -195,12 +243,35 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 				}
 				cur_b0 = (int) b0;
 			}
-			if (tid < nthr) reg_network<E, V, MODE>(v, nsteps, gbase + base, b0, S, kd);
+			if (tid < nthr) {
+				if (CPL && mode) {
+					// first group of a stage: move every element to the stage's complement state
+					if (p == S) {
+						#pragma unroll
+						for (int j = 0; j < V; ++j) {
+							const unsigned idx = (unsigned) gbase + base + ((unsigned) j << b0);
+							const unsigned f = (idx >> S) ^ (S == 1 ? kd.descending : (idx >> (S - 1)));
+							v[j] ^= (E) ((E) 0 - (E) (f & 1u));
+						}
+					}
+					reg_network_minmax<E, V, MODE, true>(v, nsteps);
+				}
+				// from stage kl up the direction bit is a bit of the tile number
+				else if (S >= kl) reg_network_uniform<E, V, MODE>(v, nsteps, (unsigned) ((gbase >> S) & 1), kd);
+				else reg_network<E, V, MODE>(v, nsteps, gbase + base, b0, S, kd);
+			}
 			p = b0;
 		}
 	}
 	// every schedule ends on steps Q..1, i.e. with b0 == 0: V consecutive elements per thread
 	if (tid < nthr) {
+		if (CPL && mode) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j) {
+				const unsigned f = (((unsigned) gbase + base + (unsigned) j) >> stage) ^ kd.descending;
+				v[j] ^= (E) ((E) 0 - (E) (f & 1u));
+			}
+		}
 		vec16* dst = reinterpret_cast<vec16*>(data + gbase + base);
 		#pragma unroll
 		for (int k = 0; k < V / PER; ++k) {
@@ -209,6 +280,118 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 			for (int q = 0; q < PER; ++q) t[q] = v[k * PER + q];
 			dst[k] = t;
 		}
+	}
+}
+
+// ---- the same for full tiles (kl == 8 + Q), schedule fixed at compile time ----
+// Every n >= 2^(8+Q) runs these: with the stage / group loops unrolled the
+// layouts are constants, so an LDS exchange is one thread base plus immediate
+// offsets (the run-time schedule spends 4 VALU per LDS access on addresses:
+// 422 VALU per element in the 91-step presort, SQ_INSTS_VALU) and the
+// complement-state masks are one XOR per element and stage.
+template <int A, int B, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+	if constexpr (A < B) {
+		f(std::integral_constant<int, A>());
+		static_for<A + 1, B>(f);
+	}
+}
+
+template <typename E, int Q, int MODE, bool PRESORT>
+__global__ __launch_bounds__(256)
+void clo_bitonic_tile_full_kernel(E* __restrict__ data, unsigned stage, key_desc kd) {
+	constexpr int V = 1 << Q;
+	constexpr int KL = 8 + Q;
+	constexpr int TILE = 256 * V;
+	constexpr bool CPL = MODE != 0 && PRESORT;
+	__shared__ E s[TILE + TILE / 32];
+	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
+	constexpr int PER = 16 / (int) sizeof(E);
+	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
+
+	const unsigned tid = threadIdx.x;
+	const size_t gbase = (size_t) blockIdx.x << KL;
+	// layout b0: value j of thread t is tile element tbase(b0) | (j << b0); the
+	// two parts share no bits, so the padded LDS slot is phys(tbase) + a constant
+	auto tbase = [&](int b0) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
+	auto phys = [](unsigned i) { return i + (i >> 5); };
+	E v[V];
+
+	auto exchange = [&](int from, int to) {
+		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
+		#pragma unroll
+		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
+		__syncthreads();
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
+	};
+	auto group = [&](int S, int b0, int nsteps, unsigned dir_uniform) {
+		if (CPL) reg_network_minmax<E, V, MODE, true>(v, nsteps);
+		else if (!PRESORT) reg_network_uniform<E, V, MODE>(v, nsteps, dir_uniform, kd);
+		else reg_network<E, V, MODE>(v, nsteps, gbase + tbase(b0), (unsigned) b0, (unsigned) S, kd);
+	};
+
+	if (PRESORT) {
+		{
+			const vec16* src = reinterpret_cast<const vec16*>(data + gbase + tbase(0));
+			#pragma unroll
+			for (int k = 0; k < V / PER; ++k) {
+				const vec16 t = src[k];
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) v[k * PER + q] = t[q];
+			}
+		}
+		static_for<1, KL + 1>([&](auto Sc) {
+			constexpr int S = decltype(Sc)::value;
+			static_for<0, (S + Q - 1) / Q>([&](auto gc) {
+				constexpr int g = decltype(gc)::value;
+				constexpr int p = S - g * Q;
+				constexpr int b0 = p > Q ? p - Q : 0;
+				constexpr int prev = g > 0 ? p : 0;   // the layout the values are in now
+				if (prev != b0) exchange(prev, b0);
+				if (CPL && g == 0) {
+					// move to stage S's complement state: bit S of the index (^ descending),
+					// coming from stage S-1's (nothing complemented before stage 1)
+					const unsigned tb = (unsigned) gbase + tbase(b0);
+					const unsigned ft = S == 1 ? ((tb >> 1) ^ kd.descending) : ((tb >> S) ^ (tb >> (S - 1)));
+					const E m0 = (E) ((E) 0 - (E) (ft & 1u)), m1 = (E) ~m0;
+					#pragma unroll
+					for (int j = 0; j < V; ++j) {
+						const unsigned ij = (unsigned) j << b0;
+						const unsigned fj = S == 1 ? (ij >> 1) : ((ij >> S) ^ (ij >> (S - 1)));
+						v[j] ^= (fj & 1u) ? m1 : m0;
+					}
+				}
+				group(S, b0, p - b0, 0u);
+			});
+		});
+		if (CPL && ((unsigned) (gbase >> KL) & 1u) != kd.descending) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j) v[j] = (E) ~v[j];
+		}
+	} else {
+		// steps KL..1 of `stage` (> KL: the direction is a bit of the tile number)
+		const unsigned dir = (unsigned) ((gbase >> stage) & 1);
+		{
+			const unsigned b = tbase(KL - Q);
+			#pragma unroll
+			for (int j = 0; j < V; ++j) v[j] = data[gbase + b + ((unsigned) j << (KL - Q))];
+		}
+		static_for<0, (KL + Q - 1) / Q>([&](auto gc) {
+			constexpr int g = decltype(gc)::value;
+			constexpr int p = KL - g * Q;
+			constexpr int b0 = p > Q ? p - Q : 0;
+			if (g > 0) exchange(p, b0);
+			group((int) stage, b0, p - b0, dir);
+		});
+	}
+	vec16* dst = reinterpret_cast<vec16*>(data + gbase + tbase(0));
+	#pragma unroll
+	for (int k = 0; k < V / PER; ++k) {
+		vec16 t;
+		#pragma unroll
+		for (int q = 0; q < PER; ++q) t[q] = v[k * PER + q];
+		dst[k] = t;
 	}
 }
 
@@ -320,7 +503,10 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	// stages 1..kl inside the tiles
 	{
 		clo_timing_scope timing("bitonic_presort", s);
-		hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
+		if (kl == KL_MAX)
+			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, MODE, true>), dim3(tiles), dim3(256), 0, s, data, kl, kd);
+		else
+			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
 	}
 	++count;
 	for (unsigned stage = kl + 1; stage <= T; ++stage) {
@@ -349,7 +535,8 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 		}
 		{
 			clo_timing_scope timing("bitonic_tile", s);
-			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, stage, kl, 0, kd);
+			// stage > kl only happens with full tiles (kl == KL_MAX)
+			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, MODE, false>), dim3(tiles), dim3(256), 0, s, data, stage, kd);
 		}
 		++count;
 	}
