@@ -306,10 +306,16 @@ unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never s
 // us of its 120 in that queue. Large arrays therefore use 1024-thread groups —
 // four times fewer tickets and look-back entries (2^26 uint -> ulong: 0.207 ->
 // 0.182 ms) — and small ones 256-thread groups, which spread over more CUs.
+// The large shape keeps 8 rows per thread whatever the sum type: 16 rows of
+// 4-byte sums need 108 VGPRs, which is ONE 16-wave group per CU, and a CU whose
+// only group sits in its look-back issues no loads (2^26 uint: 0.121 ms with 16
+// rows, 0.1135 with 8 — two groups per CU).
 constexpr size_t SCAN_BIG_NUMEL = (size_t) 1 << 24;
+constexpr int SCAN_BIG_ROWS = 8;
 constexpr int scan_threads(size_t numel) { return numel >= SCAN_BIG_NUMEL ? 1024 : 256; }
+constexpr int scan_small_rows(int sum_size) { return sum_size > 4 ? 8 : 16; }
 constexpr size_t scan_tile_elems(size_t numel, int sum_size) {
-	return (size_t) scan_threads(numel) * SCAN_VEC * (sum_size > 4 ? 8 : 16);
+	return (size_t) scan_threads(numel) * SCAN_VEC * (numel >= SCAN_BIG_NUMEL ? SCAN_BIG_ROWS : scan_small_rows(sum_size));
 }
 
 template <typename TIn, typename TOut>
@@ -318,7 +324,7 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		return CLO_HIP_EUNSUPPORTED;
 	} else {
 		typedef typename std::conditional<(sizeof(TOut) > 4), uint64_t, uint32_t>::type TSum;
-		constexpr int ROWS = sizeof(TOut) > 4 ? 8 : 16;
+		constexpr int ROWS = scan_small_rows((int) sizeof(TOut));
 		const size_t tile = scan_tile_elems(n, (int) sizeof(TOut));
 		const size_t tiles = (n + tile - 1) / tile;
 		unsigned* hdr = (unsigned*) ws;
@@ -332,7 +338,7 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		if (e != hipSuccess) return (int) e;
 		clo_timing_scope timing("scan", s);
 		if (scan_threads(n) == 1024)
-			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS, 1024>), dim3((unsigned) tiles), dim3(1024), 0, s,
+			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3((unsigned) tiles), dim3(1024), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
 				carry_in, carry_out, (unsigned) (tiles - 1));
 		else
