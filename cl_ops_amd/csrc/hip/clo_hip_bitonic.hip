@@ -283,8 +283,8 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 	}
 }
 
-// ---- the same for full tiles (kl == 8 + Q), schedule fixed at compile time ----
-// Every n >= 2^(8+Q) runs these: with the stage / group loops unrolled the
+// ---- full tiles of 2^(TB+Q) elements, 2^TB threads, schedule fixed at compile time ----
+// Every n >= 2^(TB+Q) runs these: with the stage / group loops unrolled the
 // layouts are constants, so an LDS exchange is one thread base plus immediate
 // offsets (the run-time schedule spends 4 VALU per LDS access on addresses:
 // 422 VALU per element in the 91-step presort, SQ_INSTS_VALU) and the
@@ -297,12 +297,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 	}
 }
 
-template <typename E, int Q, int MODE, bool PRESORT>
-__global__ __launch_bounds__(256)
+template <typename E, int Q, int TB, int MODE, bool PRESORT>
+__global__ __launch_bounds__(1 << TB)
 void clo_bitonic_tile_full_kernel(E* __restrict__ data, unsigned stage, key_desc kd) {
 	constexpr int V = 1 << Q;
-	constexpr int KL = 8 + Q;
-	constexpr int TILE = 256 * V;
+	constexpr int KL = TB + Q;
+	constexpr int TILE = V << TB;
 	constexpr bool CPL = MODE != 0 && PRESORT;
 	__shared__ E s[TILE + TILE / 32];
 	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
@@ -486,9 +486,14 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	int* launches, hipStream_t s) {
 	// register bits per thread: 32 values of <= 4 bytes, 16 values of 8 bytes
 	constexpr int Q = sizeof(E) == 8 ? 4 : 5;
-	constexpr unsigned KL_MAX = 8 + Q;
+	// Arrays of at least 2^KLF elements: 512-thread groups on tiles of 2^KLF
+	// (67 KiB of LDS, two groups per CU) with the compile-time schedule. Smaller
+	// ones are one tile, sorted by one launch of the run-time-schedule kernel.
+	constexpr int TBF = 9;
+	constexpr unsigned KLF = TBF + Q;
+	static_assert(KLF - 1 <= 8 + Q, "the run-time kernel covers every smaller array");
 	// strided passes need p - NS >= 6 so that a wave's 64 lanes read one
-	// contiguous row; KL_MAX >= 12 guarantees it for every p > KL_MAX.
+	// contiguous row; KLF >= 13 guarantees it for every p > KLF.
 	E* data = (E*) vdata;
 	key_desc kd; E pad;
 	int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
@@ -497,14 +502,14 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	const unsigned T = log2u(n);
 	if (T < (unsigned) Q) return simple_impl<E>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
 	pad_tail<E>(data, numel, n, pad, s);
-	const unsigned kl = T < KL_MAX ? T : KL_MAX;
+	const unsigned kl = T < KLF ? T : KLF;
 	const unsigned tiles = (unsigned) (n >> kl);
 	int count = 0;
 	// stages 1..kl inside the tiles
 	{
 		clo_timing_scope timing("bitonic_presort", s);
-		if (kl == KL_MAX)
-			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, MODE, true>), dim3(tiles), dim3(256), 0, s, data, kl, kd);
+		if (kl == KLF)
+			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, TBF, MODE, true>), dim3(tiles), dim3(1 << TBF), 0, s, data, kl, kd);
 		else
 			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
 	}
@@ -535,8 +540,8 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 		}
 		{
 			clo_timing_scope timing("bitonic_tile", s);
-			// stage > kl only happens with full tiles (kl == KL_MAX)
-			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, MODE, false>), dim3(tiles), dim3(256), 0, s, data, stage, kd);
+			// stage > kl only happens with full tiles (kl == KLF)
+			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, TBF, MODE, false>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, kd);
 		}
 		++count;
 	}
@@ -668,15 +673,15 @@ size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
 	if (!family) return 0;
 	const std::string f(family);
 	if (f == "bitonic_tile") {
-		const size_t v = elem_size == 8 ? 16 : 32;
-		return (256 * v + 256 * v / 32) * (size_t) elem_size;
+		const size_t v = elem_size == 8 ? 16 : 32;   // 512-thread groups
+		return (512 * v + 512 * v / 32) * (size_t) elem_size;
 	}
 	if (f == "radix_hist" || f == "radix_pass") {
 		const int bits = param < 1 ? 1 : (param > 8 ? 8 : param);
 		return f == "radix_hist" ? clo_radixw_lds_bytes(bits <= 4 ? 2 * bits : bits) : clo_radix4_lds_bytes(elem_size, bits);
 	}
 	if (f == "gselect") return GSEL_STAGE * sizeof(unsigned long long);
-	if (f == "scan") return (2 * (param > 4 ? 8 : 16) * 16 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;   // 1024-thread shape
+	if (f == "scan") return (2 * 8 * 16 + 1) * (size_t) (param > 4 ? 8 : 4) + 4;   // 1024-thread shape, 8 rows
 	return 0;  // bitonic_strided, bitonic_step: registers only
 }
 
