@@ -478,6 +478,32 @@ def test_bitonic_descending_compare(gpu, alg):
     assert np.array_equal(got, O.sbitonic(a, descending=True))
 
 
+@pytest.mark.parametrize("descending", [False, True])
+@pytest.mark.parametrize("et", ["uint", "int", "float", "ushort", "uchar", "long", "ulong", "double"])
+def test_abitonic_many_tiles_typed_and_descending(gpu, et, descending):
+    """2^17 elements = 8 (16 for 8-byte types) full tiles: the compile-time-schedule
+    presort (complement state for integer keys), the strided passes and the tile
+    merges, for every compare mode and both directions."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(17)
+    n = 1 << 17
+    if np.issubdtype(dt, np.floating):
+        a = ((rng.random(n) - 0.5) * 1e6).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        if dt == np.uint64:
+            a = rng.integers(0, info.max, n, dtype=np.uint64, endpoint=True)
+        else:
+            a = rng.integers(info.min, info.max, n, dtype=np.int64, endpoint=True).astype(dt)
+    s = clo.Sorter("abitonic", ctx, et, compare="((a) < (b))" if descending else None)
+    got = s.with_host_data(a, q)
+    s.close()
+    exp = np.sort(a)
+    assert np.array_equal(got, exp[::-1] if descending else exp)
+
+
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
 @pytest.mark.parametrize("n", [3, 100, 5000, 70000])
 def test_bitonic_non_power_of_two(gpu, alg, n):

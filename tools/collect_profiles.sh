@@ -18,9 +18,11 @@ for w in satradix_u32 satradix_pairs scan abitonic; do
 		python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_$w.json" 2> "$OUT/trace_$w.log" || exit 1
 	echo "trace $w done"
 done
-# HBM traffic of the headline workload: one counter per run, kernel trace only
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" --output-format csv -- \
-	python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/fetch.json" 2> "$OUT/fetch.log" || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" --output-format csv -- \
-	python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/write.json" 2> "$OUT/write.log" || exit 1
-echo "pmc done"
+# HBM traffic (headline workload first): one counter per run, kernel trace only
+for w in satradix_u32 scan abitonic; do
+	for c in FETCH_SIZE WRITE_SIZE; do
+		rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_$w" --output-format csv -- \
+			python3 "$ROOT/bench.py" --workload $w --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${c}_$w.json" 2> "$OUT/pmc_${c}_$w.log" || exit 1
+	done
+	echo "pmc $w done"
+done

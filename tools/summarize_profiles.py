@@ -27,15 +27,12 @@ for w, out in names.items():
         shutil.copy(max(st, key=os.path.getmtime), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, out)))
 
 
-def pmc(kind):
-    f = max(glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")), key=os.path.getmtime)
+def pmc(counter, workload):
+    f = max(glob.glob(os.path.join(src, "pmc_%s_%s" % (counter, workload), "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
-
-
-fetch, write = pmc("fetch"), pmc("write")
 
 
 def short(k):
@@ -43,24 +40,33 @@ def short(k):
     return k.split("(")[0].strip()
 
 
-rows = []
-for k in fetch:
-    n, f = fetch[k]
-    w = write.get(k, (0, 0.0))[1]
-    rows.append((short(k), n, f, w, int((2 * f + w) * 1024)))
-rows.sort(key=lambda r: -r[4] * r[1])
+def traffic_rows(workload):
+    fetch, write = pmc("FETCH_SIZE", workload), pmc("WRITE_SIZE", workload)
+    rows = []
+    for k in fetch:
+        n, f = fetch[k]
+        w = write.get(k, (0, 0.0))[1]
+        rows.append((short(k), n, f, w, int((2 * f + w) * 1024)))
+    rows.sort(key=lambda r: -r[4] * r[1])
+    return rows
+
+
+HEADER = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs, each with --kernel-trace only) of\n"
+          "#   python3 bench.py --workload %s --steps 2 --warmup 1 --no-cpu-baseline, MI355X\n"
+          "# Counter unit: KB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests as 64 B, i.e.\n"
+          "# reports 1/2 of a coalesced streaming read. %s WRITE_SIZE is taken as is.\n"
+          "kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+
+# ---- headline: satradix, 2^28 uint32 keys ----
+rows = traffic_rows("satradix_u32")
 hist = [r for r in rows if "tilehist" in r[0] and "unsigned int" in r[0]]
 pas = [r for r in rows if "pair_kernel" in r[0] and "unsigned int" in r[0]]
 n_keys = 1 << 28
 calib = (n_keys * 4 / 1024) / hist[0][2] if hist else float("nan")
 path = os.path.join(dst, "%s_satradix_u32_2p28_pmc_hbm_traffic.csv" % tag)
 with open(path, "w") as o:
-    o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs, each with --kernel-trace only) of\n")
-    o.write("#   python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (satradix, 2^28 uint32 keys, radix 16), MI355X\n")
-    o.write("# Counter unit: KB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests as 64 B, i.e.\n")
-    o.write("# reports 1/2 of a coalesced streaming read. Calibration in this very run: the histogram kernel reads exactly\n")
-    o.write("# 2^28*4 B = 1048576 KB and reports %.0f KB -> factor %.3f (2.0 used). WRITE_SIZE is taken as is.\n" % (hist[0][2] if hist else 0, calib))
-    o.write("kernel,launches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+    o.write(HEADER % ("satradix_u32", "Calibration in this very run: the histogram kernel reads exactly 2^28*4 B = 1048576 KB "
+                                      "and reports %.0f KB -> factor %.3f (2.0 used)." % (hist[0][2] if hist else 0, calib)))
     for r in rows:
         o.write("%s,%d,%.0f,%.0f,%d\n" % r)
 if pas:
@@ -71,3 +77,23 @@ if pas:
 print("profiles/ refreshed from", src)
 for r in rows[:6]:
     print(r)
+
+# ---- scan and abitonic: the dominant kernel of each ----
+for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_full_kernel")):
+    try:
+        rows = traffic_rows(workload)
+    except ValueError:
+        continue   # no PMC pass for this workload in gpurun_out/<tag>
+    path = os.path.join(dst, "%s_%s_pmc_hbm_traffic.csv" % (tag, workload))
+    with open(path, "w") as o:
+        o.write(HEADER % (workload, "(Same x2 as calibrated on the satradix histogram kernel.)"))
+        for r in rows:
+            o.write("%s,%d,%.0f,%.0f,%d\n" % r)
+    dom = [r for r in rows if needle in r[0]]
+    if dom:
+        d = max(dom, key=lambda r: r[1])   # the merge launches outnumber the presort
+        json.dump({"kernel": d[0], "hbm_bytes_per_launch": d[4], "fetch_size_kb": d[2], "write_size_kb": d[3],
+                   "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as is", "source": "profiles/" + os.path.basename(path)},
+                  open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
+    for r in rows[:4]:
+        print(workload, r)
