@@ -284,6 +284,7 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 }
 
 // ---- full tiles of 2^(TB+Q) elements, 2^TB threads, schedule fixed at compile time ----
+// (all of stages 1..TB+Q: the presort; the merge passes follow)
 // Every n >= 2^(TB+Q) runs these: with the stage / group loops unrolled the
 // layouts are constants, so an LDS exchange is one thread base plus immediate
 // offsets (the run-time schedule spends 4 VALU per LDS access on addresses:
@@ -297,13 +298,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 	}
 }
 
-template <typename E, int Q, int TB, int MODE, bool PRESORT>
+template <typename E, int Q, int TB, int MODE>
 __global__ __launch_bounds__(1 << TB)
-void clo_bitonic_tile_full_kernel(E* __restrict__ data, unsigned stage, key_desc kd) {
+void clo_bitonic_tile_presort_kernel(E* __restrict__ data, key_desc kd) {
 	constexpr int V = 1 << Q;
 	constexpr int KL = TB + Q;
 	constexpr int TILE = V << TB;
-	constexpr bool CPL = MODE != 0 && PRESORT;
+	constexpr bool CPL = MODE != 0;
 	__shared__ E s[TILE + TILE / 32];
 	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
 	constexpr int PER = 16 / (int) sizeof(E);
@@ -325,22 +326,30 @@ void clo_bitonic_tile_full_kernel(E* __restrict__ data, unsigned stage, key_desc
 		#pragma unroll
 		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
 	};
-	auto group = [&](int S, int b0, int nsteps, unsigned dir_uniform) {
+	auto group = [&](int S, int b0, int nsteps) {
 		if (CPL) reg_network_minmax<E, V, MODE, true>(v, nsteps);
-		else if (!PRESORT) reg_network_uniform<E, V, MODE>(v, nsteps, dir_uniform, kd);
 		else reg_network<E, V, MODE>(v, nsteps, gbase + tbase(b0), (unsigned) b0, (unsigned) S, kd);
 	};
 
-	if (PRESORT) {
-		{
-			const vec16* src = reinterpret_cast<const vec16*>(data + gbase + tbase(0));
+	// In and out through LDS: the first and last layouts give a thread V
+	// consecutive elements, and 16-byte accesses at a lane stride of V elements
+	// are 64 partial cache lines per instruction; transposed, a wave moves 1 KiB
+	// contiguous (the merge passes: 111 -> 83 us per 2^26 uint32).
+	{
+		const vec16* src = reinterpret_cast<const vec16*>(data + gbase) + tid;
+		#pragma unroll
+		for (int k = 0; k < V / PER; ++k) {
+			const vec16 t = src[(unsigned) k << TB];
+			const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);   // PER consecutive slots: no multiple of 32 inside
 			#pragma unroll
-			for (int k = 0; k < V / PER; ++k) {
-				const vec16 t = src[k];
-				#pragma unroll
-				for (int q = 0; q < PER; ++q) v[k * PER + q] = t[q];
-			}
+			for (int q = 0; q < PER; ++q) s[pe + q] = t[q];
 		}
+		__syncthreads();
+		const unsigned pt = phys(tbase(0));
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = s[pt + (unsigned) j];
+	}
+	{
 		static_for<1, KL + 1>([&](auto Sc) {
 			constexpr int S = decltype(Sc)::value;
 			static_for<0, (S + Q - 1) / Q>([&](auto gc) {
@@ -362,36 +371,110 @@ void clo_bitonic_tile_full_kernel(E* __restrict__ data, unsigned stage, key_desc
 						v[j] ^= (fj & 1u) ? m1 : m0;
 					}
 				}
-				group(S, b0, p - b0, 0u);
+				group(S, b0, p - b0);
 			});
 		});
 		if (CPL && ((unsigned) (gbase >> KL) & 1u) != kd.descending) {
 			#pragma unroll
 			for (int j = 0; j < V; ++j) v[j] = (E) ~v[j];
 		}
-	} else {
-		// steps KL..1 of `stage` (> KL: the direction is a bit of the tile number)
-		const unsigned dir = (unsigned) ((gbase >> stage) & 1);
-		{
-			const unsigned b = tbase(KL - Q);
+	}
+	{
+		const unsigned pf = phys(tbase(0));
+		#pragma unroll
+		for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
+		__syncthreads();
+		vec16* dst = reinterpret_cast<vec16*>(data + gbase) + tid;
+		#pragma unroll
+		for (int k = 0; k < V / PER; ++k) {
+			const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);
+			vec16 t;
 			#pragma unroll
-			for (int j = 0; j < V; ++j) v[j] = data[gbase + b + ((unsigned) j << (KL - Q))];
+			for (int q = 0; q < PER; ++q) t[q] = s[pe + q];
+			dst[(unsigned) k << TB] = t;
 		}
+	}
+}
+
+// ---- steps KL..1 of one stage > KL on full tiles: the merge passes ----
+// The direction of a whole tile is one bit of its number. A work-group walks
+// over several tiles and requests the next tile's values (32 more registers)
+// before it exchanges the current one through LDS: with one tile per group the
+// CU's loads stop while its two groups compute and exchange (measured: 105 us
+// per pass of 2^26 uint32, 11 waves resident on average; the strided passes,
+// which never stop loading, take 76 us).
+template <typename E, int Q, int TB, int MODE>
+__global__ __launch_bounds__(1 << TB)
+void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned tiles, unsigned stage, key_desc kd) {
+	constexpr int V = 1 << Q;
+	constexpr int KL = TB + Q;
+	constexpr int TILE = V << TB;
+	__shared__ E s[TILE + TILE / 32];
+	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
+	constexpr int PER = 16 / (int) sizeof(E);
+	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
+
+	const unsigned tid = threadIdx.x;
+	auto tbase = [&](int b0) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
+	auto phys = [](unsigned i) { return i + (i >> 5); };
+	E v[V], nxt[V];
+	auto exchange = [&](int from, int to) {
+		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
+		#pragma unroll
+		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
+		__syncthreads();
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
+	};
+	const unsigned first_b = tbase(KL - Q);   // first group: register bits [KL-Q, KL), lanes read adjacent elements
+	unsigned tile = blockIdx.x;
+	if (tile >= tiles) return;
+	{
+		const E* src = data + ((size_t) tile << KL) + first_b;
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = src[(unsigned) j << (KL - Q)];
+	}
+	while (true) {
+		const size_t gbase = (size_t) tile << KL;
+		const unsigned dir = (unsigned) ((gbase >> stage) & 1);
+		const unsigned next = tile + gridDim.x;
+		const bool more = next < tiles;
 		static_for<0, (KL + Q - 1) / Q>([&](auto gc) {
 			constexpr int g = decltype(gc)::value;
 			constexpr int p = KL - g * Q;
 			constexpr int b0 = p > Q ? p - Q : 0;
 			if (g > 0) exchange(p, b0);
-			group((int) stage, b0, p - b0, dir);
+			reg_network_uniform<E, V, MODE>(v, p - b0, dir, kd);
+			if (g == 0 && more) {
+				const E* src = data + ((size_t) next << KL) + first_b;
+				#pragma unroll
+				for (int j = 0; j < V; ++j) nxt[j] = src[(unsigned) j << (KL - Q)];
+			}
 		});
-	}
-	vec16* dst = reinterpret_cast<vec16*>(data + gbase + tbase(0));
-	#pragma unroll
-	for (int k = 0; k < V / PER; ++k) {
-		vec16 t;
+		// out through LDS once more: in the last layout a thread holds V consecutive
+		// elements, and 16-byte stores at a lane stride of V elements are 64 partial
+		// cache lines per instruction; transposed, a wave stores 1 KiB contiguous
+		{
+			const unsigned pf = phys(tbase(0));
+			#pragma unroll
+			for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
+			__syncthreads();
+			vec16* dst = reinterpret_cast<vec16*>(data + gbase) + tid;
+			#pragma unroll
+			for (int k = 0; k < V / PER; ++k) {
+				const unsigned e = ((unsigned) k << TB) * PER + tid * PER;   // PER consecutive slots: no multiple of 32 inside
+				const unsigned pe = phys(e);
+				vec16 t;
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) t[q] = s[pe + q];
+				dst[(unsigned) k << TB] = t;
+			}
+		}
+		if (!more) break;
 		#pragma unroll
-		for (int q = 0; q < PER; ++q) t[q] = v[k * PER + q];
-		dst[k] = t;
+		for (int j = 0; j < V; ++j) v[j] = nxt[j];
+		tile = next;
+		__syncthreads();   // the slots this thread writes next were last read by other threads
 	}
 }
 
@@ -491,6 +574,7 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	// ones are one tile, sorted by one launch of the run-time-schedule kernel.
 	constexpr int TBF = 9;
 	constexpr unsigned KLF = TBF + Q;
+	constexpr unsigned MERGE_GROUPS = 512;   // two per CU, each walks over tiles / 512 tiles
 	static_assert(KLF - 1 <= 8 + Q, "the run-time kernel covers every smaller array");
 	// strided passes need p - NS >= 6 so that a wave's 64 lanes read one
 	// contiguous row; KLF >= 13 guarantees it for every p > KLF.
@@ -509,7 +593,7 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	{
 		clo_timing_scope timing("bitonic_presort", s);
 		if (kl == KLF)
-			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, TBF, MODE, true>), dim3(tiles), dim3(1 << TBF), 0, s, data, kl, kd);
+			hipLaunchKernelGGL((clo_bitonic_tile_presort_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, kd);
 		else
 			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
 	}
@@ -517,11 +601,12 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	for (unsigned stage = kl + 1; stage <= T; ++stage) {
 		unsigned p = stage;
 		while (p > kl) {
-			// register bits of a strided pass: one or two more than the tile kernel's
-			// (identity keys, <= 4 bytes: 128 values per thread, 412 VGPRs, one wave per
-			// SIMD — these passes only stream, 19 of them instead of 24 at 2^26; the
-			// general compare needs more temporaries and would spill at that size)
-			constexpr int QS = MODE == 0 ? Q + 1 : Q + 2;
+			// register bits of a strided pass: 64 values per thread for identity keys,
+			// one wave per SIMD — these passes only stream (76 us per 2^26 uint32). The
+			// general compare needs more temporaries: 32 (16 of 8 bytes). 128 values
+			// were measured too: 100-117 us per pass (412 VGPRs and up, spills), which
+			// costs more over a sort than the one pass it saves.
+			constexpr int QS = MODE == 0 ? Q + 1 : 6;
 			unsigned ns = p - kl;
 			if (ns > (unsigned) QS) ns = QS;
 			switch (ns) {
@@ -530,9 +615,8 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 				case 3: launch_strided<E, 3, MODE>(data, n, stage, p, kd, s); break;
 				case 4: launch_strided<E, 4, MODE>(data, n, stage, p, kd, s); break;
 				case 5: launch_strided<E, 5, MODE>(data, n, stage, p, kd, s); break;
-				case 6: launch_strided<E, 6, MODE>(data, n, stage, p, kd, s); break;
 				default:
-					if constexpr (QS >= 7) launch_strided<E, 7, MODE>(data, n, stage, p, kd, s);
+					if constexpr (QS >= 6) launch_strided<E, 6, MODE>(data, n, stage, p, kd, s);
 					break;
 			}
 			++count;
@@ -541,7 +625,8 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 		{
 			clo_timing_scope timing("bitonic_tile", s);
 			// stage > kl only happens with full tiles (kl == KLF)
-			hipLaunchKernelGGL((clo_bitonic_tile_full_kernel<E, Q, TBF, MODE, false>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, kd);
+			hipLaunchKernelGGL((clo_bitonic_tile_merge_kernel<E, Q, TBF, MODE>), dim3(tiles < MERGE_GROUPS ? tiles : MERGE_GROUPS), dim3(1 << TBF), 0, s,
+				data, tiles, stage, kd);
 		}
 		++count;
 	}

@@ -79,7 +79,7 @@ for r in rows[:6]:
     print(r)
 
 # ---- scan and abitonic: the dominant kernel of each ----
-for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_full_kernel")):
+for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_merge_kernel")):
     try:
         rows = traffic_rows(workload)
     except ValueError:
