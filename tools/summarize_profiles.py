@@ -97,3 +97,22 @@ for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_merge_k
                   open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
     for r in rows[:4]:
         print(workload, r)
+
+# ---- the C harnesses' sweeps ----
+NOTES = {
+    "satradix": "benchmarks/bin/clo_hip_sort_bench -a satradix -t uint -n 28 -r 5",
+    "abitonic": "benchmarks/bin/clo_hip_sort_bench -a abitonic -t uint -n 26 -r 5",
+    "sbitonic": "benchmarks/bin/clo_hip_sort_bench -a sbitonic -t uint -n 20 -r 5",
+    "gselect": "benchmarks/bin/clo_hip_sort_bench -a gselect -t uint -n 16 -r 5",
+    "scan": "benchmarks/bin/clo_hip_scan_bench -t uint -y uint -n 27 -r 5",
+}
+for alg, cmd in NOTES.items():
+    f = os.path.join(src, "harness_%s.txt" % alg)
+    if not os.path.exists(f):
+        continue
+    with open(os.path.join(dst, "%s_harness_sweep_%s.txt" % (tag, alg)), "w") as o:
+        o.write("# %s on one MI355X (the reference harness's CLI and conventions: host data in, exec-queue device time "
+                "only, 5 runs per size; every run follows a fresh host-to-device copy, so these are cold-clock single-call "
+                "numbers, below bench.py's back-to-back steps). The scan pipelines 2^22-element chunks from 2^24 elements on: "
+                "its device time is the sum of the chunk scans.\n" % cmd)
+        o.write(open(f).read())
