@@ -47,6 +47,8 @@ __device__ __forceinline__ unsigned dpp_add(unsigned x) {
 	return x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true);
 }
 
+constexpr int PC_END_STRIDE = 9;   // dwords per thread in the table of ends: 8 words of two digits each, padded to an odd stride
+
 template <int BITS> struct pc_words { static constexpr int H = (1 << BITS) >= 2 ? (1 << BITS) / 2 : 1; };
 
 template <typename E, int ITEMS>
@@ -115,7 +117,7 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned lon
 // thread's elements are ITEMS consecutive positions of the tile.
 template <typename E, int BITS, int THREADS, int ITEMS, int HMAX>
 __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
-	E* s_stage, unsigned (*s_end)[THREADS], unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX]) {
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX]) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -200,12 +202,16 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 	}
 	__syncthreads();
 	#pragma unroll
-	for (int j = 0; j < H; ++j) s_end[j][tid] = w[j] + s_wbase[wave][j];
+	// the thread's 16-bit ends, thread-major with a stride of PC_END_STRIDE dwords
+	// (odd: the lanes' rows start in different banks): the lookup per element is
+	// one address (digit * 2 + row) and one ds_read_u16
+	for (int j = 0; j < H; ++j) s_end[tid * PC_END_STRIDE + j] = w[j] + s_wbase[wave][j];
+	const unsigned short* s_end16 = reinterpret_cast<const unsigned short*>(s_end) + tid * (2 * PC_END_STRIDE);
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		if (full || tbase + i < count) {
 			const unsigned d = (unsigned) (key[i] >> dshift) & dmask;
-			const unsigned end = (s_end[d >> 1][tid] >> ((d & 1u) * 16u)) & 0xffffu;
+			const unsigned end = s_end16[d];
 			const unsigned back = ITEMS == 8 ? rr[i] : ((rr[i >> 3] >> (4 * (i & 7))) & 15u) + 1u;
 			s_stage[end - back] = key[i];   // (counts of these very elements: always inside the tile)
 		}
@@ -251,7 +257,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	static_assert(R2 <= 256 && R2 <= THREADS, "one thread per combined digit, scanned by the first four waves");
 
 	__shared__ E s_stage[TILE];
-	__shared__ unsigned s_end[HMAX][THREADS];
+	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][HMAX];
 	__shared__ unsigned s_wbase[WAVES][HMAX];
 	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
@@ -372,7 +378,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = SMALL_THREADS / 64;
 	__shared__ E s_stage[SMALL_TILE];
-	__shared__ unsigned s_end[H][SMALL_THREADS];
+	__shared__ unsigned s_end[SMALL_THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][H];
 	__shared__ unsigned s_wbase[WAVES][H];
 
@@ -578,7 +584,8 @@ size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
 	const int half = digit_bits <= 4 ? digit_bits : (digit_bits + 1) / 2;   // the wider of the two local digits
 	const size_t hmax = half >= 4 ? 8 : (half == 3 ? 4 : (half == 2 ? 2 : 1));
 	const size_t pass_bits = digit_bits <= 4 ? 2 * digit_bits : digit_bits;
-	return threads * 8 * (size_t) elem_size + hmax * threads * sizeof(unsigned)
+	const size_t items = elem_size == 8 ? 8 : 16;
+	return threads * items * (size_t) elem_size + threads * PC_END_STRIDE * sizeof(unsigned)
 		+ (2 * (threads / 64) * hmax + ((size_t) 1 << pass_bits) + 4) * sizeof(unsigned);
 }
 
