@@ -11,7 +11,10 @@
 //   2. the pairs are sorted by their high word with the ordinary radix passes
 //      (stable; the index in the low word is carried along);
 //   3. a gather kernel writes out[j] = x[pair[j] & 0xffffffff].
-// Keys of up to 4 bytes (the pair is 64 bits), numel < 2^32 as everywhere.
+// The pair is 64 bits, so a key of 8 bytes takes two rounds, least significant
+// half first: round one sorts (low key half, index); a second compiled kernel
+// then builds (high key half of x[index], index) IN THAT ORDER, and the stable
+// sort of those by the high half finishes the order. numel < 2^32 as everywhere.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
@@ -34,11 +37,7 @@ typedef CLO_SORT_ELEM_TYPE E;
 typedef CLO_SORT_KEY_TYPE K;
 typedef CLO_SORT_KEY_BITS_TYPE UK;   // unsigned integer of the key's size
 
-extern "C" __global__ __launch_bounds__(256)
-void jit_extract(const E* __restrict__ in, unsigned long long* __restrict__ pairs, unsigned long n) {
-	const unsigned long i = (unsigned long) blockIdx.x * 256 + threadIdx.x;
-	if (i >= n) return;
-	const E x = in[i];
+__device__ __forceinline__ UK jit_ordered_key(const E x) {
 	const K k = (K) (CLO_SORT_KEY_GET_X(x));
 	UK u;
 	__builtin_memcpy(&u, &k, sizeof(k));
@@ -48,13 +47,33 @@ void jit_extract(const E* __restrict__ in, unsigned long long* __restrict__ pair
 #elif CLO_SORT_KEY_KIND == 2
 	u = (u & sign) ? (UK) ~u : (UK) (u | sign);  // IEEE-754
 #endif
-	pairs[i] = ((unsigned long long) u << 32) | (unsigned long long) (unsigned) i;
+	return u;
+}
+
+// pairs[i] = (low 32 bits of the ordered key, i)  — the whole key when it has <= 32 bits
+extern "C" __global__ __launch_bounds__(256)
+void jit_extract(const E* __restrict__ in, unsigned long long* __restrict__ pairs, unsigned long n) {
+	const unsigned long i = (unsigned long) blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long u = (unsigned long long) jit_ordered_key(in[i]);
+	pairs[i] = (u << 32) | (unsigned long long) (unsigned) i;
+}
+
+// 8-byte keys, second round: out[i] = (high 32 bits of the ordered key of x[j], j), j = index in pairs[i]
+extern "C" __global__ __launch_bounds__(256)
+void jit_extract_hi(const E* __restrict__ in, const unsigned long long* __restrict__ pairs,
+	unsigned long long* __restrict__ out, unsigned long n) {
+	const unsigned long i = (unsigned long) blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const unsigned j = (unsigned) pairs[i];
+	const unsigned long long u = (unsigned long long) jit_ordered_key(in[(unsigned long) j < n ? j : 0]);
+	out[i] = (u & 0xffffffff00000000ull) | (unsigned long long) j;
 }
 )CLOJIT";
 
 struct radix_jit {
 	hipModule_t module = nullptr;
-	hipFunction_t extract = nullptr;
+	hipFunction_t extract = nullptr, extract_hi = nullptr;
 	int elem_size = 0, key_size = 0;
 };
 
@@ -99,11 +118,7 @@ int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, v
 	const char* kt = ctype_of(key_type);
 	if (!et || !kt) return CLO_HIP_EUNSUPPORTED;
 	const int ks = type_size(key_type);
-	if (ks > 4) {
-		set_log(log, "a run-time compiled get_key needs a key type of at most 4 bytes for satradix");
-		return CLO_HIP_EUNSUPPORTED;
-	}
-	const char* uk = ks == 1 ? "unsigned char" : (ks == 2 ? "unsigned short" : "unsigned int");
+	const char* uk = ks == 1 ? "unsigned char" : (ks == 2 ? "unsigned short" : (ks == 4 ? "unsigned int" : "unsigned long"));
 
 	std::string src;
 	src += std::string("#define CLO_SORT_ELEM_TYPE ") + et + "\n";
@@ -139,6 +154,7 @@ int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, v
 	rj->key_size = ks;
 	hipError_t e = hipModuleLoadData(&rj->module, code.data());
 	if (e == hipSuccess) e = hipModuleGetFunction(&rj->extract, rj->module, "jit_extract");
+	if (e == hipSuccess) e = hipModuleGetFunction(&rj->extract_hi, rj->module, "jit_extract_hi");
 	if (e != hipSuccess) {
 		set_log(log, std::string("loading the compiled module failed: ") + hipGetErrorString(e));
 		if (rj->module) (void) hipModuleUnload(rj->module);
@@ -171,14 +187,29 @@ int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs
 		const hipError_t e = hipModuleLaunchKernel(rj->extract, blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
 		if (e != hipSuccess) return (int) e;
 	}
-	const int st = clo_hip_radix_sort(pairs, pairs, pairs_tmp, numel, 8, 32, 8 * rj->key_size, 0, digit_bits,
+	const int low_bits = rj->key_size >= 4 ? 32 : 8 * rj->key_size;
+	int st = clo_hip_radix_sort(pairs, pairs, pairs_tmp, numel, 8, 32, low_bits, 0, digit_bits,
 		workspace, workspace_bytes, stream);
 	if (st != 0) return st;
-	// gather through pairs_tmp when sorting in place (numel * 8 bytes >= numel * elem_size)
-	void* out = dst == src ? pairs_tmp : dst;
+	void* sorted = pairs;      // where the sorted (key, index) pairs are
+	void* spare = pairs_tmp;   // the other pair buffer
+	if (rj->key_size == 8) {
+		{
+			clo_timing_scope timing("radix_extract", s);
+			void* args[] = { (void*) &src, &pairs, &pairs_tmp, &n };
+			const hipError_t e = hipModuleLaunchKernel(rj->extract_hi, blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+			if (e != hipSuccess) return (int) e;
+		}
+		st = clo_hip_radix_sort(pairs_tmp, pairs_tmp, pairs, numel, 8, 32, 32, 0, digit_bits, workspace, workspace_bytes, stream);
+		if (st != 0) return st;
+		sorted = pairs_tmp;
+		spare = pairs;
+	}
+	// gather through the spare pair buffer when sorting in place (numel * 8 bytes >= numel * elem_size)
+	void* out = dst == src ? spare : dst;
 	{
 		clo_timing_scope timing("radix_gather", s);
-		const unsigned long long* p = (const unsigned long long*) pairs;
+		const unsigned long long* p = (const unsigned long long*) sorted;
 		switch (rj->elem_size) {
 			case 1: hipLaunchKernelGGL((clo_radix_gather_kernel<uint8_t>), dim3(blocks), dim3(256), 0, s, (const uint8_t*) src, p, (uint8_t*) out, numel); break;
 			case 2: hipLaunchKernelGGL((clo_radix_gather_kernel<uint16_t>), dim3(blocks), dim3(256), 0, s, (const uint16_t*) src, p, (uint16_t*) out, numel); break;

@@ -184,7 +184,8 @@ int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, 
 /* ---- satradix specialised at run time (hiprtc) for a get_key expression
  *      outside the ahead-of-time family: the key is materialised as
  *      (ordered key bits << 32 | index) pairs by a compiled kernel, the pairs are
- *      radix-sorted, the elements gathered. Key types of up to 4 bytes.
+ *      radix-sorted, the elements gathered. 8-byte keys take two such rounds
+ *      (low half of the key, then the high half in the first round's order).
  *      pairs / pairs_tmp: numel * 8 bytes each; workspace as for
  *      clo_hip_radix_workspace_bytes(numel, 8, 32, digit_bits). ---- */
 int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, void** handle, char** log);
