@@ -10,8 +10,9 @@
 //     one 16-byte (u32) coalesced vector load per lane and row, kept in VGPRs;
 //   * in-lane prefix of the 4 elements, wave64 shuffle scan of the lane sums,
 //     cross-wave/row offsets through 1 KiB of LDS;
-//   * tiles are handed out by a ticket (atomicAdd) so tile ids follow dispatch
-//     order; the running prefix travels tile to tile by decoupled look-back on
+//   * as many work-groups as the chip holds at once; each draws tiles by ticket
+//     (atomicAdd) until none is left, so tile ids follow the order in which the
+//     tiles are started; the running prefix travels tile to tile by decoupled look-back on
 //     8-byte {tag,value} granules with agent-scope relaxed loads/stores
 //     (per-XCD L2s are not coherent: clo_hip_internal.h).
 //
@@ -165,9 +166,11 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-	if (tid == 0) s_tile = (xflags & 2u) ? blockIdx.x : atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
 	// value carried into this call (a chunk of a longer array): added to every output
 	const TSum carry = carry_in ? (TSum) *carry_in : (TSum) 0;
+	// a work-group draws tiles until none is left (it holds one ticket at a time)
+	for (;;) {
+	if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
 	__syncthreads();
 	const unsigned tile = s_tile;
 	const size_t base = (size_t) tile * TILE;
@@ -295,6 +298,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 			}
 		}
 	}
+	__syncthreads();   // s_tile, s_part, s_off, s_excl are reused
+	}
 }
 
 unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never set in production
@@ -337,12 +342,14 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16 + supers * 48, s);
 		if (e != hipSuccess) return (int) e;
 		clo_timing_scope timing("scan", s);
+		// as many work-groups as fit the chip at once; each draws tiles until none is left
+		const unsigned groups_big = (unsigned) (tiles < 512 ? tiles : 512), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
 		if (scan_threads(n) == 1024)
-			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3((unsigned) tiles), dim3(1024), 0, s,
+			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3(groups_big), dim3(1024), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
 				carry_in, carry_out, (unsigned) (tiles - 1));
 		else
-			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS, 256>), dim3((unsigned) tiles), dim3(256), 0, s,
+			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS, 256>), dim3(groups_small), dim3(256), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
 				carry_in, carry_out, (unsigned) (tiles - 1));
 		return (int) hipGetLastError();
