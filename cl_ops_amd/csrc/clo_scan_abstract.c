@@ -37,6 +37,23 @@ typedef struct scan_pipe_res {
 
 static void scan_pipe_res_free(scan_pipe_res* r);
 
+/* The first scanner of a process scans one small dummy array, so that the code
+ * object is loaded here — where upstream builds its program — and not inside
+ * the first timed scan (see sort_warmup in clo_sort_abstract.c). Best effort. */
+static void scan_warmup(CloScan* scanner) {
+	static int done;
+	if (done || getenv("CLO_NO_WARMUP")) return;
+	done = 1;
+	const size_t n = 20000;
+	void* in = calloc(n, clo_type_sizeof(scanner->elem_type));
+	void* out = malloc(n * clo_type_sizeof(scanner->sum_type));
+	GError* err = NULL;
+	if (in && out) clo_scan_with_host_data(scanner, NULL, NULL, in, out, n, 0, &err);
+	if (err) clo_gerror_free(err);
+	free(in);
+	free(out);
+}
+
 CloScan* clo_scan_new(const char* type, const char* options, CCLContext* ctx,
 	CloType elem_type, CloType sum_type, const char* compiler_opts, GError** err) {
 
@@ -79,6 +96,7 @@ CloScan* clo_scan_new(const char* type, const char* options, CCLContext* ctx,
 			goto error_handler;
 		}
 		scanner->prg = ccl_program_new_token(ctx, token, compiler_opts);
+		scan_warmup(scanner);
 		break;
 	}
 
