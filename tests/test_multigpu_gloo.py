@@ -1,4 +1,4 @@
-"""world_size-2 (and 4) gloo tests of the multi-GPU host logic
+"""world_size-2 (and 4, 8) gloo tests of the multi-GPU host logic
 (cl_ops_amd/multigpu.py: count exchange, send/recv plan, P2P batch order,
 capacity handling) on CPU tensors. The device-side steps are injected as an
 oracle/numpy-backed LocalOps — test infrastructure only; the product's
@@ -78,7 +78,8 @@ def _worker(rank, world, port, elem_type, n, skew, out_dir):
 
 
 @pytest.mark.parametrize("world,elem_type,n,skew", [(2, "uint", 5000, False), (2, "ulong", 3000, False),
-                                                     (4, "uint", 2000, False), (2, "uint", 4000, True)])
+                                                     (4, "uint", 2000, False), (2, "uint", 4000, True),
+                                                     (8, "uint", 1500, False), (8, "ulong", 700, True)])   # the driver's N = 8 plan
 def test_sharded_sort_over_gloo(tmp_path, world, elem_type, n, skew):
     import torch.multiprocessing as mp
     port = _free_port()
