@@ -28,6 +28,7 @@ struct clo_scan {
 typedef struct scan_pipe_res {
 	void* s_in_own;              /* copies in, when the caller gave one queue for both */
 	void* s_out;                 /* copies out */
+	size_t chunk_cap;            /* elements the chunk buffers hold */
 	void* in_dev[2];
 	void* out_dev[2];
 	void* carry;                 /* two device uint64: carry of even / odd chunks */
@@ -144,8 +145,23 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
  * out are issued by a helper thread; pinning the caller's memory instead
  * costs ~10 ms per GiB, more than the overlap gains.                     */
 /* ------------------------------------------------------------------ */
-#define CLO_SCAN_PIPE_CHUNK ((size_t) 1 << 22)   /* elements per chunk */
+#define CLO_SCAN_PIPE_CHUNK ((size_t) 1 << 22)   /* smallest chunk, elements */
+#define CLO_SCAN_PIPE_CHUNK_MAX ((size_t) 1 << 24)
 #define CLO_SCAN_PIPE_MIN_CHUNKS 4               /* below this the fill/drain of the pipeline eats the gain */
+
+/* Eight chunks or more per array, 2^22 .. 2^24 elements each. Measured wall
+ * times, uint -> uint, host to host: 2^26 elements 6.2 ms with chunks of 2^22 or
+ * 2^23 (6.7 with 2^24), 2^28 elements 23.2-23.8 ms with 2^22 .. 2^24 (24.5 with
+ * 2^25) — flat, so the larger chunk wins: its scans run the large kernel shape
+ * (the reference harness prints the sum of the chunk scans: 174 GValues/s with
+ * chunks of 2^22 elements, 395 with 2^24). */
+static size_t scan_pipe_chunk(size_t numel) {
+	const char* x = getenv("CLO_SCAN_PIPE_CHUNK_LOG2");   /* (A/B measurements only) */
+	if (x && atoi(x) >= 16 && atoi(x) <= 28) return (size_t) 1 << atoi(x);
+	size_t c = CLO_SCAN_PIPE_CHUNK;
+	while (c < CLO_SCAN_PIPE_CHUNK_MAX && c * 8 < numel) c <<= 1;
+	return c;
+}
 
 static void scan_pipe_res_free(scan_pipe_res* r) {
 	if (!r) return;
@@ -161,13 +177,15 @@ static void scan_pipe_res_free(scan_pipe_res* r) {
 	free(r);
 }
 
-static scan_pipe_res* scan_pipe_res_get(CloScan* scanner, size_t es, size_t ss, int* status) {
-	if (scanner->pipe) return scanner->pipe;
+static scan_pipe_res* scan_pipe_res_get(CloScan* scanner, size_t chunk, size_t es, size_t ss, int* status) {
+	if (scanner->pipe && scanner->pipe->chunk_cap >= chunk) return scanner->pipe;
+	if (scanner->pipe) { scan_pipe_res_free(scanner->pipe); scanner->pipe = NULL; }
 	scan_pipe_res* r = (scan_pipe_res*) calloc(1, sizeof(*r));
 	int st = r ? 0 : CLO_HIP_EARGS;
+	if (r) r->chunk_cap = chunk;
 	for (int i = 0; i < 2 && st == 0; ++i) {
-		st = clo_hip_malloc(&r->in_dev[i], CLO_SCAN_PIPE_CHUNK * es);
-		if (st == 0) st = clo_hip_malloc(&r->out_dev[i], CLO_SCAN_PIPE_CHUNK * ss);
+		st = clo_hip_malloc(&r->in_dev[i], chunk * es);
+		if (st == 0) st = clo_hip_malloc(&r->out_dev[i], chunk * ss);
 		if (st == 0) st = clo_hip_event_create(&r->in_done[i]);
 		if (st == 0) st = clo_hip_event_create(&r->scan_done[i]);
 	}
@@ -218,7 +236,7 @@ static cl_bool scan_with_host_data_pipelined(CloScan* scanner, CCLQueue* cq_exec
 	const void* data_in, void* data_out, size_t numel, GError** err) {
 
 	const size_t es = clo_type_sizeof(scanner->elem_type), ss = clo_type_sizeof(scanner->sum_type);
-	const size_t chunk = CLO_SCAN_PIPE_CHUNK;
+	const size_t chunk = scan_pipe_chunk(numel);
 	const size_t nchunks = (numel + chunk - 1) / chunk;
 	void* s_in = ccl_queue_get_stream(cq_comm);
 	void* s_exec = ccl_queue_get_stream(cq_exec);
@@ -233,7 +251,7 @@ static cl_bool scan_with_host_data_pipelined(CloScan* scanner, CCLQueue* cq_exec
 	pthread_cond_init(&p.cv, NULL);
 	p.sum_size = ss; p.chunk = chunk; p.numel = numel; p.out_host = (char*) data_out;
 	if (clo_hip_get_device(&p.device) != 0) p.device = 0;
-	scan_pipe_res* r = scan_pipe_res_get(scanner, es, ss, &st);
+	scan_pipe_res* r = scan_pipe_res_get(scanner, chunk, es, ss, &st);
 	if (!r) goto finish;
 	p.r = r;
 	if (s_in == s_exec) s_in = r->s_in_own;
