@@ -113,6 +113,6 @@ for alg, cmd in NOTES.items():
     with open(os.path.join(dst, "%s_harness_sweep_%s.txt" % (tag, alg)), "w") as o:
         o.write("# %s on one MI355X (the reference harness's CLI and conventions: host data in, exec-queue device time "
                 "only, 5 runs per size; every run follows a fresh host-to-device copy, so these are cold-clock single-call "
-                "numbers, below bench.py's back-to-back steps). The scan pipelines 2^22-element chunks from 2^24 elements on: "
+                "numbers, below bench.py's back-to-back steps). The scan pipelines chunks of 2^22..2^24 elements from 2^24 elements on: "
                 "its device time is the sum of the chunk scans.\n" % cmd)
         o.write(open(f).read())
