@@ -431,8 +431,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const unsigned tiles = (unsigned) L.tiles;
 	const clo_keyx kx_none = { 0, 0, 0 };
 
-	hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES, s);   // status word
-	if (e != hipSuccess) return (int) e;
+	hipError_t e;   // (no kernel of the sort polls another work-group: the header's status word stays unused)
 
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
 	const E* cur_in = src;
@@ -524,8 +523,6 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles;
 	const clo_keyx kx_none = { 0, 0, 0 };
-	hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES, s);
-	if (e != hipSuccess) return (int) e;
 	clo_timing_scope timing("msd_partition", s);
 	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tiles, kx_none, s);
 	if (st != 0) return st;
