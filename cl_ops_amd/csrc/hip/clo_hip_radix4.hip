@@ -523,6 +523,8 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles;
 	const clo_keyx kx_none = { 0, 0, 0 };
+	hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES, s);   // (clo_hip_check_status may be asked about this workspace)
+	if (e != hipSuccess) return (int) e;
 	clo_timing_scope timing("msd_partition", s);
 	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tiles, kx_none, s);
 	if (st != 0) return st;
