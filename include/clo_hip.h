@@ -197,8 +197,9 @@ int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs
  * The scan is the one kernel that polls other work-groups' state (decoupled
  * look-back); it bounds every spin and on give-up sets a word in its workspace
  * and finishes. This reads the word back (synchronises `stream`). Returns 0,
- * CLO_HIP_ETIMEOUT or a hip error. (The sorts never wait on another
- * work-group; their workspaces carry the word, always 0, for uniformity.) */
+ * CLO_HIP_ETIMEOUT or a hip error. Meaningful for the workspaces of the scan
+ * and of clo_hip_msd_partition (always 0 there: no kernel of the sorts waits on
+ * another work-group); clo_hip_radix_sort leaves the word untouched. */
 int clo_hip_check_status(void* workspace, void* stream);
 
 /* ---- per-kernel device timing (measurement only; bench.py's roofline leg) ----
