@@ -504,6 +504,31 @@ def test_abitonic_many_tiles_typed_and_descending(gpu, et, descending):
     assert np.array_equal(got, exp[::-1] if descending else exp)
 
 
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic", "satradix"])
+@pytest.mark.parametrize("et", ["float", "double", "half"])
+def test_float_keys_follow_the_ieee_total_order(gpu, alg, et):
+    """Floating-point keys are ordered by the total order of their bit patterns
+    (-NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN) in every sorter: the same
+    image the radix passes sort by. Upstream's `>` ties -0 with +0 and is
+    undefined with NaNs; without NaNs the two orders agree as values."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    dt = clo.api.CLO_TYPE_NP[et]
+    ut = np.dtype("u%d" % dt.itemsize)
+    rng = np.random.default_rng(5)
+    n = 1 << 15
+    a = ((rng.random(n) - 0.5) * 1e4).astype(dt)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1.0, -1.0], dtype=dt)
+    a[rng.integers(0, n, 4000)] = special[rng.integers(0, special.size, 4000)]
+    u = a.view(ut)
+    sign = ut.type(1) << ut.type(8 * dt.itemsize - 1)
+    image = np.where(u & sign, ~u, u | sign)
+    s = clo.Sorter(alg, ctx, et)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got.view(ut), u[np.argsort(image, kind="stable")])
+
+
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
 @pytest.mark.parametrize("n", [3, 100, 5000, 70000])
 def test_bitonic_non_power_of_two(gpu, alg, n):
