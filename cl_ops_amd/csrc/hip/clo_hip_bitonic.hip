@@ -420,15 +420,16 @@ void clo_bitonic_tile_presort_kernel(E* __restrict__ data, key_desc kd) {
 }
 
 // ---- steps KL..1 of one stage > KL on full tiles: the merge passes ----
-// The direction of a whole tile is one bit of its number. A work-group walks
-// over several tiles and requests the next tile's values (32 more registers)
-// before it exchanges the current one through LDS: with one tile per group the
-// CU's loads stop while its two groups compute and exchange (measured: 105 us
-// per pass of 2^26 uint32, 11 waves resident on average; the strided passes,
-// which never stop loading, take 76 us).
+// The direction of a whole tile is one bit of its number: a scalar branch
+// around a bare min/max network. The last layout gives a thread V consecutive
+// elements, and 16-byte stores at that lane stride are 64 partial cache lines
+// per instruction: the tile leaves through one more LDS transpose, a wave
+// storing 1 KiB contiguous (111 -> 83 us per pass of 2^26 uint32). (A group
+// walking over several tiles with the next tile's loads in flight measured the
+// same for 4-byte elements and 35 % slower for 8-byte ones: 32 more registers.)
 template <typename E, int Q, int TB, int MODE>
 __global__ __launch_bounds__(1 << TB)
-void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned tiles, unsigned stage, key_desc kd) {
+void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned stage, key_desc kd) {
 	constexpr int V = 1 << Q;
 	constexpr int KL = TB + Q;
 	constexpr int TILE = V << TB;
@@ -440,7 +441,7 @@ void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned tiles, unsigne
 	const unsigned tid = threadIdx.x;
 	auto tbase = [&](int b0) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
 	auto phys = [](unsigned i) { return i + (i >> 5); };
-	E v[V], nxt[V];
+	E v[V];
 	auto exchange = [&](int from, int to) {
 		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
 		#pragma unroll
@@ -449,55 +450,35 @@ void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned tiles, unsigne
 		#pragma unroll
 		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
 	};
-	const unsigned first_b = tbase(KL - Q);   // first group: register bits [KL-Q, KL), lanes read adjacent elements
-	unsigned tile = blockIdx.x;
-	if (tile >= tiles) return;
+	const size_t gbase = (size_t) blockIdx.x << KL;
+	const unsigned dir = (unsigned) ((gbase >> stage) & 1);
 	{
-		const E* src = data + ((size_t) tile << KL) + first_b;
+		// first group: register bits [KL-Q, KL), lanes read adjacent elements
+		const E* src = data + gbase + tbase(KL - Q);
 		#pragma unroll
 		for (int j = 0; j < V; ++j) v[j] = bt_in<E, MODE>(src[(unsigned) j << (KL - Q)]);
 	}
-	while (true) {
-		const size_t gbase = (size_t) tile << KL;
-		const unsigned dir = (unsigned) ((gbase >> stage) & 1);
-		const unsigned next = tile + gridDim.x;
-		const bool more = next < tiles;
-		static_for<0, (KL + Q - 1) / Q>([&](auto gc) {
-			constexpr int g = decltype(gc)::value;
-			constexpr int p = KL - g * Q;
-			constexpr int b0 = p > Q ? p - Q : 0;
-			if (g > 0) exchange(p, b0);
-			reg_network_uniform<E, V, MODE>(v, p - b0, dir, kd);
-			if (g == 0 && more) {
-				const E* src = data + ((size_t) next << KL) + first_b;
-				#pragma unroll
-				for (int j = 0; j < V; ++j) nxt[j] = bt_in<E, MODE>(src[(unsigned) j << (KL - Q)]);
-			}
-		});
-		// out through LDS once more: in the last layout a thread holds V consecutive
-		// elements, and 16-byte stores at a lane stride of V elements are 64 partial
-		// cache lines per instruction; transposed, a wave stores 1 KiB contiguous
-		{
-			const unsigned pf = phys(tbase(0));
-			#pragma unroll
-			for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
-			__syncthreads();
-			vec16* dst = reinterpret_cast<vec16*>(data + gbase) + tid;
-			#pragma unroll
-			for (int k = 0; k < V / PER; ++k) {
-				const unsigned e = ((unsigned) k << TB) * PER + tid * PER;   // PER consecutive slots: no multiple of 32 inside
-				const unsigned pe = phys(e);
-				vec16 t;
-				#pragma unroll
-				for (int q = 0; q < PER; ++q) t[q] = bt_out<E, MODE>(s[pe + q]);
-				dst[(unsigned) k << TB] = t;
-			}
-		}
-		if (!more) break;
+	static_for<0, (KL + Q - 1) / Q>([&](auto gc) {
+		constexpr int g = decltype(gc)::value;
+		constexpr int p = KL - g * Q;
+		constexpr int b0 = p > Q ? p - Q : 0;
+		if (g > 0) exchange(p, b0);
+		reg_network_uniform<E, V, MODE>(v, p - b0, dir, kd);
+	});
+	{
+		const unsigned pf = phys(tbase(0));
 		#pragma unroll
-		for (int j = 0; j < V; ++j) v[j] = nxt[j];
-		tile = next;
-		__syncthreads();   // the slots this thread writes next were last read by other threads
+		for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
+		__syncthreads();
+		vec16* dst = reinterpret_cast<vec16*>(data + gbase) + tid;
+		#pragma unroll
+		for (int k = 0; k < V / PER; ++k) {
+			const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);   // PER consecutive slots: no multiple of 32 inside
+			vec16 t;
+			#pragma unroll
+			for (int q = 0; q < PER; ++q) t[q] = bt_out<E, MODE>(s[pe + q]);
+			dst[(unsigned) k << TB] = t;
+		}
 	}
 }
 
@@ -597,7 +578,6 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	// ones are one tile, sorted by one launch of the run-time-schedule kernel.
 	constexpr int TBF = 9;
 	constexpr unsigned KLF = TBF + Q;
-	constexpr unsigned MERGE_GROUPS = 512;   // two per CU, each walks over tiles / 512 tiles
 	static_assert(KLF - 1 <= 8 + Q, "the run-time kernel covers every smaller array");
 	// strided passes need p - NS >= 6 so that a wave's 64 lanes read one
 	// contiguous row; KLF >= 13 guarantees it for every p > KLF.
@@ -648,8 +628,7 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 		{
 			clo_timing_scope timing("bitonic_tile", s);
 			// stage > kl only happens with full tiles (kl == KLF)
-			hipLaunchKernelGGL((clo_bitonic_tile_merge_kernel<E, Q, TBF, MODE>), dim3(tiles < MERGE_GROUPS ? tiles : MERGE_GROUPS), dim3(1 << TBF), 0, s,
-				data, tiles, stage, kd);
+			hipLaunchKernelGGL((clo_bitonic_tile_merge_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, kd);
 		}
 		++count;
 	}
