@@ -156,6 +156,10 @@ def main():
                              % (args.gpus, args.gpus))
         args.gpus = world
 
+    # The library loads its kernels at sorter creation with two small dummy sorts;
+    # this script has untimed steps of its own for that, and the dummy launches
+    # would dilute the per-kernel averages of a rocprofv3 run of this command.
+    os.environ.setdefault("CLO_NO_WARMUP", "1")
     import torch
     import cl_ops_amd as clo
     from cl_ops_amd import _hip
