@@ -95,6 +95,42 @@ __device__ __forceinline__ void cmpxch(E& a, E& b, unsigned dir, const key_desc&
 	}
 }
 
+// General keys (MODE 0): the ordered keys are computed ONCE per call and carried
+// with their elements through the steps of the call (cmpxch<E, 0> recomputes
+// both keys at every exchange: ~19 VALU per pair; here a compare, the selects
+// of key and element, and the keys' ~5 VALU per element and call — abitonic of
+// 2^26 (uint key, uint value) pairs: 25.5 ms before). The swap rule is
+// cmpxch's, bit for bit. K: 32-bit image when the key has at most 32 bits.
+template <typename E, typename K, int V, typename DIRFN>
+__device__ __forceinline__ void reg_network_keyed(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn) {
+	K k[V];
+	#pragma unroll
+	for (int j = 0; j < V; ++j) k[j] = (K) okey<E>(v[j], kd);
+	const bool desc = kd.descending != 0;
+	#pragma unroll
+	for (int half = V / 2; half >= 1; half /= 2) {
+		if (half < (1 << nsteps)) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j)
+				if ((j & half) == 0) {
+					const K ka = k[j], kb = k[j + half];
+					const bool cmp = desc ? (ka < kb) : (ka > kb);
+					const bool sw = cmp != (bool) dirfn(j);
+					k[j] = sw ? kb : ka;
+					k[j + half] = sw ? ka : kb;
+					const E a = v[j], b = v[j + half];
+					v[j] = sw ? b : a;
+					v[j + half] = sw ? a : b;
+				}
+		}
+	}
+}
+template <typename E, int V, typename DIRFN>
+__device__ __forceinline__ void reg_network_general(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn) {
+	if (sizeof(E) <= 4 || (kd.mask >> 32) == 0ull) reg_network_keyed<E, unsigned, V>(v, nsteps, kd, dirfn);
+	else reg_network_keyed<E, unsigned long long, V>(v, nsteps, kd, dirfn);
+}
+
 // Up to log2(V) steps on the V values of one thread: strides 2^(nsteps-1) .. 1
 // (the register networks of abitonic.cl:163-224, any size). Value j sits at
 // element index idx0 | (j << b0); its direction bit is bit S of that index.
@@ -104,6 +140,10 @@ __device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, 
 	const unsigned dbase = (unsigned) ((idx0 >> S) & 1);
 	// non-zero iff the direction bit is one of this thread's register bits
 	const unsigned dsel = (S >= b0 && S - b0 < 31u) ? ((1u << (S - b0)) & (unsigned) (V - 1)) : 0u;
+	if (MODE == 0) {
+		reg_network_general<E, V>(v, nsteps, kd, [&](int j) { return dsel ? (((unsigned) j & dsel) ? 1u : 0u) : dbase; });
+		return;
+	}
 	#pragma unroll
 	for (int half = V / 2; half >= 1; half /= 2) {
 		if (half < (1 << nsteps)) {
@@ -141,14 +181,7 @@ __device__ __forceinline__ void reg_network_minmax(E (&v)[V], int nsteps) {
 template <typename E, int V, int MODE>
 __device__ __forceinline__ void reg_network_uniform(E (&v)[V], int nsteps, unsigned dir, const key_desc& kd) {
 	if (MODE == 0) {
-		#pragma unroll
-		for (int half = V / 2; half >= 1; half /= 2) {
-			if (half < (1 << nsteps)) {
-				#pragma unroll
-				for (int j = 0; j < V; ++j)
-					if ((j & half) == 0) cmpxch<E, 0>(v[j], v[j + half], dir, kd);
-			}
-		}
+		reg_network_general<E, V>(v, nsteps, kd, [&](int) { return dir; });
 	} else if ((dir ^ kd.descending) == 0) {
 		reg_network_minmax<E, V, MODE, true>(v, nsteps);
 	} else {
@@ -204,7 +237,7 @@ void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, 
 	const unsigned tile = 1u << kl;
 	const unsigned nthr = tile >> Q;  // active threads
 	const size_t gbase = (size_t) blockIdx.x << kl;
-	auto phys = [](unsigned i) { return i + (i >> 5); };
+	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
 
 	// The thread's V values stay in VGPRs across consecutive step groups that
 	// use the same register bits (all of stages 1..Q, for one). The first group
@@ -337,11 +370,11 @@ void clo_bitonic_tile_presort_kernel(E* __restrict__ data, key_desc kd) {
 	const size_t gbase = (size_t) blockIdx.x << KL;
 	// layout b0: value j of thread t is tile element tbase(b0) | (j << b0); the
 	// two parts share no bits, so the padded LDS slot is phys(tbase) + a constant
-	auto tbase = [&](int b0) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
-	auto phys = [](unsigned i) { return i + (i >> 5); };
+	auto tbase = [&](int b0) __attribute__((always_inline)) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
+	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
 	E v[V];
 
-	auto exchange = [&](int from, int to) {
+	auto exchange = [&](int from, int to) __attribute__((always_inline)) {
 		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
 		#pragma unroll
 		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
@@ -349,7 +382,7 @@ void clo_bitonic_tile_presort_kernel(E* __restrict__ data, key_desc kd) {
 		#pragma unroll
 		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
 	};
-	auto group = [&](int S, int b0, int nsteps) {
+	auto group = [&](int S, int b0, int nsteps) __attribute__((always_inline)) {
 		if (CPL) reg_network_minmax<E, V, MODE, true>(v, nsteps);
 		else reg_network<E, V, MODE>(v, nsteps, gbase + tbase(b0), (unsigned) b0, (unsigned) S, kd);
 	};
@@ -373,9 +406,9 @@ void clo_bitonic_tile_presort_kernel(E* __restrict__ data, key_desc kd) {
 		for (int j = 0; j < V; ++j) v[j] = s[pt + (unsigned) j];
 	}
 	{
-		static_for<1, KL + 1>([&](auto Sc) {
+		static_for<1, KL + 1>([&](auto Sc) __attribute__((always_inline)) {
 			constexpr int S = decltype(Sc)::value;
-			static_for<0, (S + Q - 1) / Q>([&](auto gc) {
+			static_for<0, (S + Q - 1) / Q>([&](auto gc) __attribute__((always_inline)) {
 				constexpr int g = decltype(gc)::value;
 				constexpr int p = S - g * Q;
 				constexpr int b0 = p > Q ? p - Q : 0;
@@ -439,10 +472,10 @@ void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned stage, key_des
 	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
 
 	const unsigned tid = threadIdx.x;
-	auto tbase = [&](int b0) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
-	auto phys = [](unsigned i) { return i + (i >> 5); };
+	auto tbase = [&](int b0) __attribute__((always_inline)) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
+	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
 	E v[V];
-	auto exchange = [&](int from, int to) {
+	auto exchange = [&](int from, int to) __attribute__((always_inline)) {
 		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
 		#pragma unroll
 		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
@@ -458,7 +491,7 @@ void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned stage, key_des
 		#pragma unroll
 		for (int j = 0; j < V; ++j) v[j] = bt_in<E, MODE>(src[(unsigned) j << (KL - Q)]);
 	}
-	static_for<0, (KL + Q - 1) / Q>([&](auto gc) {
+	static_for<0, (KL + Q - 1) / Q>([&](auto gc) __attribute__((always_inline)) {
 		constexpr int g = decltype(gc)::value;
 		constexpr int p = KL - g * Q;
 		constexpr int b0 = p > Q ? p - Q : 0;
