@@ -355,13 +355,14 @@ def test_bitonic_u32(gpu, alg, n):
         assert np.array_equal(got, O.sbitonic(a))
 
 
+@pytest.mark.parametrize("logn", [15, 19])
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
-def test_bitonic_pairs_tie_order_matches_reference_network(gpu, alg):
+def test_bitonic_pairs_tie_order_matches_reference_network(gpu, alg, logn):
     """Non-identity keys: tie order depends on the exact network; must equal the
-    restated reference network bit for bit."""
+    restated reference network bit for bit (2^19: 64 tiles, every strided width)."""
     import cl_ops_amd as clo
     ctx, q = gpu
-    n = 1 << 15
+    n = 1 << logn
     rng = np.random.default_rng(3)
     keys = rng.integers(0, 50, n, dtype=np.uint64)
     e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
@@ -369,8 +370,9 @@ def test_bitonic_pairs_tie_order_matches_reference_network(gpu, alg):
     got = s.with_host_data(e, q)
     s.close()
     assert np.array_equal(got, O.sbitonic(e, key_size=4, key_shift=32))
-    exp_ab, _ = O.abitonic(e, key_size=4, key_shift=32, dev_max_lws=256)
-    assert np.array_equal(got, exp_ab)
+    if logn <= 15:
+        exp_ab, _ = O.abitonic(e, key_size=4, key_shift=32, dev_max_lws=256)
+        assert np.array_equal(got, exp_ab)
 
 
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
