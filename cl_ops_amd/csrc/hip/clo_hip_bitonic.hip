@@ -32,717 +32,7 @@
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
 
-namespace {
-
-struct key_desc {
-	unsigned shift;
-	unsigned kind;        // 0 unsigned, 1 signed, 2 float
-	unsigned descending;  // CLO_SORT_COMPARE "((a) < (b))"
-	unsigned long long mask, signbit;
-};
-
-// Key as an unsigned integer whose order is the typed order of the key.
-template <typename E>
-__device__ __forceinline__ unsigned long long okey(E e, const key_desc& kd) {
-	unsigned long long k = ((unsigned long long) e >> kd.shift) & kd.mask;
-	if (kd.kind == 1) k ^= kd.signbit;
-	else if (kd.kind == 2) k = (k & kd.signbit) ? (~k & kd.mask) : (k | kd.signbit);
-	return k;
-}
-
-// MODE 3 (the key is the whole element, IEEE floating point): a kernel maps
-// every element to the unsigned integer with the same order when it loads it and
-// back when it stores it, and runs the unsigned min/max networks in between (the
-// general compare recomputes that image for both elements at every step: 2^26
-// floats took 29.6 ms against 2.8 ms for 2^26 uints). Equal images are equal
-// bit patterns, so equal keys are equal elements here too.
-template <typename E, int MODE>
-__device__ __forceinline__ E bt_in(E x) {
-	if (MODE != 3) return x;
-	typedef typename std::make_signed<E>::type S;
-	constexpr int W = 8 * (int) sizeof(E);
-	const E m = (E) ((E) ((S) x >> (W - 1)) | (E) ((E) 1 << (W - 1)));   // negative: all ones; else the sign bit
-	return (E) (x ^ m);
-}
-template <typename E, int MODE>
-__device__ __forceinline__ E bt_out(E y) {
-	if (MODE != 3) return y;
-	typedef typename std::make_signed<E>::type S;
-	constexpr int W = 8 * (int) sizeof(E);
-	const E m = (E) ((E) ~(E) ((S) y >> (W - 1)) | (E) ((E) 1 << (W - 1)));
-	return (E) (y ^ m);
-}
-
-// Compare-exchange with the reference's rule (abitonic.cl:31-38).
-// MODE 0: any key (shift/mask/typed compare). MODE 1 / 2: the key is the whole
-// element, unsigned / signed integer: equal keys are equal elements, so the
-// exchange is min/max (2 VALU + 2 selects instead of ~20); a descending
-// compare is the ascending one with the direction bit flipped.
-template <typename E, int MODE>
-__device__ __forceinline__ void cmpxch(E& a, E& b, unsigned dir, const key_desc& kd) {
-	if (MODE == 0) {
-		const unsigned long long ka = okey<E>(a, kd), kb = okey<E>(b, kd);
-		const bool cmp = kd.descending ? (ka < kb) : (ka > kb);
-		if (cmp != (bool) dir) { const E t = a; a = b; b = t; }
-	} else {
-		typedef typename std::make_signed<E>::type S;
-		E lo, hi;
-		if (MODE != 2) { lo = a < b ? a : b; hi = a < b ? b : a; }
-		else { lo = (S) a < (S) b ? a : b; hi = (S) a < (S) b ? b : a; }
-		const bool up = (dir ^ kd.descending) == 0;
-		a = up ? lo : hi;
-		b = up ? hi : lo;
-	}
-}
-
-// General keys (MODE 0): the ordered keys are computed ONCE per call and carried
-// with their elements through the steps of the call (cmpxch<E, 0> recomputes
-// both keys at every exchange: ~19 VALU per pair; here a compare, the selects
-// of key and element, and the keys' ~5 VALU per element and call — abitonic of
-// 2^26 (uint key, uint value) pairs: 25.5 ms before). The swap rule is
-// cmpxch's, bit for bit. K: 32-bit image when the key has at most 32 bits.
-template <typename E, typename K, int V, typename DIRFN>
-__device__ __forceinline__ void reg_network_keyed(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn) {
-	K k[V];
-	#pragma unroll
-	for (int j = 0; j < V; ++j) k[j] = (K) okey<E>(v[j], kd);
-	const bool desc = kd.descending != 0;
-	#pragma unroll
-	for (int half = V / 2; half >= 1; half /= 2) {
-		if (half < (1 << nsteps)) {
-			#pragma unroll
-			for (int j = 0; j < V; ++j)
-				if ((j & half) == 0) {
-					const K ka = k[j], kb = k[j + half];
-					const bool cmp = desc ? (ka < kb) : (ka > kb);
-					const bool sw = cmp != (bool) dirfn(j);
-					k[j] = sw ? kb : ka;
-					k[j + half] = sw ? ka : kb;
-					const E a = v[j], b = v[j + half];
-					v[j] = sw ? b : a;
-					v[j + half] = sw ? a : b;
-				}
-		}
-	}
-}
-template <typename E, int V, typename DIRFN>
-__device__ __forceinline__ void reg_network_general(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn) {
-	if (sizeof(E) <= 4 || (kd.mask >> 32) == 0ull) reg_network_keyed<E, unsigned, V>(v, nsteps, kd, dirfn);
-	else reg_network_keyed<E, unsigned long long, V>(v, nsteps, kd, dirfn);
-}
-
-// Up to log2(V) steps on the V values of one thread: strides 2^(nsteps-1) .. 1
-// (the register networks of abitonic.cl:163-224, any size). Value j sits at
-// element index idx0 | (j << b0); its direction bit is bit S of that index.
-template <typename E, int V, int MODE>
-__device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, unsigned b0, unsigned S,
-	const key_desc& kd) {
-	const unsigned dbase = (unsigned) ((idx0 >> S) & 1);
-	// non-zero iff the direction bit is one of this thread's register bits
-	const unsigned dsel = (S >= b0 && S - b0 < 31u) ? ((1u << (S - b0)) & (unsigned) (V - 1)) : 0u;
-	if (MODE == 0) {
-		reg_network_general<E, V>(v, nsteps, kd, [&](int j) { return dsel ? (((unsigned) j & dsel) ? 1u : 0u) : dbase; });
-		return;
-	}
-	#pragma unroll
-	for (int half = V / 2; half >= 1; half /= 2) {
-		if (half < (1 << nsteps)) {
-			#pragma unroll
-			for (int j = 0; j < V; ++j)
-				if ((j & half) == 0) {
-					const unsigned dir = dsel ? (((unsigned) j & dsel) ? 1u : 0u) : dbase;
-					cmpxch<E, MODE>(v[j], v[j + half], dir, kd);
-				}
-		}
-	}
-}
-
-// The same network when the direction bit is above every index bit the wave
-// (or work-group) spans: `dir` is then one scalar, and for whole-element integer
-// keys the exchange is a bare min/max pair under a scalar branch.
-template <typename E, int V, int MODE, bool UP>
-__device__ __forceinline__ void reg_network_minmax(E (&v)[V], int nsteps) {
-	typedef typename std::make_signed<E>::type S;
-	#pragma unroll
-	for (int half = V / 2; half >= 1; half /= 2) {
-		if (half < (1 << nsteps)) {
-			#pragma unroll
-			for (int j = 0; j < V; ++j)
-				if ((j & half) == 0) {
-					E &a = v[j], &b = v[j + half];
-					const bool lt = MODE != 2 ? (a < b) : ((S) a < (S) b);
-					const E lo = lt ? a : b, hi = lt ? b : a;
-					a = UP ? lo : hi;
-					b = UP ? hi : lo;
-				}
-		}
-	}
-}
-template <typename E, int V, int MODE>
-__device__ __forceinline__ void reg_network_uniform(E (&v)[V], int nsteps, unsigned dir, const key_desc& kd) {
-	if (MODE == 0) {
-		reg_network_general<E, V>(v, nsteps, kd, [&](int) { return dir; });
-	} else if ((dir ^ kd.descending) == 0) {
-		reg_network_minmax<E, V, MODE, true>(v, nsteps);
-	} else {
-		reg_network_minmax<E, V, MODE, false>(v, nsteps);
-	}
-}
-
-// ---- one launch per step (sbitonic.cl:38-69 / abit_any) ----
-template <typename E>
-__global__ __launch_bounds__(256)
-void clo_bitonic_step_kernel(E* __restrict__ data, size_t npairs, unsigned stage, unsigned step, key_desc kd) {
-	const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x;
-	if (gid >= npairs) return;
-	const unsigned sh = step - 1;
-	const size_t i1 = ((gid >> sh) << (sh + 1)) | (gid & (((size_t) 1 << sh) - 1));
-	const size_t i2 = i1 + ((size_t) 1 << sh);
-	E a = data[i1], b = data[i2];
-	const E a0 = a, b0 = b;
-	cmpxch<E, 0>(a, b, (unsigned) ((i1 >> stage) & 1), kd);
-	if (a != a0 || b != b0) { data[i1] = a; data[i2] = b; }
-}
-
-// ---- strided register kernel: steps p .. p-NS+1 of stage S, p-NS >= 6 ----
-template <typename E, int NS, int MODE>
-__global__ __launch_bounds__(256)
-void clo_bitonic_strided_kernel(E* __restrict__ data, size_t n, unsigned stage, unsigned p, key_desc kd) {
-	constexpr int V = 1 << NS;
-	const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
-	if (t >= (n >> NS)) return;
-	const unsigned b0 = p - NS;  // lowest index bit handled in registers
-	const size_t base = ((t >> b0) << (b0 + NS)) | (t & (((size_t) 1 << b0) - 1));
-	E v[V];
-	#pragma unroll
-	for (int j = 0; j < V; ++j) v[j] = bt_in<E, MODE>(data[base + ((size_t) j << b0)]);
-	// bit `stage` of base is bit stage-NS >= b0 >= 6 of t: the same for the 64 lanes
-	reg_network_uniform<E, V, MODE>(v, NS, __builtin_amdgcn_readfirstlane((unsigned) ((base >> stage) & 1)), kd);
-	#pragma unroll
-	for (int j = 0; j < V; ++j) data[base + ((size_t) j << b0)] = bt_out<E, MODE>(v[j]);
-}
-
-// ---- LDS tile kernel ----
-// Q register bits, 256 threads, tile = 2^(8+Q) elements max; kl = log2 of the
-// tile actually used (Q <= kl <= 8+Q). mode 0: run steps p_hi..1 of `stage`;
-// mode 1: run all of stages 1..stage (stage <= kl).
-template <typename E, int Q, int MODE>
-__global__ __launch_bounds__(256)
-void clo_bitonic_tile_kernel(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, int mode, key_desc kd) {
-	constexpr int V = 1 << Q;
-	constexpr int TILE_MAX = 256 * V;
-	__shared__ E s[TILE_MAX + TILE_MAX / 32];
-
-	const unsigned tid = threadIdx.x;
-	const unsigned tile = 1u << kl;
-	const unsigned nthr = tile >> Q;  // active threads
-	const size_t gbase = (size_t) blockIdx.x << kl;
-	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
-
-	// The thread's V values stay in VGPRs across consecutive step groups that
-	// use the same register bits (all of stages 1..Q, for one). The first group
-	// is loaded straight from global memory and the last one stored straight
-	// back (its register bits are the lowest Q: V consecutive elements, 16-byte
-	// vectors); LDS only carries the exchanges between groups. (In an exchange a
-	// thread overwrites exactly the LDS slots it last read — each layout
-	// partitions the tile among the threads — so one barrier per exchange.)
-	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));   // element alignment is all a caller guarantees
-	constexpr int PER = 16 / (int) sizeof(E);
-	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
-	// Whole-element integer keys, all stages of a tile (mode 1): an element whose
-	// stage direction is "down" is held COMPLEMENTED for that stage (the direction
-	// is a bit of the element's own index, so every thread agrees, also across the
-	// LDS exchanges), which makes every exchange of the stage an ascending min/max.
-	// The complement state moves at each stage's first group and is undone at the
-	// end. Any network gives the same result for these keys: equal keys are equal
-	// elements.
-	constexpr bool CPL = MODE != 0;
-	E v[V];
-	int cur_b0 = -1;
-	unsigned base = 0;
-	const unsigned s_first = mode ? 1u : stage;
-	for (unsigned S = s_first; S <= stage; ++S) {
-		unsigned p = mode ? S : p_hi;
-		while (p >= 1) {
-			// register bits [b0, b0+Q) of the tile index; steps p .. b0+1
-			const unsigned b0 = p > (unsigned) Q ? p - Q : 0u;
-			const int nsteps = (int) (p - b0);
-			if (cur_b0 != (int) b0) {
-				if (cur_b0 >= 0) {
-					if (tid < nthr) {
-						#pragma unroll
-						for (int j = 0; j < V; ++j) s[phys(base + ((unsigned) j << cur_b0))] = v[j];
-					}
-					__syncthreads();
-				}
-				base = ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u));
-				if (tid < nthr) {
-					if (cur_b0 < 0) {
-						// first group: from global memory (b0 == 0: V consecutive elements;
-						// b0 >= 6 or a single wave: lanes read adjacent elements)
-						if (b0 == 0) {
-							const vec16* src = reinterpret_cast<const vec16*>(data + gbase + base);
-							#pragma unroll
-							for (int k = 0; k < V / PER; ++k) {
-								const vec16 t = src[k];
-								#pragma unroll
-								for (int q = 0; q < PER; ++q) v[k * PER + q] = bt_in<E, MODE>(t[q]);
-							}
-						} else {
-							#pragma unroll
-							for (int j = 0; j < V; ++j) v[j] = bt_in<E, MODE>(data[gbase + base + ((unsigned) j << b0)]);
-						}
-					} else {
-						#pragma unroll
-						for (int j = 0; j < V; ++j) v[j] = s[phys(base + ((unsigned) j << b0))];
-					}
-				}
-				cur_b0 = (int) b0;
-			}
-			if (tid < nthr) {
-				if (CPL && mode) {
-					// first group of a stage: move every element to the stage's complement state
-					if (p == S) {
-						#pragma unroll
-						for (int j = 0; j < V; ++j) {
-							const unsigned idx = (unsigned) gbase + base + ((unsigned) j << b0);
-							const unsigned f = (idx >> S) ^ (S == 1 ? kd.descending : (idx >> (S - 1)));
-							v[j] ^= (E) ((E) 0 - (E) (f & 1u));
-						}
-					}
-					reg_network_minmax<E, V, MODE, true>(v, nsteps);
-				}
-				// from stage kl up the direction bit is a bit of the tile number
-				else if (S >= kl) reg_network_uniform<E, V, MODE>(v, nsteps, (unsigned) ((gbase >> S) & 1), kd);
-				else reg_network<E, V, MODE>(v, nsteps, gbase + base, b0, S, kd);
-			}
-			p = b0;
-		}
-	}
-	// every schedule ends on steps Q..1, i.e. with b0 == 0: V consecutive elements per thread
-	if (tid < nthr) {
-		if (CPL && mode) {
-			#pragma unroll
-			for (int j = 0; j < V; ++j) {
-				const unsigned f = (((unsigned) gbase + base + (unsigned) j) >> stage) ^ kd.descending;
-				v[j] ^= (E) ((E) 0 - (E) (f & 1u));
-			}
-		}
-		vec16* dst = reinterpret_cast<vec16*>(data + gbase + base);
-		#pragma unroll
-		for (int k = 0; k < V / PER; ++k) {
-			vec16 t;
-			#pragma unroll
-			for (int q = 0; q < PER; ++q) t[q] = bt_out<E, MODE>(v[k * PER + q]);
-			dst[k] = t;
-		}
-	}
-}
-
-// ---- full tiles of 2^(TB+Q) elements, 2^TB threads, schedule fixed at compile time ----
-// (all of stages 1..TB+Q: the presort; the merge passes follow)
-// Every n >= 2^(TB+Q) runs these: with the stage / group loops unrolled the
-// layouts are constants, so an LDS exchange is one thread base plus immediate
-// offsets (the run-time schedule spends 4 VALU per LDS access on addresses:
-// 422 VALU per element in the 91-step presort, SQ_INSTS_VALU) and the
-// complement-state masks are one XOR per element and stage.
-template <int A, int B, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-	if constexpr (A < B) {
-		f(std::integral_constant<int, A>());
-		static_for<A + 1, B>(f);
-	}
-}
-
-template <typename E, int Q, int TB, int MODE>
-__global__ __launch_bounds__(1 << TB)
-void clo_bitonic_tile_presort_kernel(E* __restrict__ data, key_desc kd) {
-	constexpr int V = 1 << Q;
-	constexpr int KL = TB + Q;
-	constexpr int TILE = V << TB;
-	constexpr bool CPL = MODE != 0;
-	__shared__ E s[TILE + TILE / 32];
-	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
-	constexpr int PER = 16 / (int) sizeof(E);
-	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
-
-	const unsigned tid = threadIdx.x;
-	const size_t gbase = (size_t) blockIdx.x << KL;
-	// layout b0: value j of thread t is tile element tbase(b0) | (j << b0); the
-	// two parts share no bits, so the padded LDS slot is phys(tbase) + a constant
-	auto tbase = [&](int b0) __attribute__((always_inline)) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
-	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
-	E v[V];
-
-	auto exchange = [&](int from, int to) __attribute__((always_inline)) {
-		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
-		#pragma unroll
-		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
-		__syncthreads();
-		#pragma unroll
-		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
-	};
-	auto group = [&](int S, int b0, int nsteps) __attribute__((always_inline)) {
-		if (CPL) reg_network_minmax<E, V, MODE, true>(v, nsteps);
-		else reg_network<E, V, MODE>(v, nsteps, gbase + tbase(b0), (unsigned) b0, (unsigned) S, kd);
-	};
-
-	// In and out through LDS: the first and last layouts give a thread V
-	// consecutive elements, and 16-byte accesses at a lane stride of V elements
-	// are 64 partial cache lines per instruction; transposed, a wave moves 1 KiB
-	// contiguous (the merge passes: 111 -> 83 us per 2^26 uint32).
-	{
-		const vec16* src = reinterpret_cast<const vec16*>(data + gbase) + tid;
-		#pragma unroll
-		for (int k = 0; k < V / PER; ++k) {
-			const vec16 t = src[(unsigned) k << TB];
-			const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);   // PER consecutive slots: no multiple of 32 inside
-			#pragma unroll
-			for (int q = 0; q < PER; ++q) s[pe + q] = bt_in<E, MODE>(t[q]);
-		}
-		__syncthreads();
-		const unsigned pt = phys(tbase(0));
-		#pragma unroll
-		for (int j = 0; j < V; ++j) v[j] = s[pt + (unsigned) j];
-	}
-	{
-		static_for<1, KL + 1>([&](auto Sc) __attribute__((always_inline)) {
-			constexpr int S = decltype(Sc)::value;
-			static_for<0, (S + Q - 1) / Q>([&](auto gc) __attribute__((always_inline)) {
-				constexpr int g = decltype(gc)::value;
-				constexpr int p = S - g * Q;
-				constexpr int b0 = p > Q ? p - Q : 0;
-				constexpr int prev = g > 0 ? p : 0;   // the layout the values are in now
-				if (prev != b0) exchange(prev, b0);
-				if (CPL && g == 0) {
-					// move to stage S's complement state: bit S of the index (^ descending),
-					// coming from stage S-1's (nothing complemented before stage 1)
-					const unsigned tb = (unsigned) gbase + tbase(b0);
-					const unsigned ft = S == 1 ? ((tb >> 1) ^ kd.descending) : ((tb >> S) ^ (tb >> (S - 1)));
-					const E m0 = (E) ((E) 0 - (E) (ft & 1u)), m1 = (E) ~m0;
-					#pragma unroll
-					for (int j = 0; j < V; ++j) {
-						const unsigned ij = (unsigned) j << b0;
-						const unsigned fj = S == 1 ? (ij >> 1) : ((ij >> S) ^ (ij >> (S - 1)));
-						v[j] ^= (fj & 1u) ? m1 : m0;
-					}
-				}
-				group(S, b0, p - b0);
-			});
-		});
-		if (CPL && ((unsigned) (gbase >> KL) & 1u) != kd.descending) {
-			#pragma unroll
-			for (int j = 0; j < V; ++j) v[j] = (E) ~v[j];
-		}
-	}
-	{
-		const unsigned pf = phys(tbase(0));
-		#pragma unroll
-		for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
-		__syncthreads();
-		vec16* dst = reinterpret_cast<vec16*>(data + gbase) + tid;
-		#pragma unroll
-		for (int k = 0; k < V / PER; ++k) {
-			const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);
-			vec16 t;
-			#pragma unroll
-			for (int q = 0; q < PER; ++q) t[q] = bt_out<E, MODE>(s[pe + q]);
-			dst[(unsigned) k << TB] = t;
-		}
-	}
-}
-
-// ---- steps KL..1 of one stage > KL on full tiles: the merge passes ----
-// The direction of a whole tile is one bit of its number: a scalar branch
-// around a bare min/max network. The last layout gives a thread V consecutive
-// elements, and 16-byte stores at that lane stride are 64 partial cache lines
-// per instruction: the tile leaves through one more LDS transpose, a wave
-// storing 1 KiB contiguous (111 -> 83 us per pass of 2^26 uint32). (A group
-// walking over several tiles with the next tile's loads in flight measured the
-// same for 4-byte elements and 35 % slower for 8-byte ones: 32 more registers.)
-template <typename E, int Q, int TB, int MODE>
-__global__ __launch_bounds__(1 << TB)
-void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned stage, key_desc kd) {
-	constexpr int V = 1 << Q;
-	constexpr int KL = TB + Q;
-	constexpr int TILE = V << TB;
-	__shared__ E s[TILE + TILE / 32];
-	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
-	constexpr int PER = 16 / (int) sizeof(E);
-	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
-
-	const unsigned tid = threadIdx.x;
-	auto tbase = [&](int b0) __attribute__((always_inline)) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
-	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
-	E v[V];
-	auto exchange = [&](int from, int to) __attribute__((always_inline)) {
-		const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
-		#pragma unroll
-		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
-		__syncthreads();
-		#pragma unroll
-		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
-	};
-	const size_t gbase = (size_t) blockIdx.x << KL;
-	const unsigned dir = (unsigned) ((gbase >> stage) & 1);
-	{
-		// first group: register bits [KL-Q, KL), lanes read adjacent elements
-		const E* src = data + gbase + tbase(KL - Q);
-		#pragma unroll
-		for (int j = 0; j < V; ++j) v[j] = bt_in<E, MODE>(src[(unsigned) j << (KL - Q)]);
-	}
-	static_for<0, (KL + Q - 1) / Q>([&](auto gc) __attribute__((always_inline)) {
-		constexpr int g = decltype(gc)::value;
-		constexpr int p = KL - g * Q;
-		constexpr int b0 = p > Q ? p - Q : 0;
-		if (g > 0) exchange(p, b0);
-		reg_network_uniform<E, V, MODE>(v, p - b0, dir, kd);
-	});
-	{
-		const unsigned pf = phys(tbase(0));
-		#pragma unroll
-		for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
-		__syncthreads();
-		vec16* dst = reinterpret_cast<vec16*>(data + gbase) + tid;
-		#pragma unroll
-		for (int k = 0; k < V / PER; ++k) {
-			const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);   // PER consecutive slots: no multiple of 32 inside
-			vec16 t;
-			#pragma unroll
-			for (int q = 0; q < PER; ++q) t[q] = bt_out<E, MODE>(s[pe + q]);
-			dst[(unsigned) k << TB] = t;
-		}
-	}
-}
-
-// ---- pad the tail [numel, padded) with elements that sort last ----
-template <typename E>
-__global__ void clo_bitonic_pad_kernel(E* data, size_t numel, size_t padded, E pad) {
-	const size_t i = numel + (size_t) blockIdx.x * 256 + threadIdx.x;
-	if (i < padded) data[i] = pad;
-}
-
-size_t nlpo2(size_t x) {
-	size_t p = 1;
-	while (p < x) p <<= 1;
-	return p;
-}
-
-unsigned log2u(size_t x) {
-	unsigned l = 0;
-	while (((size_t) 1 << l) < x) ++l;
-	return l;
-}
-
-template <typename E>
-int make_desc(int key_shift, int key_bits, int key_size, int key_kind, int descending, key_desc* kd, E* pad) {
-	if (key_size != 1 && key_size != 2 && key_size != 4 && key_size != 8) return CLO_HIP_EARGS;
-	if (key_bits < 1 || key_bits > 8 * key_size) return CLO_HIP_EARGS;
-	if (key_shift < 0 || key_shift + key_bits > 8 * (int) sizeof(E)) return CLO_HIP_EARGS;
-	if (key_kind < 0 || key_kind > 2) return CLO_HIP_EARGS;
-	if (key_kind == 2 && (key_size < 2 || key_bits != 8 * key_size)) return CLO_HIP_EUNSUPPORTED;
-	kd->shift = (unsigned) key_shift;
-	kd->kind = (unsigned) key_kind;
-	kd->descending = descending ? 1u : 0u;
-	kd->mask = key_bits == 64 ? ~0ull : ((1ull << key_bits) - 1ull);
-	kd->signbit = 1ull << (8 * key_size - 1);
-	if (key_kind == 1 && key_bits < 8 * key_size) kd->kind = 0;  // sign bit masked off: plain unsigned order
-	// Element whose key is the last one in the requested order.
-	unsigned long long last_ordered = descending ? 0ull : kd->mask;  // in okey space
-	unsigned long long k = last_ordered;
-	if (key_kind == 1) k ^= kd->signbit;
-	else if (key_kind == 2) k = (k & kd->signbit) ? (k & ~kd->signbit) : (~k & kd->mask);
-	// all other bits of the element: ones (any value would do)
-	unsigned long long e = ~0ull;
-	e &= ~(kd->mask << key_shift);
-	e |= (k & kd->mask) << key_shift;
-	*pad = (E) e;
-	return 0;
-}
-
-template <typename E>
-int pad_tail(E* data, size_t numel, size_t padded, E pad, hipStream_t s) {
-	if (padded > numel) {
-		const size_t cnt = padded - numel;
-		hipLaunchKernelGGL((clo_bitonic_pad_kernel<E>), dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, s,
-			data, numel, padded, pad);
-	}
-	return 0;
-}
-
-template <typename E>
-int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
-	int* launches, hipStream_t s) {
-	E* data = (E*) vdata;
-	key_desc kd; E pad;
-	int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
-	if (st) return st;
-	const size_t n = nlpo2(numel);
-	const unsigned T = log2u(n);
-	pad_tail<E>(data, numel, n, pad, s);
-	int count = 0;
-	const size_t npairs = n / 2;
-	const unsigned blocks = (unsigned) ((npairs + 255) / 256);
-	for (unsigned stage = 1; stage <= T; ++stage)
-		for (unsigned step = stage; step >= 1; --step) {
-			clo_timing_scope timing("bitonic_step", s);
-			hipLaunchKernelGGL((clo_bitonic_step_kernel<E>), dim3(blocks), dim3(256), 0, s, data, npairs, stage, step, kd);
-			++count;
-		}
-	if (launches) *launches = count;
-	return (int) hipGetLastError();
-}
-
-template <typename E, int NS, int MODE>
-void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_desc& kd, hipStream_t s) {
-	const size_t threads = n >> NS;
-	clo_timing_scope timing("bitonic_strided", s);
-	hipLaunchKernelGGL((clo_bitonic_strided_kernel<E, NS, MODE>), dim3((unsigned) ((threads + 255) / 256)), dim3(256), 0, s,
-		data, n, stage, p, kd);
-}
-
-template <typename E, int MODE>
-int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
-	int* launches, hipStream_t s) {
-	// register bits per thread: 32 values of <= 4 bytes, 16 values of 8 bytes
-	constexpr int Q = sizeof(E) == 8 ? 4 : 5;
-	// Arrays of at least 2^KLF elements: 512-thread groups on tiles of 2^KLF
-	// (67 KiB of LDS, two groups per CU) with the compile-time schedule. Smaller
-	// ones are one tile, sorted by one launch of the run-time-schedule kernel.
-	constexpr int TBF = 9;
-	constexpr unsigned KLF = TBF + Q;
-	static_assert(KLF - 1 <= 8 + Q, "the run-time kernel covers every smaller array");
-	// strided passes need p - NS >= 6 so that a wave's 64 lanes read one
-	// contiguous row; KLF >= 13 guarantees it for every p > KLF.
-	E* data = (E*) vdata;
-	key_desc kd; E pad;
-	int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
-	if (st) return st;
-	const size_t n = nlpo2(numel);
-	const unsigned T = log2u(n);
-	if (T < (unsigned) Q) return simple_impl<E>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-	pad_tail<E>(data, numel, n, pad, s);
-	const unsigned kl = T < KLF ? T : KLF;
-	const unsigned tiles = (unsigned) (n >> kl);
-	int count = 0;
-	// stages 1..kl inside the tiles
-	{
-		clo_timing_scope timing("bitonic_presort", s);
-		if (kl == KLF)
-			hipLaunchKernelGGL((clo_bitonic_tile_presort_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, kd);
-		else
-			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
-	}
-	++count;
-	for (unsigned stage = kl + 1; stage <= T; ++stage) {
-		unsigned p = stage;
-		while (p > kl) {
-			// register bits of a strided pass: 64 values per thread for identity keys,
-			// one wave per SIMD — these passes only stream (76 us per 2^26 uint32). The
-			// general compare needs more temporaries: 32 (16 of 8 bytes). 128 values
-			// were measured too: 100-117 us per pass (412 VGPRs and up, spills), which
-			// costs more over a sort than the one pass it saves.
-			constexpr int QS = MODE == 0 ? Q + 1 : 6;
-			unsigned ns = p - kl;
-			if (ns > (unsigned) QS) ns = QS;
-			switch (ns) {
-				case 1: launch_strided<E, 1, MODE>(data, n, stage, p, kd, s); break;
-				case 2: launch_strided<E, 2, MODE>(data, n, stage, p, kd, s); break;
-				case 3: launch_strided<E, 3, MODE>(data, n, stage, p, kd, s); break;
-				case 4: launch_strided<E, 4, MODE>(data, n, stage, p, kd, s); break;
-				case 5: launch_strided<E, 5, MODE>(data, n, stage, p, kd, s); break;
-				default:
-					if constexpr (QS >= 6) launch_strided<E, 6, MODE>(data, n, stage, p, kd, s);
-					break;
-			}
-			++count;
-			p -= ns;
-		}
-		{
-			clo_timing_scope timing("bitonic_tile", s);
-			// stage > kl only happens with full tiles (kl == KLF)
-			hipLaunchKernelGGL((clo_bitonic_tile_merge_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, kd);
-		}
-		++count;
-	}
-	if (launches) *launches = count;
-	return (int) hipGetLastError();
-}
-
-template <typename E>
-int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
-	int* launches, hipStream_t s) {
-	const bool identity = key_shift == 0 && key_bits == 8 * (int) sizeof(E) && key_size == (int) sizeof(E);
-	if (identity && key_kind == 0)
-		return tiled_run<E, 1>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-	if (identity && key_kind == 1)
-		return tiled_run<E, 2>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-	if constexpr (sizeof(E) >= 2) {
-		if (identity && key_kind == 2)
-			return tiled_run<E, 3>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-	}
-	return tiled_run<E, 0>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-}
-
-// ---------------------------------------------------------------------------
-// gselect: global-memory selection (rank) sort, upstream's O(n^2) baseline
-// sorter (sort/clo_sort_gselect.cl:38-58): element gid goes to position
-//   #{ i : COMPARE(key_gid, key_i)  or  (key_i == key_gid and i < gid) }.
-// Upstream's work-item reads all n keys from global memory; here a work-group
-// stages 2048 ordered keys at a time in LDS and every thread walks the stage
-// (all lanes read the same LDS word: a broadcast, no bank conflicts).
-// ---------------------------------------------------------------------------
-constexpr int GSEL_THREADS = 256;
-constexpr int GSEL_STAGE = 2048;
-
-template <typename E>
-__device__ __forceinline__ unsigned long long gsel_key(E e, const key_desc& kd) {
-	unsigned long long raw = ((unsigned long long) e >> kd.shift) & kd.mask;
-	if (kd.kind == 2 && raw == kd.signbit) e = (E) ((unsigned long long) e & ~(kd.signbit << kd.shift));  // -0 == +0, as upstream's float compare
-	return okey<E>(e, kd);
-}
-
-template <typename E>
-__global__ __launch_bounds__(GSEL_THREADS)
-void clo_gselect_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n, key_desc kd) {
-	__shared__ unsigned long long s_key[GSEL_STAGE];
-	const size_t gid = (size_t) blockIdx.x * GSEL_THREADS + threadIdx.x;
-	const E mine = gid < n ? in[gid] : (E) 0;
-	const unsigned long long km = gsel_key<E>(mine, kd);
-	size_t pos = 0;
-	for (size_t base = 0; base < n; base += GSEL_STAGE) {
-		const unsigned cnt = n - base < (size_t) GSEL_STAGE ? (unsigned) (n - base) : (unsigned) GSEL_STAGE;
-		__syncthreads();
-		for (unsigned i = threadIdx.x; i < cnt; i += GSEL_THREADS) s_key[i] = gsel_key<E>(in[base + i], kd);
-		__syncthreads();
-		// ties: only elements with a smaller index count; the stage is wholly
-		// before gid, wholly after it, or contains it
-		const unsigned before = gid <= base ? 0u : (gid - base < (size_t) cnt ? (unsigned) (gid - base) : cnt);
-		unsigned c = 0;
-		if (kd.descending) {
-			for (unsigned i = 0; i < cnt; ++i) { const unsigned long long k = s_key[i]; c += (k > km) | ((k == km) & (i < before)); }
-		} else {
-			for (unsigned i = 0; i < cnt; ++i) { const unsigned long long k = s_key[i]; c += (k < km) | ((k == km) & (i < before)); }
-		}
-		pos += c;
-	}
-	if (gid < n && pos < n) out[pos] = mine;
-}
-
-template <typename E>
-int gselect_impl(const void* src, void* dst, size_t n, int key_shift, int key_bits, int key_size, int key_kind,
-	int descending, hipStream_t s) {
-	key_desc kd;
-	E pad;
-	const int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
-	if (st != 0) return st;
-	clo_timing_scope timing("gselect", s);
-	hipLaunchKernelGGL((clo_gselect_kernel<E>), dim3((unsigned) ((n + GSEL_THREADS - 1) / GSEL_THREADS)), dim3(GSEL_THREADS), 0, s,
-		(const E*) src, (E*) dst, n, kd);
-	return (int) hipGetLastError();
-}
-
-}  // namespace
+#include "clo_hip_bitonic_impl.h"
 
 extern "C" {
 
@@ -785,10 +75,11 @@ int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
 	if (!data) return CLO_HIP_EARGS;
 	hipStream_t s = (hipStream_t) stream;
 	switch (elem_size) {
-		case 1: return tiled_impl<uint8_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-		case 2: return tiled_impl<uint16_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-		case 4: return tiled_impl<uint32_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
-		case 8: return tiled_impl<uint64_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		// (one translation unit per element size: clo_hip_bitonic_e{1,2,4,8}.hip)
+		case 1: return clo_bitonic_tiled_e1(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 2: return clo_bitonic_tiled_e2(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 4: return clo_bitonic_tiled_e4(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 8: return clo_bitonic_tiled_e8(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }

@@ -1,0 +1,8 @@
+// clo_hip_bitonic_e1.hip — the tiled bitonic schedule (abitonic) for 1-byte
+// elements: see clo_hip_bitonic_impl.h / clo_hip_bitonic.hip.
+#include "clo_hip_bitonic_impl.h"
+
+int clo_bitonic_tiled_e1(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, hipStream_t s) {
+	return tiled_impl<uint8_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+}

@@ -68,6 +68,11 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
 	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits);
+// the tiled bitonic schedule, one translation unit per element size
+int clo_bitonic_tiled_e1(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
+int clo_bitonic_tiled_e2(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
+int clo_bitonic_tiled_e4(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
+int clo_bitonic_tiled_e8(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
 size_t clo_radixw_lds_bytes(int digit_bits);
 size_t clo_radixw_tile_elems(int elem_size);
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
