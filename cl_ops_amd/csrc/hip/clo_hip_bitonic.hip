@@ -13,17 +13,23 @@
 //  * clo_hip_bitonic_simple — one launch per (stage, step), global memory only:
 //    what sort/clo_sort_sbitonic.c:102-118 does.
 //  * clo_hip_bitonic_tiled  — replaces the 26-kernel strategy of
-//    sort/clo_sort_abitonic.c:58-313. Two kernels:
-//      - bitonic_tile: a work-group owns 2^KL consecutive elements in LDS and
-//        runs every step p <= KL of a stage (or all of stages 1..KL) there.
-//        Each thread keeps 2^Q elements in VGPRs and runs up to Q consecutive
-//        steps on them between two LDS exchanges; the LDS image is padded by
-//        one slot per 32 so that every exchange pattern is bank-conflict free.
+//    sort/clo_sort_abitonic.c:58-313 (kernels in clo_hip_bitonic_impl.h, one
+//    translation unit per element size: clo_hip_bitonic_e{1,2,4,8}.hip):
+//      - tile kernels: a work-group owns 2^KL consecutive elements in LDS
+//        (KL = 14, 13 for 8-byte elements) and runs every step p <= KL of a
+//        stage (the merge kernel) or all of stages 1..KL (the presort). Each
+//        thread keeps 2^Q elements in VGPRs and runs up to Q consecutive steps
+//        on them between two LDS exchanges; the schedule is fixed at compile
+//        time and the LDS image is padded by one slot per 32 so that every
+//        exchange pattern is bank-conflict free.
 //      - bitonic_strided: steps p > KL; each thread loads 2^NS elements
 //        2^(p-NS) apart (adjacent lanes = adjacent addresses, so every access
-//        is a full coalesced row), runs NS steps in VGPRs, stores them back.
-//    For 2^26 keys that is 38 passes over the array instead of the reference's
-//    58-62.
+//        is a full coalesced row), runs NS <= 6 steps in VGPRs, stores them back.
+//    For 2^26 4-byte keys that is 31 passes over the array instead of the
+//    reference's 58-62.
+// Whole-element integer and floating-point keys run bare min/max networks (the
+// latter on their order-preserving unsigned image); any other key the general
+// compare with keys carried through a register network.
 #include <hip/hip_runtime.h>
 
 #include <string>
