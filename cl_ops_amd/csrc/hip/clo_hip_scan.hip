@@ -311,10 +311,12 @@ unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never s
 // us of its 120 in that queue. Large arrays therefore use 1024-thread groups —
 // four times fewer tickets and look-back entries (2^26 uint -> ulong: 0.207 ->
 // 0.182 ms) — and small ones 256-thread groups, which spread over more CUs.
-// The large shape keeps 8 rows per thread whatever the sum type: 16 rows of
-// 4-byte sums need 108 VGPRs, which is ONE 16-wave group per CU, and a CU whose
-// only group sits in its look-back issues no loads (2^26 uint: 0.121 ms with 16
-// rows, 0.1135 with 8 — two groups per CU).
+// The large shape keeps 8 rows per thread whatever the sum type: 2^26 uint
+// measured 0.121 ms with 16 rows and 0.1135 with 8 (512 x 16 and 512 x 8 within
+// 2 % of that). Either way one 16-wave group is resident per CU (96 VGPRs with
+// 8 rows, 108 with 16; capping at 64 for two groups spills 82 registers): the
+// shorter tile is what helps — its load, look-back and store phases alternate
+// twice as often.
 constexpr size_t SCAN_BIG_NUMEL = (size_t) 1 << 24;
 constexpr int SCAN_BIG_ROWS = 8;
 constexpr int scan_threads(size_t numel) { return numel >= SCAN_BIG_NUMEL ? 1024 : 256; }
@@ -343,7 +345,7 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		if (e != hipSuccess) return (int) e;
 		clo_timing_scope timing("scan", s);
 		// as many work-groups as fit the chip at once; each draws tiles until none is left
-		const unsigned groups_big = (unsigned) (tiles < 512 ? tiles : 512), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
+		const unsigned groups_big = (unsigned) (tiles < 256 ? tiles : 256), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
 		if (scan_threads(n) == 1024)
 			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3(groups_big), dim3(1024), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
