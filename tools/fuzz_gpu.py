@@ -24,7 +24,8 @@ def main():
         alg = ["abitonic", "sbitonic", "satradix"][int(rng.integers(0, 3))]
         et = types[int(rng.integers(0, len(types)))]
         dt = clo.api.CLO_TYPE_NP[et]
-        logn = int(rng.integers(1, 22 if alg != "sbitonic" else 17))
+        top = int(os.environ.get("FUZZ_MAX_LOG2", "21"))
+        logn = int(rng.integers(1, (top + 1) if alg != "sbitonic" else 17))
         n = int(rng.integers(1 << (logn - 1), (1 << logn) + 1))
         if np.issubdtype(dt, np.floating):
             a = ((rng.random(n) - 0.5) * 1e6).astype(dt)
