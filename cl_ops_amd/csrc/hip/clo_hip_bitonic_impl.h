@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -83,14 +84,14 @@ __device__ __forceinline__ void cmpxch(E& a, E& b, unsigned dir, const key_desc&
 // 2^26 (uint key, uint value) pairs: 25.5 ms before). The swap rule is
 // cmpxch's, bit for bit. K: 32-bit image when the key has at most 32 bits.
 template <typename E, typename K, int V, typename DIRFN>
-__device__ __forceinline__ void reg_network_keyed(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn) {
+__device__ __forceinline__ void reg_network_keyed(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn, int min_half = 1) {
 	K k[V];
 	#pragma unroll
 	for (int j = 0; j < V; ++j) k[j] = (K) okey<E>(v[j], kd);
 	const bool desc = kd.descending != 0;
 	#pragma unroll
 	for (int half = V / 2; half >= 1; half /= 2) {
-		if (half < (1 << nsteps)) {
+		if (half < (1 << nsteps) && half >= min_half) {
 			#pragma unroll
 			for (int j = 0; j < V; ++j)
 				if ((j & half) == 0) {
@@ -107,9 +108,9 @@ __device__ __forceinline__ void reg_network_keyed(E (&v)[V], int nsteps, const k
 	}
 }
 template <typename E, int V, typename DIRFN>
-__device__ __forceinline__ void reg_network_general(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn) {
-	if (sizeof(E) <= 4 || (kd.mask >> 32) == 0ull) reg_network_keyed<E, unsigned, V>(v, nsteps, kd, dirfn);
-	else reg_network_keyed<E, unsigned long long, V>(v, nsteps, kd, dirfn);
+__device__ __forceinline__ void reg_network_general(E (&v)[V], int nsteps, const key_desc& kd, DIRFN dirfn, int min_half = 1) {
+	if (sizeof(E) <= 4 || (kd.mask >> 32) == 0ull) reg_network_keyed<E, unsigned, V>(v, nsteps, kd, dirfn, min_half);
+	else reg_network_keyed<E, unsigned long long, V>(v, nsteps, kd, dirfn, min_half);
 }
 
 // Up to log2(V) steps on the V values of one thread: strides 2^(nsteps-1) .. 1
@@ -142,11 +143,11 @@ __device__ __forceinline__ void reg_network(E (&v)[V], int nsteps, size_t idx0, 
 // (or work-group) spans: `dir` is then one scalar, and for whole-element integer
 // keys the exchange is a bare min/max pair under a scalar branch.
 template <typename E, int V, int MODE, bool UP>
-__device__ __forceinline__ void reg_network_minmax(E (&v)[V], int nsteps) {
+__device__ __forceinline__ void reg_network_minmax(E (&v)[V], int nsteps, int min_half = 1) {
 	typedef typename std::make_signed<E>::type S;
 	#pragma unroll
 	for (int half = V / 2; half >= 1; half /= 2) {
-		if (half < (1 << nsteps)) {
+		if (half < (1 << nsteps) && half >= min_half) {
 			#pragma unroll
 			for (int j = 0; j < V; ++j)
 				if ((j & half) == 0) {
@@ -160,13 +161,15 @@ __device__ __forceinline__ void reg_network_minmax(E (&v)[V], int nsteps) {
 	}
 }
 template <typename E, int V, int MODE>
-__device__ __forceinline__ void reg_network_uniform(E (&v)[V], int nsteps, unsigned dir, const key_desc& kd) {
+// (min_half: only the strides >= min_half, i.e. the TOP register bits — for a
+// group whose low register bits carry no step)
+__device__ __forceinline__ void reg_network_uniform(E (&v)[V], int nsteps, unsigned dir, const key_desc& kd, int min_half = 1) {
 	if (MODE == 0) {
-		reg_network_general<E, V>(v, nsteps, kd, [&](int) { return dir; });
+		reg_network_general<E, V>(v, nsteps, kd, [&](int) { return dir; }, min_half);
 	} else if ((dir ^ kd.descending) == 0) {
-		reg_network_minmax<E, V, MODE, true>(v, nsteps);
+		reg_network_minmax<E, V, MODE, true>(v, nsteps, min_half);
 	} else {
-		reg_network_minmax<E, V, MODE, false>(v, nsteps);
+		reg_network_minmax<E, V, MODE, false>(v, nsteps, min_half);
 	}
 }
 
@@ -496,6 +499,57 @@ void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned stage, key_des
 	}
 }
 
+// ---- two-level strided pass: steps p .. p-ns+1 (Q < ns <= 2Q) of a stage in ONE pass ----
+// A work-group owns 2^ns rows (the index bits [p-ns, p)) of 2^(KL-ns) contiguous
+// elements each, as a tile of 2^KL elements in LDS order t = row * 2^(KL-ns) +
+// column. Threads first hold the top Q row bits in registers (Q steps), exchange
+// once through LDS, then hold tile bits [KL-2Q, KL-Q), whose top ns-Q bits are the
+// remaining row bits (ns-Q steps). Rows are >= 64 bytes long, lanes run along
+// them. One pass where the plain strided kernel needs two.
+template <typename E, int Q, int TB, int MODE>
+__global__ __launch_bounds__(1 << TB)
+void clo_bitonic_strided2_kernel(E* __restrict__ data, unsigned stage, unsigned p, unsigned ns, key_desc kd) {
+	constexpr int V = 1 << Q;
+	constexpr int KL = TB + Q;
+	constexpr int TILE = V << TB;
+	constexpr int B1 = KL - Q, B2 = KL - 2 * Q;   // lowest tile bit held in registers, first / second group
+	static_assert(B2 >= 0, "two register groups inside the tile");
+	__shared__ E s[TILE + TILE / 32];
+
+	const unsigned tid = threadIdx.x;
+	auto tbase = [&](int b0) __attribute__((always_inline)) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
+	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
+	const unsigned C = (unsigned) KL - ns;        // column bits of the tile
+	const unsigned midbits = p - ns - C;          // index bits between the columns and the rows
+	const size_t w = blockIdx.x;
+	const size_t wbase = ((w >> midbits) << p) | ((w & (((size_t) 1 << midbits) - 1)) << C);
+	const unsigned cmask = (1u << C) - 1u;
+	auto gaddr = [&](unsigned t) __attribute__((always_inline)) { return wbase + ((size_t) (t >> C) << (p - ns)) + (t & cmask); };
+	const unsigned dir = (unsigned) ((wbase >> stage) & 1);   // stage >= p: a bit of the group's own part of the index
+	E v[V];
+	{
+		// register bits = the top Q row bits = index bits [p-Q, p)
+		const E* src = data + gaddr(tbase(B1));
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = bt_in<E, MODE>(src[(size_t) j << (p - Q)]);
+	}
+	reg_network_uniform<E, V, MODE>(v, Q, dir, kd);
+	{
+		const unsigned pf = phys(tbase(B1)), pt = phys(tbase(B2));
+		#pragma unroll
+		for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << B1)] = v[j];
+		__syncthreads();
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << B2)];
+	}
+	reg_network_uniform<E, V, MODE>(v, Q, dir, kd, V >> (ns - Q));
+	{
+		const unsigned t0 = tbase(B2);
+		#pragma unroll
+		for (int j = 0; j < V; ++j) data[gaddr(t0 | ((unsigned) j << B2))] = bt_out<E, MODE>(v[j]);
+	}
+}
+
 // ---- pad the tail [numel, padded) with elements that sort last ----
 template <typename E>
 __global__ void clo_bitonic_pad_kernel(E* data, size_t numel, size_t padded, E pad) {
@@ -574,6 +628,8 @@ int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_
 	return (int) hipGetLastError();
 }
 
+inline bool g_no_strided2() { static const bool off = getenv("CLO_BITONIC_NO_STRIDED2") != nullptr; return off; }   // (A/B measurements only)
+
 template <typename E, int NS, int MODE>
 void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_desc& kd, hipStream_t s) {
 	const size_t threads = n >> NS;
@@ -625,6 +681,18 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 			// costs more over a sort than the one pass it saves.
 			constexpr int QS = MODE == 0 ? Q + 1 : 6;
 			unsigned ns = p - kl;
+			{
+				// a two-level pass (up to 2Q steps) when it saves a pass over plain ones
+				const unsigned h = ns, n2 = h < 2u * Q ? h : 2u * Q;
+				const unsigned plain = (h + QS - 1) / QS, with2 = 1u + (h - n2 + QS - 1) / QS;
+				if (n2 > (unsigned) Q && with2 < plain && !g_no_strided2()) {
+					clo_timing_scope timing("bitonic_strided2", s);
+					hipLaunchKernelGGL((clo_bitonic_strided2_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, p, n2, kd);
+					++count;
+					p -= n2;
+					continue;
+				}
+			}
 			if (ns > (unsigned) QS) ns = QS;
 			switch (ns) {
 				case 1: launch_strided<E, 1, MODE>(data, n, stage, p, kd, s); break;

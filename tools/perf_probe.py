@@ -102,7 +102,7 @@ def probe_bitonic(ctx, q, logn, alg="abitonic"):
     lib.clo_hip_timing_enable(1)
     lib.clo_hip_timing_reset()
     timed(lambda: s.with_device_data(q, src, dst, n), q, reps=1)
-    k = kernels(["bitonic_presort", "bitonic_tile", "bitonic_strided", "bitonic_step"])
+    k = kernels(["bitonic_presort", "bitonic_tile", "bitonic_strided", "bitonic_strided2", "bitonic_step"])
     lib.clo_hip_timing_enable(0)
     lib.clo_hip_timing_reset()
     ms = timed(lambda: s.with_device_data(q, src, dst, n), q, reps=3)
