@@ -506,6 +506,25 @@ def test_abitonic_many_tiles_typed_and_descending(gpu, et, descending):
     assert np.array_equal(got, exp[::-1] if descending else exp)
 
 
+def test_abitonic_general_keys_tie_order_at_2p21(gpu):
+    """General keys over 128+ tiles: every strided width and the two-level strided
+    passes, tie order bit for bit the restated reference network's."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = 1 << 21
+    a = rand_u32(np.random.default_rng(21), n)
+    s = clo.Sorter("abitonic", ctx, "uint", get_key="((x) >> 20)")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, O.sbitonic(a, key_shift=20))
+    keys = np.random.default_rng(1).integers(0, 1000, n, dtype=np.uint64)
+    e = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter("abitonic", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    got = s.with_host_data(e, q)
+    s.close()
+    assert np.array_equal(got, O.sbitonic(e, key_size=4, key_shift=32))
+
+
 @pytest.mark.parametrize("alg", ["sbitonic", "abitonic", "satradix"])
 @pytest.mark.parametrize("et", ["float", "double", "half"])
 def test_float_keys_follow_the_ieee_total_order(gpu, alg, et):
