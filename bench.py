@@ -10,34 +10,51 @@ array: clo_sort_with_device_data(src -> dst) through the C-ABI of
 libcl_ops_hip.so; inputs are in HBM before the timed region starts (the
 reference times the exec queue only: clo_sort_bench.c:160-162,201-207).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak
-scaling, 2^28 keys per GPU; a step is the distributed sort of the 2^28*N-key
-array: MSD bucket histogram -> count all-gather -> local partition ->
-all-to-all(v) over xGMI -> local satradix (cl_ops_amd/multigpu.py).
-value = all keys of all ranks / max-over-ranks time.
+N > 1: one rank per GPU over RCCL. Started either by the driver
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) or
+by this script itself: with WORLD_SIZE unset, `python bench.py --gpus N` spawns
+that very command as a child process BEFORE anything here touches a GPU and
+exits with its code. A step is the distributed sort of the whole array: MSD
+bucket partition -> count all-gather -> all-to-all(v) over xGMI -> local
+satradix (cl_ops_amd/multigpu.py). Three legs, K timed steps each
+(--scaling both, the default):
+  weak    2^28 uint32 keys per GPU       -> the line's `value` (scaling: weak)
+  strong  2^28 uint32 keys in total      -> "strong": {...}  (BASELINE.json's
+          metric read literally: the same array at 1/2/4/8 GPUs)
+  u64     2^28 uint64 keys per GPU       -> "config5_u64": {...} (BASELINE
+          config 5 is this leg at N = 8: 2^31 keys)
+value = all keys of all ranks / max-over-ranks time. "ranks_seen" proves how
+many ranks took part (world size and an all-reduce of ones); "phases_ms" splits
+a step into partition / count exchange / key exchange / local sort.
 
 Rank 0 prints ONE JSON line. Besides the contract's fields it carries
-  roofline:     the dominant kernel (the pass kernel) against the HBM peak:
-                ALGORITHMIC bytes per launch / average launch duration measured
-                live with HIP events on the kernel's own stream. SURVEY.md §8d
-                prices a digit at 3*s bytes per element (read for histogram +
-                read for scatter + write); the histogram read is a kernel of its
-                own here, so the pass kernel is credited with the other two
-                streams, and a launch handles TWO 4-bit digits of every
-                element: 2 digits * 2*s * N. "moved_GBps" is what the kernel
-                must move at least (one read + one write per launch),
-                "traffic" what the PMC counters saw, and
-                "algorithmic_GBps_per_step" the whole sort at the contract's
-                3*s per digit (all kernels).
+  roofline:     PHYSICAL. `kernels` lists every kernel family of a step with
+                launches per step, mean launch duration (HIP events on the
+                kernel's own stream, measured live over K extra steps right
+                after the timed region) and the bytes a launch moves through
+                HBM: the PMC-measured traffic where profiles/traffic_*.json has
+                it (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), never less
+                than what the kernel must move at least. `frac` = those bytes /
+                duration / 8 TB/s for the dominant kernel — a fraction of the
+                chip's peak, <= 1. SURVEY.md §8d's accounting (3*s bytes per
+                element and 4-bit digit, whatever the kernels really move) is
+                reported next to it as `contract_A_*`; it exceeds 1 when a pass
+                handles two digits per trip through HBM.
   cpu_baseline: the CPU oracle (a port of the reference decomposition,
                 oracle/clo_oracle.c, OpenMP) on a bounded sample of the same
                 workload, on this box's host cores.
 Other workloads (parity-test configs, not bench lines): --workload
 {satradix_pairs,satradix_u64,scan,abitonic,sbitonic}.
+
+--dry-run (tests only): no GPU — gloo, CPU tensors and the numpy stand-in of
+the device steps from tests/numpy_ops.py, tiny sizes; exercises launching,
+rendezvous, the exchange plan and the JSON line. Its `value` is not a result.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,7 +67,7 @@ PREWARM = 3
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy ceiling)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -60,9 +77,12 @@ def parse_args():
     ap.add_argument("--log2n", type=int, default=None, help="log2 of elements per GPU (default: BASELINE size)")
     ap.add_argument("--radix", type=int, default=16)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--scaling", default="both", choices=["weak", "strong", "both"],
+                    help="N > 1: which legs to run (both = weak + strong + the uint64 leg of config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2n", type=int, default=None)
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="launcher / exchange-plan test on CPU (gloo); not a measurement")
+    return ap.parse_args(argv)
 
 
 WORKLOADS = {
@@ -90,26 +110,78 @@ def make_input(workload, n, seed):
     raise ValueError(workload)
 
 
-def algorithmic_bytes_per_elem(workload, radix):
-    """(per-launch bytes of the dominant kernel, per-step bytes), per element."""
+def reference_bitonic_round_trips(log2n):
+    """Global-memory round trips of the reference's abitonic strategy at work-group
+    size 1024 (clo_sort_abitonic.c:58-313: step 1 -> abit_any; steps above
+    sfs = min(12, log2(lws) + maxps) = 12 go four at a time (priv_4s16v); a stage at or
+    below sfs finishes in one local/hybrid kernel). 58 at 2^26 = SURVEY.md §8d's G_ref."""
+    sfs = 12
+    return sum(1 if s <= sfs else 1 + -(-(s - sfs) // 4) for s in range(1, log2n + 1))
+
+
+def contract_bytes_per_elem(workload, radix, log2n):
+    """SURVEY.md §8d's algorithmic bytes of one step, per element (the contract's
+    accounting, independent of what the kernels really move)."""
     bits = int(np.log2(radix))
     if workload == "satradix_u32":
-        return 3 * 4, (32 // bits) * 3 * 4
+        return (32 // bits) * 3 * 4
     if workload == "satradix_pairs":
-        return 3 * 8, (32 // bits) * 3 * 8
+        return (32 // bits) * 3 * 8
     if workload == "satradix_u64":
-        return 3 * 8, (64 // bits) * 3 * 8
+        return (64 // bits) * 3 * 8
     if workload == "scan":
-        return 8, 8
+        return 8
     if workload == "abitonic":
-        return 8, 8 * 58     # yardstick: G_ref = 58 global round trips of the reference strategy at 2^26
+        return 8 * reference_bitonic_round_trips(log2n)
     if workload == "sbitonic":
-        return 8, 8 * 136
+        return 8 * (log2n * (log2n + 1) // 2)
     raise ValueError(workload)
 
 
 DOMINANT_KERNEL = {"satradix_u32": "radix_pass", "satradix_pairs": "radix_pass", "satradix_u64": "radix_pass",
                    "scan": "scan", "abitonic": "bitonic_tile", "sbitonic": "bitonic_step"}
+
+# kernel families a step may launch (the labels of clo_hip_timing_read, include/clo_hip.h)
+FAMILIES = {
+    "satradix": ["radix_ghist", "radix_sweep", "radix_hist", "radix_offsets", "radix_pass", "radix_small"],
+    "scan": ["scan"],
+    "abitonic": ["bitonic_presort", "bitonic_tile", "bitonic_strided", "bitonic_strided2"],
+    "sbitonic": ["bitonic_step"],
+}
+
+
+def min_moved_bytes(label, n, es, radix):
+    """What one launch of the family must move through HBM at the very least
+    (element streams + its counters), from the kernels' definitions."""
+    bits = int(np.log2(radix))
+    pass_bits = 2 * bits if bits <= 4 else bits
+    tile = 512 * (8 if es == 8 else 16)
+    counters = -(-n // tile) * (1 << pass_bits) * 4          # one row of counters per tile
+    return {
+        "radix_hist": n * es + counters,                      # read every element, write the tile histograms
+        "radix_offsets": 2 * counters,                        # histograms in, offsets out (chunk sums are noise)
+        "radix_pass": 2 * n * es + 2 * counters,              # read + write every element, read both counter rows
+        "radix_ghist": n * es,                                # one read of the source
+        "radix_sweep": 2 * n * es + 2 * counters,             # read + write every element; publish + look back
+        "radix_small": 2 * n * es,
+        "scan": 2 * n * es,                                   # (uint32 -> uint32 workload)
+        "bitonic_presort": 2 * n * es, "bitonic_tile": 2 * n * es, "bitonic_strided": 2 * n * es,
+        "bitonic_strided2": 2 * n * es, "bitonic_step": 2 * n * es,
+    }[label]
+
+
+def load_traffic(workload):
+    """PMC-measured HBM bytes per launch by kernel family, from the tracked summary of
+    tools/collect_profiles.sh (separate --pmc FETCH_SIZE / WRITE_SIZE passes)."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return {}, None
+    fams = dict(d.get("families") or {})
+    if not fams and d.get("hbm_bytes_per_launch"):           # round-1 file: the dominant kernel only
+        fams = {DOMINANT_KERNEL[workload]: {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"]}}
+    return fams, {"log2n": d.get("log2n"), "source": d.get("source")}
 
 
 def cpu_baseline(workload, host_input, radix, sample_log2n):
@@ -145,17 +217,185 @@ def cpu_baseline(workload, host_input, radix, sample_log2n):
                       % (int(np.log2(m)), "OpenMP" if cores > 1 else "serial", dt, "" if ok else " (CHECK FAILED)")}
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
+# ----------------------------------------------------------------------------
+# launching N ranks from a plain `python bench.py --gpus N`
+# ----------------------------------------------------------------------------
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """No launcher started us: become the launcher. Nothing in this process has
+    touched a GPU yet (no torch import, no library load), and the ranks are fresh
+    child processes — never an exec of a process that initialised HIP."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------
+# the distributed legs (N > 1)
+# ----------------------------------------------------------------------------
+
+class _Backend:
+    """What differs between the real run (RCCL, HIP) and --dry-run (gloo, numpy)."""
+
+    def __init__(self, dry, local_rank):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.dry = torch, dist, dry
+        self.device = "cpu" if dry else torch.device("cuda", local_rank)
+        if not dry:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=self.device)
+
+    def sync(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def fence(self):
+        self.sync()
+        self.dist.barrier()
+        self.sync()
+
+    def ops(self, etype, local_rank):
+        if self.dry:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from numpy_ops import NumpyLocalOps          # test infrastructure, --dry-run only
+            return NumpyLocalOps(etype)
+        from cl_ops_amd.multigpu import HipLocalOps
+        return HipLocalOps(etype, local_rank)
+
+    def max_over_ranks(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix):
+    """K timed distributed sorts of n_local keys per rank; returns the leg's record
+    (on every rank; only rank 0's is printed)."""
+    torch, dist = be.torch, be.dist
+    from cl_ops_amd.multigpu import ShardedSorter
+    es = 4 if etype == "uint" else 8
+    workload = "satradix_u32" if es == 4 else "satradix_u64"
+    host = make_input(workload, n_local, seed + rank)
+    src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to(be.device)
+    sharded = ShardedSorter(be.ops(etype, local_rank))
+
+    def step():
+        return sharded.sort(src, n_local)      # the shard is only read: partition into the send buffer
+
+    for _ in range(PREWARM + warmup):
+        step()
+    be.fence()
+    # ---- timed region: exactly K steps, fenced on both sides ----
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    be.fence()
+    wall = time.perf_counter() - t0
+    t_max = be.max_over_ranks(wall)
+
+    # ---- phases: K more steps with device events around each phase (outside the timed region) ----
+    sharded.phase_times = {}
+    for _ in range(steps):
+        step()
+    be.fence()
+    phases = {k: be.max_over_ranks(v / steps) for k, v in sorted(sharded.collect_phase_times().items())}
+    sharded.phase_times = None
+
+    # ---- correctness of what was timed (size-independent properties) ----
+    out_t, m = last
+    udt = np.uint32 if es == 4 else np.uint64
+    got = out_t[:m].cpu().numpy().view(udt)
+    ok = bool(np.all(got[:-1] <= got[1:])) if m > 1 else True
+    # per rank: [first key, last key, count, xor of output keys, xor of input keys, sum out, sum in] as raw 64-bit words
+    mine = np.array([int(got[0]) if m else 0, int(got[-1]) if m else 0, m,
+                     int(np.bitwise_xor.reduce(got)) if m else 0, int(np.bitwise_xor.reduce(host)),
+                     int(got.sum(dtype=np.uint64)) if m else 0, int(host.sum(dtype=np.uint64))], dtype=np.uint64)
+    t_mine = torch.from_numpy(mine.view(np.int64).copy()).to(be.device)
+    alls = [torch.empty_like(t_mine) for _ in range(world)]
+    dist.all_gather(alls, t_mine)
+    a = torch.stack(alls).cpu().numpy().view(np.uint64)
+    ok = ok and int(a[:, 2].sum()) == n_local * world                              # nothing lost
+    ok = ok and all(a[i, 1] <= a[i + 1, 0] for i in range(world - 1) if a[i, 2] and a[i + 1, 2])  # rank order = key order
+    ok = ok and int(np.bitwise_xor.reduce(a[:, 3])) == int(np.bitwise_xor.reduce(a[:, 4]))         # same multiset (xor)
+    ok = ok and int(a[:, 5].sum(dtype=np.uint64)) == int(a[:, 6].sum(dtype=np.uint64))             # same multiset (sum mod 2^64)
+    ones = torch.ones(1, dtype=torch.int64, device=be.device)
+    dist.all_reduce(ones)
+    sharded.ops.close() if hasattr(sharded.ops, "close") else None
+    del src
+    return {"value": round(n_local * world * steps / t_max / 1e6, 1), "unit": "Mkeys/s",
+            "ms_per_step": round(t_max / steps * 1e3, 4), "elements_per_gpu": n_local, "elements_total": n_local * world,
+            "dtype": "u32" if es == 4 else "u64", "radix": radix, "correct": ok,
+            "ranks_seen": {"world_size": dist.get_world_size(), "allreduce_of_ones": int(ones.item())},
+            "largest_bucket_over_mean": round(float(a[:, 2].max()) / n_local, 4),
+            "phases_ms": {k: round(v * 1e3, 4) for k, v in phases.items()}}
+
+
+def main_sharded(args, world, rank, local_rank):
+    if args.workload not in ("satradix_u32", "satradix_u64"):
+        raise SystemExit("multi-GPU runs shard the satradix key sorts only; %s is replicas-only" % args.workload)
+    os.environ.setdefault("CLO_NO_WARMUP", "1")
+    be = _Backend(args.dry_run, local_rank)
+    etype = WORKLOADS[args.workload][1]
+    log2n = args.log2n or (12 if args.dry_run else WORKLOADS[args.workload][0])
+    n = 1 << log2n
+    wbits = world.bit_length() - 1
+    legs = {}
+    common = (args.steps, args.warmup, args.seed, rank, world, local_rank, args.radix)
+    if args.scaling in ("weak", "both"):
+        legs["weak"] = run_sharded_leg(be, etype, n, *common)
+    if args.scaling in ("strong", "both"):
+        legs["strong"] = run_sharded_leg(be, etype, max(n >> wbits, 1), *common)
+    if args.scaling == "both" and etype == "uint":       # BASELINE config 5's shape: uint64 keys, the same count per GPU
+        legs["config5_u64"] = run_sharded_leg(be, "ulong", n, *common)
+    head = legs.get("weak") or legs["strong"]
+    ok = all(l["correct"] for l in legs.values())
+    if rank == 0:
+        out = {
+            "metric": "Mkeys/s sorting 2^28 uint32 (satradix, 4-bit digits) at 1/2/4/8 GPUs",
+            "value": head["value"], "unit": "Mkeys/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "prewarm": PREWARM, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak" if "weak" in legs else "strong", "vs_baseline": None, "dtype": head["dtype"],
+            "data": "synthetic" if not args.dry_run else "dry-run (no GPU: gloo + numpy stand-ins; NOT a measurement)",
+            "config": {"workload": "satradix sort of %d x 2^%d %s keys sharded over %d GPUs, radix=%d"
+                                   % (world, int(np.log2(head["elements_per_gpu"])), "uint32" if etype == "uint" else "uint64",
+                                      world, args.radix),
+                       "elements_per_gpu": head["elements_per_gpu"], "radix": args.radix,
+                       "parallelism": "msd-bucket-exchange x%d (RCCL send/recv all-to-all) + local satradix" % world,
+                       "api": "cl_ops_amd.multigpu.ShardedSorter over clo_hip_msd_partition + clo_sort_with_device_data"},
+            "correct": ok, "ranks_seen": head["ranks_seen"], "phases_ms": head["phases_ms"],
+        }
+        for k, v in legs.items():
+            if v is not head:
+                out[k] = v
+        print(json.dumps(out), flush=True)
+    be.dist.barrier()
+    be.dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ----------------------------------------------------------------------------
+# one GPU
+# ----------------------------------------------------------------------------
+
+def main_single(args):
     # The library loads its kernels at sorter creation with two small dummy sorts;
     # this script has untimed steps of its own for that, and the dummy launches
     # would dilute the per-kernel averages of a rocprofv3 run of this command.
@@ -167,62 +407,40 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
+    torch.cuda.set_device(0)
     workload = args.workload
     log2n = args.log2n or WORKLOADS[workload][0]
     n = 1 << log2n
     etype = WORKLOADS[workload][1]
     es = 4 if etype == "uint" else 8
-    if world > 1 and workload not in ("satradix_u32", "satradix_u64"):
-        raise SystemExit("multi-GPU runs shard the satradix key sorts only; %s is replicas-only" % workload)
 
-    host = make_input(workload, n, args.seed + rank)
-    tdt = torch.int32 if es == 4 else torch.int64
+    host = make_input(workload, n, args.seed)
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to("cuda")
     dst = torch.empty_like(src)
     torch.cuda.synchronize()
 
-    ctx = clo.Context(local_rank)
+    ctx = clo.Context(0)
     # our own queue = our own HIP stream; every kernel of the path runs on it
     q = clo.Queue(ctx, profiling=False)
     bsrc = clo.Buffer(ctx, n * es, device_ptr=src.data_ptr())
     bdst = clo.Buffer(ctx, n * es, device_ptr=dst.data_ptr())
 
-    sharded = None
     if workload.startswith("satradix"):
         kw = {}
         if workload == "satradix_pairs":
             kw = dict(key_type="uint", get_key="(uint) ((x) >> 32)")
         op = clo.Sorter("satradix", ctx, etype, options="radix=%d" % args.radix, **kw)
-        if world > 1:
-            from cl_ops_amd.multigpu import HipLocalOps, ShardedSorter
-            sharded = ShardedSorter(HipLocalOps(etype, local_rank))
     elif workload == "scan":
         op = clo.Scanner("blelloch", ctx, "uint", "uint")
     else:
         op = clo.Sorter(workload, ctx, "uint")
 
     def step():
-        if sharded is not None:
-            return sharded.sort(src, n)          # the shard is only read: histogram + partition into the send buffer
-        if workload == "scan":
-            op.with_device_data(q, bsrc, bdst, n)
-        else:
-            op.with_device_data(q, bsrc, bdst, n)  # src stays unsorted, result in dst
-        return None
+        op.with_device_data(q, bsrc, bdst, n)  # src stays unsorted, result in dst
 
     def fence():
         q.finish()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     # PREWARM untimed steps first (allocations of the cached aux buffers, clock
     # ramp), then the W warm-up steps the caller asked for
@@ -234,13 +452,12 @@ def main():
     timer = clo.HipEventTimer(q)
     t0 = time.perf_counter()
     timer.start()
-    last = None
     for _ in range(args.steps):
-        last = step()
+        step()
     timer.stop()
     fence()
     wall = time.perf_counter() - t0
-    dev_ms = timer.elapsed_ms() if sharded is None else None
+    dev_ms = timer.elapsed_ms()
 
     # ---- roofline leg: the same K steps again with every kernel launch
     # bracketed by HIP events on its own stream (clo_hip_timing_*). Kept out of
@@ -253,113 +470,102 @@ def main():
     fence()
     lib.clo_hip_timing_enable(0)
 
-    t_max = wall
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-
     # ---- correctness of what was timed (size-independent properties) ----
-    ok = True
-    if sharded is not None:
-        out_t, m = last
-        udt = np.uint32 if es == 4 else np.uint64
-        got = out_t[:m].cpu().numpy().view(udt)
-        ok = bool(np.all(got[:-1] <= got[1:])) if m > 1 else True
-        # per rank: [first key, last key, count, xor of output keys, xor of input keys] as raw 64-bit words
-        mine = np.array([int(got[0]) if m else 0, int(got[-1]) if m else 0, m,
-                         int(np.bitwise_xor.reduce(got)) if m else 0, int(np.bitwise_xor.reduce(host))],
-                        dtype=np.uint64)
-        t_mine = torch.from_numpy(mine.view(np.int64).copy()).cuda()
-        alls = [torch.empty_like(t_mine) for _ in range(world)]
-        dist.all_gather(alls, t_mine)
-        if rank == 0:
-            a = torch.stack(alls).cpu().numpy().view(np.uint64)
-            ok = ok and int(a[:, 2].sum()) == n * world                    # nothing lost
-            ok = ok and all(a[i, 1] <= a[i + 1, 0] for i in range(world - 1) if a[i, 2] and a[i + 1, 2])  # rank order = key order
-            ok = ok and int(np.bitwise_xor.reduce(a[:, 3])) == int(np.bitwise_xor.reduce(a[:, 4]))       # same multiset
+    got = dst.cpu().numpy().view(host.dtype)
+    if workload == "scan":
+        ok = bool(np.array_equal(got, (np.cumsum(host, dtype=np.uint64) - host).astype(np.uint32)))
+    elif workload == "satradix_pairs":
+        k = got >> np.uint64(32)
+        v = got & np.uint64(0xFFFFFFFF)
+        ok = bool(np.all(k[:-1] <= k[1:])) and bool(np.all((k[:-1] != k[1:]) | (v[:-1] < v[1:])))  # stable
+        ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
     else:
-        got = dst.cpu().numpy().view(host.dtype)
-        if workload == "scan":
-            ok = bool(np.array_equal(got, (np.cumsum(host, dtype=np.uint64) - host).astype(np.uint32)))
-        elif workload == "satradix_pairs":
-            k = got >> np.uint64(32)
-            v = got & np.uint64(0xFFFFFFFF)
-            ok = bool(np.all(k[:-1] <= k[1:])) and bool(np.all((k[:-1] != k[1:]) | (v[:-1] < v[1:])))  # stable
-            ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
-        else:
-            ok = bool(np.all(got[:-1] <= got[1:]))
-            ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
-            ok = ok and int(got.sum(dtype=np.uint64)) == int(host.sum(dtype=np.uint64))
+        ok = bool(np.all(got[:-1] <= got[1:]))
+        ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
+        ok = ok and int(got.sum(dtype=np.uint64)) == int(host.sum(dtype=np.uint64))
 
-    if rank == 0:
-        per_launch_B, per_step_B = algorithmic_bytes_per_elem(workload, args.radix)
-        label = DOMINANT_KERNEL[workload]
+    # ---- the line ----
+    group = "satradix" if workload.startswith("satradix") else workload
+    traffic, tmeta = load_traffic(workload)
+    if tmeta and tmeta.get("log2n") not in (None, log2n):
+        traffic = {}                                   # measured at another size: not comparable
+    kernels = []
+    for label in FAMILIES[group]:
         cnt, tot_ms = _hip.timing_read(label)
-        avg_ms = tot_ms / cnt if cnt else float("nan")
-        per_launch_elems = n  # every launch of the dominant kernel sweeps the local array once
-        digits_per_launch = 1
-        if workload.startswith("satradix") and cnt:
-            # the pass kernel handles several digit steps per launch (two 4-bit digits at radix 16)
-            key_bits = 64 if workload == "satradix_u64" else 32
-            digits = key_bits // int(np.log2(args.radix))
-            digits_per_launch = max(1, round(digits * args.steps / cnt))
-            per_launch_B = 2 * es * digits_per_launch   # scatter read + write, per digit step
-        achieved = per_launch_B * per_launch_elems / (avg_ms * 1e-3) if cnt else float("nan")
-        moved = 2 * es * per_launch_elems / (avg_ms * 1e-3) if cnt and workload.startswith("satradix") else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        unit = "MValues/s" if workload == "scan" else "Mkeys/s"
-        total_elems = n * world * args.steps
-        out = {
-            "metric": "Mkeys/s sorting 2^28 uint32 (satradix, 4-bit digits); achieved % of HBM roofline"
-                      if workload == "satradix_u32" else WORKLOADS[workload][2],
-            "value": round(total_elems / t_max / 1e6, 1),
-            "unit": unit,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "prewarm": PREWARM,
-            "ms_per_step": round(t_max / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32" if es == 4 else "u64",
-            "data": "synthetic",
-            "config": {"workload": WORKLOADS[workload][2], "elements_per_gpu": n, "radix": args.radix,
-                       "parallelism": "single GPU" if world == 1 else
-                       "msd-bucket-exchange x%d (RCCL send/recv all-to-all) + local satradix" % world,
-                       "api": "clo_sort_with_device_data" if workload != "scan" else "clo_scan_with_device_data"},
-            "correct": ok,
-            "device_ms_per_step": round(dev_ms / args.steps, 4) if dev_ms is not None else None,
-            "algorithmic_GBps_per_step": round(per_step_B * n * world / (t_max / args.steps) / 1e9, 1),
-            "roofline": {"bound": "hbm", "kernel": label, "launches": cnt,
-                         "avg_launch_ms": round(avg_ms, 5),
-                         "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_launch_B * per_launch_elems,
-                         "digit_steps_per_launch": digits_per_launch,
-                         "moved_GBps": round(moved / 1e9, 1) if moved else None,
-                         "note": "per-launch durations from HIP events on the kernel's stream over %d extra steps "
-                                 "run right after the timed region" % args.steps},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            # sized for about 10-30 core-seconds of CPU work
-            default_sample = {"satradix_u32": 28, "satradix_pairs": 27, "satradix_u64": 26, "scan": 26,
-                              "abitonic": 20, "sbitonic": 16}[workload]
-            out["cpu_baseline"] = cpu_baseline(workload, host, args.radix,
-                                               args.cpu_sample_log2n or default_sample)
-        print(json.dumps(out), flush=True)
-
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if not cnt:
+            continue
+        avg_ms = tot_ms / cnt
+        floor_b = min_moved_bytes(label, n, es, args.radix)
+        pmc_b = (traffic.get(label) or {}).get("hbm_bytes_per_launch")
+        moved = max(floor_b, pmc_b or 0)
+        kernels.append({"name": label, "launches_per_step": round(cnt / args.steps, 3), "avg_launch_ms": round(avg_ms, 5),
+                        "bytes_per_launch": int(moved), "traffic_pmc": pmc_b, "min_moved_bytes": int(floor_b),
+                        "GBps": round(moved / (avg_ms * 1e-3) / 1e9, 1),
+                        "frac": round(moved / (avg_ms * 1e-3) / HBM_PEAK, 4)})
+    label = DOMINANT_KERNEL[workload]
+    if not any(k["name"] == label for k in kernels) and kernels:
+        label = max(kernels, key=lambda k: k["avg_launch_ms"] * k["launches_per_step"])["name"]
+    dom = next((k for k in kernels if k["name"] == label), None)
+    step_bytes = sum(k["bytes_per_launch"] * k["launches_per_step"] for k in kernels)
+    kernel_ms = sum(k["avg_launch_ms"] * k["launches_per_step"] for k in kernels)
+    contract_B = contract_bytes_per_elem(workload, args.radix, log2n) * n
+    unit = "MValues/s" if workload == "scan" else "Mkeys/s"
+    ms_step = wall / args.steps * 1e3
+    roof = {"bound": "hbm", "kernel": label, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+    if dom:
+        assert dom["frac"] <= 1.0, "a physical fraction above 1: %r" % (dom,)
+        roof.update({
+            "achieved": dom["GBps"], "frac": dom["frac"], "traffic": dom["traffic_pmc"],
+            "launches": int(round(dom["launches_per_step"] * args.steps)), "avg_launch_ms": dom["avg_launch_ms"],
+            "bytes_per_launch": dom["bytes_per_launch"],
+            "basis": "PMC traffic (profiles/traffic_%s.json)" % workload if dom["traffic_pmc"] else
+                     "minimum moved bytes (no PMC summary for this size in profiles/)",
+        })
+    roof.update({
+        "kernels": kernels,
+        "kernel_ms_per_step": round(kernel_ms, 4),                # sum over the list: what is left of ms_per_step is launch gaps
+        "traffic_step_bytes": int(step_bytes),
+        "step_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+        "step_frac": round(step_bytes / (ms_step * 1e-3) / HBM_PEAK, 4),   # whole step, physical
+        "contract_A_bytes_per_step": int(contract_B),              # SURVEY.md §8d's accounting
+        "contract_A_GBps": round(contract_B / (ms_step * 1e-3) / 1e9, 1),
+        "contract_A_frac": round(contract_B / (ms_step * 1e-3) / HBM_PEAK, 4),
+        "note": "per-launch durations from HIP events on the kernel's stream over %d extra steps run right after the "
+                "timed region; frac = bytes really moved / duration / 8 TB/s" % args.steps,
+    })
+    out = {
+        "metric": "Mkeys/s sorting 2^28 uint32 (satradix, 4-bit digits); achieved % of HBM roofline"
+                  if workload == "satradix_u32" else WORKLOADS[workload][2],
+        "value": round(n * args.steps / wall / 1e6, 1), "unit": unit, "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "prewarm": PREWARM, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32" if es == 4 else "u64", "data": "synthetic",
+        "config": {"workload": WORKLOADS[workload][2] if log2n == WORKLOADS[workload][0] else
+                   WORKLOADS[workload][2].replace("2^%d" % WORKLOADS[workload][0], "2^%d" % log2n),
+                   "elements_per_gpu": n, "radix": args.radix, "parallelism": "single GPU",
+                   "api": "clo_sort_with_device_data" if workload != "scan" else "clo_scan_with_device_data"},
+        "correct": ok, "device_ms_per_step": round(dev_ms / args.steps, 4), "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        # sized for about 10-30 core-seconds of CPU work
+        default_sample = {"satradix_u32": 28, "satradix_pairs": 27, "satradix_u64": 26, "scan": 26,
+                          "abitonic": 20, "sbitonic": 16}[workload]
+        out["cpu_baseline"] = cpu_baseline(workload, host, args.radix, args.cpu_sample_log2n or default_sample)
+    print(json.dumps(out), flush=True)
     return 0 if ok else 1
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0:                     # started as a plain script
+        if args.gpus > 1:
+            return self_launch(args)
+        return main_single(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return main_single(args)
+    return main_sharded(args, world, rank, local_rank)
 
 
 if __name__ == "__main__":

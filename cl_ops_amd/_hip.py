@@ -48,6 +48,7 @@ _sig("clo_hip_memcpy_d2d_async", ci, vp, vp, sz, vp)
 _sig("clo_hip_memset_async", ci, vp, ci, sz, vp)
 _sig("clo_hip_host_register", ci, vp, sz)
 _sig("clo_hip_host_unregister", ci, vp)
+_sig("clo_hip_stream_is_capturing", ci, vp)
 _sig("clo_hip_graph_capture_begin", ci, vp)
 _sig("clo_hip_graph_capture_end", ci, vp, C.POINTER(vp))
 _sig("clo_hip_graph_launch", ci, vp, vp)
@@ -61,6 +62,8 @@ _sig("clo_hip_event_elapsed_ms", ci, vp, vp, C.POINTER(C.c_float))
 _sig("clo_hip_stream_wait_event", ci, vp, vp)
 _sig("clo_hip_error_string", C.c_char_p, ci)
 _sig("clo_hip_scan_workspace_bytes", sz, sz, ci, ci)
+_sig("clo_hip_scan_workspace_init", ci, vp, sz, vp)
+_sig("clo_hip_scan_workspace_set_epoch", ci, vp, C.c_uint, vp)
 _sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_scan_exclusive_carry", ci, vp, vp, sz, ci, ci, ci, vp, vp, vp, sz, vp)
 _sig("clo_hip_reduce_sum", ci, vp, sz, ci, ci, vp, vp)

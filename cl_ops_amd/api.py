@@ -89,6 +89,15 @@ _sig("ccl_prof_add_queue", None, vp, C.c_char_p, vp)
 _sig("ccl_prof_calc", _u32, vp, _E)
 _sig("ccl_prof_get_duration", C.c_uint64, vp)
 
+
+class ProfAgg(C.Structure):
+    _fields_ = [("event_name", C.c_char_p), ("absolute_time", C.c_uint64), ("relative_time", C.c_double)]
+
+
+_sig("ccl_prof_get_agg", C.POINTER(ProfAgg), vp, C.c_char_p)
+_sig("ccl_prof_iter_agg_init", None, vp, ci)
+_sig("ccl_prof_iter_agg_next", C.POINTER(ProfAgg), vp)
+
 _sig("clo_sort_new", vp, C.c_char_p, C.c_char_p, vp, C.POINTER(ci), C.POINTER(ci), C.c_char_p, C.c_char_p,
      C.c_char_p, _E)
 _sig("clo_sort_destroy", None, vp)
@@ -401,6 +410,17 @@ class Profiler:
         lib.ccl_prof_calc(self.h, err.ref)
         err.raise_if_set()
         return lib.ccl_prof_get_duration(self.h)
+
+    def aggregates(self):
+        """{event name: total ns} of the last duration_ns() call (cf4ocl2: ccl_prof_iter_agg_*)."""
+        out = {}
+        lib.ccl_prof_iter_agg_init(self.h, 0)
+        while True:
+            a = lib.ccl_prof_iter_agg_next(self.h)
+            if not a:
+                break
+            out[a.contents.event_name.decode()] = a.contents.absolute_time
+        return out
 
     def close(self):
         if self.h:

@@ -7,6 +7,7 @@
 #include "clo_hip.h"
 
 #include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -29,10 +30,25 @@ struct ccl_context {
 
 struct ccl_event {
 	struct ccl_event* next;  /* queue-owned list */
+	struct ccl_queue* cq;    /* the queue that owns it */
 	char name[48];
 	void* start;             /* hip events; start only when profiling */
 	void* end;
 };
+
+/* A device status word some kernel of this queue's commands may raise (the
+ * bounded look-back spins), shared between its owner (a scanner) and the
+ * queues that have run its commands. */
+struct clo_status_cell {
+	int refs;
+	void* dev_word;   /* NULL once the owner has released the memory */
+	int tripped;      /* set when a check found the word raised; the owner re-initialises its workspace */
+};
+
+#define CCL_QUEUE_MAX_CELLS 8
+/* Events a queue WITHOUT profiling keeps alive (the most recent ones; a queue
+ * with profiling keeps all of them until ccl_prof_calc / ccl_queue_gc). */
+#define CCL_QUEUE_KEEP_EVENTS 64
 
 struct ccl_queue {
 	CCLContext* ctx;
@@ -41,6 +57,9 @@ struct ccl_queue {
 	int profiling;
 	struct ccl_event* events;  /* most recent first */
 	struct ccl_event* first;   /* oldest since last gc */
+	size_t nevents;
+	struct clo_status_cell* cells[CCL_QUEUE_MAX_CELLS];
+	int ncells;
 };
 
 struct ccl_buffer {
@@ -65,6 +84,9 @@ struct ccl_prof {
 	CCLQueue* queues[CCL_PROF_MAX_QUEUES];
 	int nqueues;
 	cl_ulong duration_ns;
+	CCLProfAgg* aggs;     /* per event name, filled by ccl_prof_calc */
+	char (*agg_names)[48];
+	size_t naggs, cap, iter;
 };
 
 GQuark ccl_hip_error_quark(void) { return CLO_QUARK("ccl-hip-error-quark"); }
@@ -192,12 +214,65 @@ void ccl_queue_gc(CCLQueue* cq) {
 	}
 	cq->events = NULL;
 	cq->first = NULL;
+	cq->nevents = 0;
+}
+
+/* ---- status cells (clo_ccl.h, internal part) ---- */
+
+clo_status_cell* clo_status_cell_new(void* dev_word) {
+	clo_status_cell* c = (clo_status_cell*) calloc(1, sizeof(*c));
+	if (c) { c->refs = 1; c->dev_word = dev_word; }
+	return c;
+}
+
+void clo_status_cell_set_word(clo_status_cell* c, void* dev_word) { if (c) c->dev_word = dev_word; }
+int clo_status_cell_take_tripped(clo_status_cell* c) { if (!c || !c->tripped) return 0; c->tripped = 0; return 1; }
+
+void clo_status_cell_unref(clo_status_cell* c) {
+	if (c && --c->refs == 0) free(c);
+}
+
+void ccl_queue_watch_status(CCLQueue* cq, clo_status_cell* cell) {
+	if (!cq || !cell) return;
+	for (int i = 0; i < cq->ncells; ++i) if (cq->cells[i] == cell) return;
+	if (cq->ncells == CCL_QUEUE_MAX_CELLS) {   /* drop the oldest watch */
+		clo_status_cell_unref(cq->cells[0]);
+		memmove(&cq->cells[0], &cq->cells[1], (CCL_QUEUE_MAX_CELLS - 1) * sizeof(cq->cells[0]));
+		--cq->ncells;
+	}
+	++cell->refs;
+	cq->cells[cq->ncells++] = cell;
+}
+
+/* After the queue's stream has been synchronised: did any watched kernel give
+ * up a bounded spin? Returns 0 (and sets err) if so. */
+static int queue_check_status(CCLQueue* cq, GError** err) {
+	int ok = 1;
+	for (int i = 0; i < cq->ncells; ++i) {
+		clo_status_cell* c = cq->cells[i];
+		if (!c->dev_word) continue;
+		const int st = clo_hip_check_status(c->dev_word, cq->stream);
+		if (st == CLO_HIP_ETIMEOUT) {
+			c->tripped = 1;
+			clo_hip_memset_async(c->dev_word, 0, sizeof(unsigned), cq->stream);
+			if (ok) clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY,
+				"A scan kernel gave up waiting for another work-group's prefix (bounded look-back spin): "
+				"the data this queue produced since its last synchronisation is not valid");
+			ok = 0;
+		} else if (st != 0 && ok) {
+			hip_failed(st, err, "clo_hip_check_status");
+			ok = 0;
+		}
+	}
+	return ok;
 }
 
 void ccl_queue_destroy(CCLQueue* cq) {
 	if (!cq) return;
 	clo_hip_set_device(cq->ctx->dev.index);
 	clo_hip_stream_synchronize(cq->stream);
+	for (int i = 0; i < cq->ncells; ++i) clo_status_cell_unref(cq->cells[i]);
+	cq->ncells = 0;
 	ccl_queue_gc(cq);
 	if (cq->owns_stream) clo_hip_stream_destroy(cq->stream);
 	ccl_context_unref(cq->ctx);
@@ -216,10 +291,18 @@ CCLContext* ccl_queue_get_context(CCLQueue* cq, GError** err) {
 
 cl_bool ccl_queue_finish(CCLQueue* cq, GError** err) {
 	if (!cq) return CL_FALSE;
-	return hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize") ? CL_FALSE : CL_TRUE;
+	if (hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize")) return CL_FALSE;
+	return queue_check_status(cq, err) ? CL_TRUE : CL_FALSE;
 }
 
 void* ccl_queue_get_stream(CCLQueue* cq) { return cq ? cq->stream : NULL; }
+int ccl_queue_is_profiling(CCLQueue* cq) { return cq ? cq->profiling : 0; }
+
+static void event_free(struct ccl_event* e) {
+	clo_hip_event_destroy(e->start);
+	clo_hip_event_destroy(e->end);
+	free(e);
+}
 
 CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err) {
 	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }
@@ -237,10 +320,36 @@ CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err) 
 			return NULL;
 		}
 	}
+	e->cq = cq;
 	e->next = cq->events;
 	cq->events = e;
 	if (!cq->first) cq->first = e;
+	if (++cq->nevents > 2 * CCL_QUEUE_KEEP_EVENTS && !cq->profiling) {
+		/* Nobody profiles this queue: only the most recent events stay (a loop
+		 * of sorts would otherwise grow the list without bound). An in-order
+		 * queue has finished or will finish the older commands first; destroying
+		 * a pending hipEvent is legal. */
+		struct ccl_event* keep = cq->events;
+		for (size_t i = 1; i < CCL_QUEUE_KEEP_EVENTS && keep->next; ++i) keep = keep->next;
+		struct ccl_event* old = keep->next;
+		keep->next = NULL;
+		cq->first = keep;
+		cq->nevents = CCL_QUEUE_KEEP_EVENTS;
+		while (old) { struct ccl_event* next = old->next; event_free(old); old = next; }
+	}
 	return e;
+}
+
+void ccl_queue_abort_command(CCLQueue* cq, CCLEvent* evt) {
+	if (!cq || !evt) return;
+	struct ccl_event** link = &cq->events;
+	while (*link && *link != evt) link = &(*link)->next;
+	if (!*link) return;
+	*link = evt->next;
+	if (cq->first == evt) cq->first = NULL;
+	for (struct ccl_event* e = cq->events; e; e = e->next) if (!e->next) cq->first = e;
+	if (cq->nevents) --cq->nevents;
+	event_free(evt);
 }
 
 cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err) {
@@ -315,8 +424,8 @@ static CCLEvent* enqueue_copy(CCLQueue* cq, const char* name, copy_fn fn, void* 
 	if (ewl) ccl_event_wait_list_clear(ewl);
 	CCLEvent* e = ccl_queue_begin_command(cq, name, err);
 	if (!e) return NULL;
-	if (hip_failed(fn(dst, src, size, cq->stream), err, name)) return NULL;
-	if (!ccl_queue_end_command(cq, e, err)) return NULL;
+	if (hip_failed(fn(dst, src, size, cq->stream), err, name)) { ccl_queue_abort_command(cq, e); return NULL; }
+	if (!ccl_queue_end_command(cq, e, err)) { ccl_queue_abort_command(cq, e); return NULL; }
 	if (blocking && hip_failed(clo_hip_event_synchronize(e->end), err, "hipEventSynchronize")) return NULL;
 	return e;
 }
@@ -400,6 +509,12 @@ cl_bool ccl_event_wait(CCLEventWaitList* ewl, GError** err) {
 	if (ewl && *ewl) {
 		for (size_t i = 0; i < (*ewl)->n && ok; ++i)
 			if (hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) ok = CL_FALSE;
+		/* a command that polls other work-groups may have given up: its queue
+		 * watches the status word (only queues that ran such commands pay this) */
+		for (size_t i = 0; i < (*ewl)->n && ok; ++i) {
+			CCLQueue* cq = (*ewl)->evts[i]->cq;
+			if (cq && cq->ncells > 0 && !queue_check_status(cq, err)) ok = CL_FALSE;
+		}
 		ccl_event_wait_list_clear(ewl);
 	}
 	return ok;
@@ -428,7 +543,44 @@ const char* ccl_program_get_build_options(CCLProgram* prg) { return prg ? prg->o
 /* ---------------- profiling ---------------- */
 
 CCLProf* ccl_prof_new(void) { return (CCLProf*) calloc(1, sizeof(CCLProf)); }
-void ccl_prof_destroy(CCLProf* prof) { free(prof); }
+void ccl_prof_destroy(CCLProf* prof) {
+	if (!prof) return;
+	free(prof->aggs);
+	free(prof->agg_names);
+	free(prof);
+}
+
+static void prof_agg_add(CCLProf* prof, const char* name, cl_ulong ns) {
+	for (size_t i = 0; i < prof->naggs; ++i)
+		if (strcmp(prof->agg_names[i], name) == 0) { prof->aggs[i].absolute_time += ns; return; }
+	if (prof->naggs == prof->cap) {
+		const size_t cap = prof->cap ? prof->cap * 2 : 8;
+		CCLProfAgg* a = (CCLProfAgg*) realloc(prof->aggs, cap * sizeof(*a));
+		if (!a) return;
+		prof->aggs = a;
+		char (*n)[48] = (char (*)[48]) realloc(prof->agg_names, cap * sizeof(*n));
+		if (!n) return;
+		prof->agg_names = n;
+		prof->cap = cap;
+	}
+	snprintf(prof->agg_names[prof->naggs], sizeof(prof->agg_names[0]), "%s", name);
+	prof->aggs[prof->naggs].absolute_time = ns;
+	prof->aggs[prof->naggs].relative_time = 0.0;
+	++prof->naggs;
+}
+
+const CCLProfAgg* ccl_prof_get_agg(CCLProf* prof, const char* event_name) {
+	if (!prof || !event_name) return NULL;
+	for (size_t i = 0; i < prof->naggs; ++i)
+		if (strcmp(prof->agg_names[i], event_name) == 0) return &prof->aggs[i];
+	return NULL;
+}
+
+void ccl_prof_iter_agg_init(CCLProf* prof, int sort) { (void) sort; if (prof) prof->iter = 0; }
+const CCLProfAgg* ccl_prof_iter_agg_next(CCLProf* prof) {
+	if (!prof || prof->iter >= prof->naggs) return NULL;
+	return &prof->aggs[prof->iter++];
+}
 
 void ccl_prof_add_queue(CCLProf* prof, const char* name, CCLQueue* cq) {
 	(void) name;
@@ -438,6 +590,7 @@ void ccl_prof_add_queue(CCLProf* prof, const char* name, CCLQueue* cq) {
 cl_bool ccl_prof_calc(CCLProf* prof, GError** err) {
 	if (!prof) return CL_FALSE;
 	prof->duration_ns = 0;
+	prof->naggs = 0;
 	for (int q = 0; q < prof->nqueues; ++q) {
 		CCLQueue* cq = prof->queues[q];
 		if (!cq->profiling) {
@@ -446,6 +599,7 @@ cl_bool ccl_prof_calc(CCLProf* prof, GError** err) {
 		}
 		if (!cq->events) continue;
 		if (hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize")) return CL_FALSE;
+		if (!queue_check_status(cq, err)) return CL_FALSE;
 		/* Sum of the commands' own durations: on an in-order queue that is the
 		 * time the device spent on them, idle gaps between commands (a chunked
 		 * pipeline waiting for its next copy) excluded — cf4ocl2's aggregate
@@ -455,9 +609,14 @@ cl_bool ccl_prof_calc(CCLProf* prof, GError** err) {
 			if (!e->start) continue;
 			if (hip_failed(clo_hip_event_elapsed_ms(e->start, e->end, &ms), err, "hipEventElapsedTime")) return CL_FALSE;
 			prof->duration_ns += (cl_ulong) ((double) ms * 1e6);
+			prof_agg_add(prof, e->name, (cl_ulong) ((double) ms * 1e6));
 		}
 		/* cf4ocl2 releases the queue's events once profiled. */
 		ccl_queue_gc(cq);
+	}
+	for (size_t i = 0; i < prof->naggs; ++i) {   /* (the names array may have moved while growing) */
+		prof->aggs[i].event_name = prof->agg_names[i];
+		prof->aggs[i].relative_time = prof->duration_ns ? (double) prof->aggs[i].absolute_time / (double) prof->duration_ns : 0.0;
 	}
 	return CL_TRUE;
 }

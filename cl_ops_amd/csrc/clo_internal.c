@@ -63,6 +63,48 @@ int clo_parse_options(const char* options, clo_option_cb cb, void* user, const c
 	return ok;
 }
 
+/* ---- per-kernel events (clo_internal.h) ---- */
+
+static void kernel_events_observer(void* user, const char* label, int phase, void* stream) {
+	clo_kernel_events* ke = (clo_kernel_events*) user;
+	(void) stream;
+	if (ke->failed) return;
+	if (phase == 0) {
+		const char* name = ke->other;
+		for (size_t i = 0; i < ke->nmap; ++i)
+			if (strcmp(ke->map[i].label, label) == 0) { name = ke->map[i].name; break; }
+		ke->open = ccl_queue_begin_command(ke->cq, name, NULL);
+		if (!ke->open) ke->failed = 1;
+	} else if (ke->open) {
+		if (!ccl_queue_end_command(ke->cq, ke->open, NULL)) {
+			ccl_queue_abort_command(ke->cq, ke->open);
+			ke->failed = 1;
+		} else {
+			ke->last = ke->open;
+		}
+		ke->open = NULL;
+	}
+}
+
+void clo_kernel_events_install(clo_kernel_events* ke, CCLQueue* cq, const clo_kname* map, size_t nmap, const char* other) {
+	memset(ke, 0, sizeof(*ke));
+	ke->cq = cq;
+	ke->map = map;
+	ke->nmap = nmap;
+	ke->other = other;
+	clo_hip_set_launch_observer(kernel_events_observer, ke);
+}
+
+CCLEvent* clo_kernel_events_remove(clo_kernel_events* ke, GError** err) {
+	clo_hip_set_launch_observer(NULL, NULL);
+	if (ke->open) { ccl_queue_abort_command(ke->cq, ke->open); ke->open = NULL; }   /* a launch that never reported its end */
+	if (ke->failed) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "Could not record the profiling events of a kernel launch");
+		return NULL;
+	}
+	return ke->last;
+}
+
 /* ---- cached launch sequences (clo_internal.h) ---- */
 
 void clo_graph_cache_release(clo_graph_cache* gc) {
@@ -81,20 +123,24 @@ int clo_graph_cache_run(clo_graph_cache* gc, int allowed, const void* k0, const 
 		gc->k0 = k0; gc->k1 = k1; gc->n = n; gc->variant = variant; gc->stream = stream;
 	}
 	if (allowed && same && gc->exec != NULL) return clo_hip_graph_launch(gc->exec, stream);
-	if (allowed && same && gc->seen >= 1) {
-		int st = clo_hip_graph_capture_begin(stream);
-		if (st != 0) return st;
-		st = enqueue(user, stream);
-		void* exec = NULL;
-		const int st2 = clo_hip_graph_capture_end(stream, &exec);
-		if (st != 0 || st2 != 0) {
-			clo_hip_graph_destroy(exec);
-			gc->seen = 0;   /* do not try again for this key */
-			return st != 0 ? st : st2;
+	/* Replay is an optimisation, never a requirement: the legacy NULL stream
+	 * (a queue adopted from torch's default stream) cannot be captured, nor can
+	 * a stream that is being captured already; and when capturing or
+	 * instantiating fails the sequence is simply enqueued. */
+	if (allowed && same && gc->seen >= 1 && stream != NULL && !clo_hip_stream_is_capturing(stream)) {
+		if (clo_hip_graph_capture_begin(stream) == 0) {
+			const int st = enqueue(user, stream);
+			void* exec = NULL;
+			const int st2 = clo_hip_graph_capture_end(stream, &exec);
+			if (st == 0 && st2 == 0 && exec != NULL) {
+				gc->exec = exec;
+				return clo_hip_graph_launch(exec, stream);   /* capturing recorded the launches, it did not run them */
+			}
+			clo_hip_graph_destroy(exec);   /* (nothing was enqueued: capturing only records) */
 		}
-		gc->exec = exec;
-		return clo_hip_graph_launch(exec, stream);   /* capturing recorded the launches, it did not run them */
+		gc->seen = -1;   /* never try to capture this key again */
+		return enqueue(user, stream);
 	}
-	gc->seen += 1;
+	if (gc->seen >= 0) gc->seen += 1;
 	return enqueue(user, stream);
 }

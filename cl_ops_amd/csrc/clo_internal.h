@@ -60,6 +60,50 @@ int clo_graph_cache_run(clo_graph_cache* gc, int allowed, const void* k0, const 
 	void* stream, clo_enqueue_fn enqueue, void* user);
 void clo_graph_cache_release(clo_graph_cache* gc);
 
+/* Extensions of a scan implementation that are NOT part of the public
+ * CloScanImplDef (whose layout is upstream's, clo_scan_abstract.in.h:41-103: a
+ * plugin compiled against upstream's header must stay valid). Looked up by
+ * implementation name; an implementation without an entry simply has none.
+ *  scan_chunk: scans `numel` elements at raw device pointers as one chunk of a
+ *    longer array: *carry_in_dev (device uint64, NULL = 0) is added to every
+ *    output, *carry_out_dev receives the next chunk's carry. Enqueued on cq_exec
+ *    as one command (a profiling queue sees it like any scan). Used by the
+ *    pipelined clo_scan_with_host_data.
+ *  check_status: after cq has been synchronised, fails with CLO_ERROR_LIBRARY if
+ *    a kernel of this scanner gave up a bounded spin (wrong output). */
+struct clo_scan;
+typedef struct {
+	const char* name;
+	cl_bool (*scan_chunk)(struct clo_scan* scanner, CCLQueue* cq_exec, const void* in_dev, void* out_dev, size_t numel,
+		const void* carry_in_dev, void* carry_out_dev, GError** err);
+	cl_bool (*check_status)(struct clo_scan* scanner, CCLQueue* cq, GError** err);
+} clo_scan_impl_ext;
+const clo_scan_impl_ext* clo_scan_impl_ext_find(const char* name);
+extern const clo_scan_impl_ext clo_scan_blelloch_ext;
+
+/* Per-kernel events on a profiling queue. Upstream enqueues every kernel itself
+ * and names its event (clo_sort_satradix.c:282,295,312; clo_scan_blelloch.c:158,
+ * 183,193; clo_sort_sbitonic.c:115), and CCLProf consumers see those names. Here
+ * one C-ABI call launches all the kernels of a sort, so while such a call runs
+ * the driver has the C-ABI report every launch (clo_hip_set_launch_observer) and
+ * opens / closes one CCLEvent per kernel, named through `map` (kernel family ->
+ * upstream's event name; families not listed get `other`). Only used when the
+ * queue profiles: event pairs between back-to-back kernels cost a few percent. */
+typedef struct { const char* label; const char* name; } clo_kname;
+typedef struct {
+	CCLQueue* cq;
+	const clo_kname* map;
+	size_t nmap;
+	const char* other;
+	CCLEvent* open;
+	CCLEvent* last;
+	int failed;
+} clo_kernel_events;
+void clo_kernel_events_install(clo_kernel_events* ke, CCLQueue* cq, const clo_kname* map, size_t nmap, const char* other);
+/* Removes the observer; returns the last kernel's event (NULL if there was no
+ * launch) and reports a failed event operation through err. */
+CCLEvent* clo_kernel_events_remove(clo_kernel_events* ke, GError** err);
+
 /* Set *err from a clo_hip_* status (domain CCL_HIP_ERROR); returns 1 if st != 0. */
 int clo_hip_failed(int st, GError** err, const char* what);
 

@@ -20,8 +20,16 @@ struct clo_scan {
 	CloType elem_type;
 	CloType sum_type;
 	void* data;
+	const clo_scan_impl_ext* ext;  /* private extensions of the implementation (clo_internal.h), or NULL */
 	struct scan_pipe_res* pipe;   /* streams / buffers of the pipelined host-data path, created on first use */
 };
+
+const clo_scan_impl_ext* clo_scan_impl_ext_find(const char* name) {
+	static const clo_scan_impl_ext* const table[] = { &clo_scan_blelloch_ext, NULL };
+	for (unsigned i = 0; table[i] != NULL; ++i)
+		if (strcmp(table[i]->name, name) == 0) return table[i];
+	return NULL;
+}
 
 /* Device-side resources of the pipelined clo_scan_with_host_data: creating a
  * stream costs milliseconds, so they are made once per scanner. */
@@ -72,6 +80,7 @@ CloScan* clo_scan_new(const char* type, const char* options, CCLContext* ctx,
 		scanner = (CloScan*) calloc(1, sizeof(CloScan));
 		if (!scanner) break;
 		scanner->impl_def = *impls[i];
+		scanner->ext = clo_scan_impl_ext_find(impls[i]->name);
 		ccl_context_ref(ctx);
 		scanner->ctx = ctx;
 		scanner->elem_type = elem_type;
@@ -277,7 +286,7 @@ static cl_bool scan_with_host_data_pipelined(CloScan* scanner, CCLQueue* cq_exec
 		if (st == 0) st = clo_hip_event_record(r->in_done[slot], s_in);
 		if (st == 0) st = clo_hip_stream_wait_event(s_exec, r->in_done[slot]);
 		if (st != 0) goto finish;
-		if (!scanner->impl_def.scan_chunk(scanner, cq_exec, r->in_dev[slot], r->out_dev[slot], cnt,
+		if (!scanner->ext->scan_chunk(scanner, cq_exec, r->in_dev[slot], r->out_dev[slot], cnt,
 			(char*) r->carry + slot * sizeof(uint64_t), (char*) r->carry + (slot ^ 1) * sizeof(uint64_t), err)) goto finish;
 		what = "hipEventRecord";
 		st = clo_hip_event_record(r->scan_done[slot], s_exec);
@@ -293,6 +302,9 @@ static cl_bool scan_with_host_data_pipelined(CloScan* scanner, CCLQueue* cq_exec
 	pthread_mutex_unlock(&p.mtx);
 	what = "copy out";
 	ok = st == 0;
+	/* every chunk is back on the host, so every scan has completed: did one of
+	 * them give up a look-back spin? */
+	if (ok && scanner->ext->check_status && !scanner->ext->check_status(scanner, cq_exec, err)) ok = CL_FALSE;
 
 finish:
 	if (helper_started) {
@@ -338,7 +350,7 @@ cl_bool clo_scan_with_host_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* c
 	}
 	if (cq_comm == NULL) cq_comm = cq_exec;
 
-	if (scanner->impl_def.scan_chunk != NULL && numel >= CLO_SCAN_PIPE_MIN_CHUNKS * CLO_SCAN_PIPE_CHUNK && ccl_queue_get_stream(cq_exec) != NULL
+	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && numel >= CLO_SCAN_PIPE_MIN_CHUNKS * CLO_SCAN_PIPE_CHUNK && ccl_queue_get_stream(cq_exec) != NULL
 		&& getenv("CLO_SCAN_NO_PIPELINE") == NULL) {   /* (the variable: A/B measurements only) */
 		status = scan_with_host_data_pipelined(scanner, cq_exec, cq_comm, data_in, data_out, numel, &err_internal);
 		if (err_internal) goto error_handler;
@@ -366,6 +378,8 @@ cl_bool clo_scan_with_host_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* c
 	ccl_event_set_name(evt, "clo_scan_read");
 	ccl_event_wait(ccl_ewl(&ewl, evt, NULL), &err_internal);
 	if (err_internal) goto error_handler;
+	/* the result is on the host: it is only good if no look-back spin gave up */
+	if (scanner->ext && scanner->ext->check_status && !scanner->ext->check_status(scanner, cq_exec, &err_internal)) goto error_handler;
 
 	status = CL_TRUE;
 	goto finish;

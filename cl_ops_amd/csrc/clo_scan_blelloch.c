@@ -16,8 +16,41 @@
 
 typedef struct {
 	clo_devbuf workspace;
+	void* ws_ready;            /* the allocation clo_hip_scan_workspace_init has prepared (NULL: none) */
+	size_t ws_ready_bytes;
+	clo_status_cell* status;   /* the workspace's status word, watched by the queues this scanner has used */
 	void* last_stream;
 } clo_scan_blelloch_data;
+
+/* The one kernel of this scanner does the jobs of upstream's three; its event
+ * carries the first one's name (clo_scan_blelloch.c:158). */
+#define CLO_SCAN_BLELLOCH_EVENT "clo_scan_blelloch_wgscan"
+
+/* The workspace for `numel` elements, ready for a scan on `stream`: (re)allocated
+ * when it has to grow, zeroed once per allocation (and again after a call that
+ * gave up a spin), its status word watched by the queue. */
+static int blelloch_workspace(CloScan* scanner, CCLQueue* cq_exec, size_t numel, GError** err) {
+	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scanner);
+	void* stream = ccl_queue_get_stream(cq_exec);
+	const int es = (int) clo_scan_get_element_size(scanner);
+	const int ss = (int) clo_scan_get_sum_size(scanner);
+	if (data->last_stream && data->last_stream != stream)
+		if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return 0;
+	data->last_stream = stream;
+	const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
+	if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return 0;
+	const int tripped = clo_status_cell_take_tripped(data->status);
+	if (data->ws_ready != data->workspace.ptr || data->ws_ready_bytes != data->workspace.bytes || tripped) {
+		if (clo_hip_failed(clo_hip_scan_workspace_init(data->workspace.ptr, data->workspace.bytes, stream), err,
+			"clo_hip_scan_workspace_init")) return 0;
+		data->ws_ready = data->workspace.ptr;
+		data->ws_ready_bytes = data->workspace.bytes;
+		clo_status_cell_set_word(data->status, data->workspace.ptr);
+	}
+	ccl_queue_watch_status(cq_exec, data->status);
+	clo_debug("BLELLOCH: N=%zu elem=%dB sum=%dB workspace=%zuB", numel, es, ss, ws);
+	return 1;
+}
 
 static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec,
 	CCLQueue* cq_comm, CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max,
@@ -39,48 +72,54 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 		return NULL;
 	}
 
-	if (numel > 0) {
-		if (data->last_stream && data->last_stream != stream)
-			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
-		data->last_stream = stream;
-		const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
-		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return NULL;
-		clo_debug("BLELLOCH: N=%zu elem=%dB sum=%dB workspace=%zuB", numel, es, ss, ws);
-	}
+	if (numel > 0 && !blelloch_workspace(scanner, cq_exec, numel, err)) return NULL;
 
-	CCLEvent* evt = ccl_queue_begin_command(cq_exec, "clo_scan_blelloch_wgscan", err);
+	CCLEvent* evt = ccl_queue_begin_command(cq_exec, CLO_SCAN_BLELLOCH_EVENT, err);
 	if (!evt) return NULL;
 
 	if (numel > 0) {
 		int st = clo_hip_scan_exclusive(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out),
 			numel, es, clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 			data->workspace.ptr, data->workspace.bytes, stream);
-		if (clo_hip_failed(st, err, "clo_hip_scan_exclusive")) return NULL;
+		if (clo_hip_failed(st, err, "clo_hip_scan_exclusive")) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	}
 
-	if (!ccl_queue_end_command(cq_exec, evt, err)) return NULL;
+	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	return evt;
 }
 
-/* One chunk of a longer scan, on raw device pointers (clo_scan.h: scan_chunk). */
+/* One chunk of a longer scan, on raw device pointers (clo_internal.h: clo_scan_impl_ext). */
 static cl_bool clo_scan_blelloch_scan_chunk(CloScan* scanner, CCLQueue* cq_exec, const void* in_dev, void* out_dev,
 	size_t numel, const void* carry_in_dev, void* carry_out_dev, GError** err) {
 	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scanner);
 	void* stream = ccl_queue_get_stream(cq_exec);
 	const int es = (int) clo_scan_get_element_size(scanner);
 	const int ss = (int) clo_scan_get_sum_size(scanner);
-	if (data->last_stream && data->last_stream != stream)
-		if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return CL_FALSE;
-	data->last_stream = stream;
-	if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, clo_hip_scan_workspace_bytes(numel, es, ss)), err,
-		"hipMalloc(scan workspace)")) return CL_FALSE;
-	CCLEvent* evt = ccl_queue_begin_command(cq_exec, "clo_scan_blelloch_wgscan", err);
+	if (!blelloch_workspace(scanner, cq_exec, numel, err)) return CL_FALSE;
+	CCLEvent* evt = ccl_queue_begin_command(cq_exec, CLO_SCAN_BLELLOCH_EVENT, err);
 	if (!evt) return CL_FALSE;
 	int st = clo_hip_scan_exclusive_carry(in_dev, out_dev, numel, es,
 		clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 		(const uint64_t*) carry_in_dev, (uint64_t*) carry_out_dev, data->workspace.ptr, data->workspace.bytes, stream);
-	if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_carry")) return CL_FALSE;
-	return ccl_queue_end_command(cq_exec, evt, err) ? CL_TRUE : CL_FALSE;
+	if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_carry")) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
+	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
+	return CL_TRUE;
+}
+
+/* After cq has been synchronised: did a scan of this scanner give up a spin? */
+static cl_bool clo_scan_blelloch_check_status(CloScan* scanner, CCLQueue* cq, GError** err) {
+	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scanner);
+	if (!data || !data->workspace.ptr) return CL_TRUE;
+	const int st = clo_hip_check_status(data->workspace.ptr, ccl_queue_get_stream(cq));
+	if (st == 0) return CL_TRUE;
+	if (st == CLO_HIP_ETIMEOUT) {
+		data->ws_ready = NULL;   /* prepare the workspace again before the next scan */
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY,
+			"blelloch scan: a work-group gave up waiting for its predecessors' prefix (bounded look-back spin); the output is not valid");
+		return CL_FALSE;
+	}
+	clo_hip_failed(st, err, "clo_hip_check_status");
+	return CL_FALSE;
 }
 
 /* ref: clo_scan_blelloch.c:219-249 — options must be empty. */
@@ -91,6 +130,7 @@ static const char* clo_scan_blelloch_init(CloScan* scanner, const char* options,
 	}
 	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) calloc(1, sizeof(*data));
 	if (!data) return NULL;
+	data->status = clo_status_cell_new(NULL);
 	clo_scan_set_data(scanner, data);
 	return "blelloch:hip";
 }
@@ -98,6 +138,8 @@ static const char* clo_scan_blelloch_init(CloScan* scanner, const char* options,
 static void clo_scan_blelloch_finalize(CloScan* scan) {
 	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scan);
 	if (data) {
+		clo_status_cell_set_word(data->status, NULL);   /* queues still watching must not read freed memory */
+		clo_status_cell_unref(data->status);
 		clo_devbuf_release(&data->workspace);
 		free(data);
 	}
@@ -138,6 +180,12 @@ const CloScanImplDef clo_scan_blelloch_def = {
 	clo_scan_blelloch_scan_with_device_data,
 	clo_scan_blelloch_get_num_kernels,
 	clo_scan_blelloch_get_kernel_name,
-	clo_scan_blelloch_get_localmem_usage,
-	clo_scan_blelloch_scan_chunk
+	clo_scan_blelloch_get_localmem_usage
+};
+
+/* not part of the public struct (clo_internal.h) */
+const clo_scan_impl_ext clo_scan_blelloch_ext = {
+	"blelloch",
+	clo_scan_blelloch_scan_chunk,
+	clo_scan_blelloch_check_status
 };

@@ -66,8 +66,21 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 	if (!ccl_queue_wait_for(cq_exec, &ewl, err)) { ccl_event_wait_list_clear(&ewl); return NULL; }
 	ccl_event_wait_list_clear(&ewl);
 
-	evt = ccl_queue_begin_command(cq_exec, evt_name, err);
-	if (!evt) return NULL;
+	/* a profiling queue gets one event per launch (upstream: clo_sort_sbitonic.c:115
+	 * "sbitonic_ndrange", clo_sort_abitonic.c:426 the step's kernel name) */
+	static const clo_kname knames[] = {
+		{ "bitonic_step", "sbitonic_ndrange" }, { "bitonic_presort", "abit_presort" }, { "bitonic_tile", "abit_merge" },
+		{ "bitonic_strided", "abit_strided" }, { "bitonic_strided2", "abit_strided2" }
+	};
+	const int per_kernel = ccl_queue_is_profiling(cq_exec) && numel > 1;
+	clo_kernel_events ke;
+	if (per_kernel) {
+		clo_kernel_events_install(&ke, cq_exec, knames, sizeof(knames) / sizeof(knames[0]), evt_name);
+	} else {
+		evt = ccl_queue_begin_command(cq_exec, evt_name, err);
+		if (!evt) return NULL;
+	}
+#define BITONIC_FAIL() do { if (per_kernel) clo_kernel_events_remove(&ke, NULL); else ccl_queue_abort_command(cq_exec, evt); return NULL; } while (0)
 
 	void* jit = clo_sort_get_jit(sorter);
 	if (numel > 1 && jit != NULL) {
@@ -75,11 +88,11 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		if (clo_hip_bitonic_padded_numel(numel) != numel) {
 			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
 				"bitonic sorts with a run-time compiled compare/get_key need a power-of-two numel");
-			return NULL;
+			BITONIC_FAIL();
 		}
 		int launches = 0;
 		int st = clo_hip_bitonic_jit_sort(jit, ccl_buffer_get_device_ptr(target), numel, tiled, &launches, stream);
-		if (clo_hip_failed(st, err, "clo_hip_bitonic_jit_sort")) return NULL;
+		if (clo_hip_failed(st, err, "clo_hip_bitonic_jit_sort")) BITONIC_FAIL();
 		clo_debug("%s (jit): numel=%zu launches=%d", evt_name, numel, launches);
 	} else if (numel > 1) {
 		const size_t padded = clo_hip_bitonic_padded_numel(numel);
@@ -91,13 +104,13 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 			if (ks->key_shift != 0 || ks->key_bits != 8 * ks->elem_size) {
 				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
 					"bitonic sorts of a non-power-of-two numel need the key to be the whole element");
-				return NULL;
+				BITONIC_FAIL();
 			}
 			if (state->last_stream && state->last_stream != stream)
-				if (clo_hip_failed(clo_hip_stream_synchronize(state->last_stream), err, "hipStreamSynchronize")) return NULL;
+				if (clo_hip_failed(clo_hip_stream_synchronize(state->last_stream), err, "hipStreamSynchronize")) BITONIC_FAIL();
 			state->last_stream = stream;
-			if (clo_hip_failed(clo_devbuf_reserve(&state->padded, padded * (size_t) ks->elem_size), err, "hipMalloc(bitonic pad)")) return NULL;
-			if (clo_hip_failed(clo_hip_memcpy_d2d_async(state->padded.ptr, work, bytes, stream), err, "hipMemcpyAsync")) return NULL;
+			if (clo_hip_failed(clo_devbuf_reserve(&state->padded, padded * (size_t) ks->elem_size), err, "hipMalloc(bitonic pad)")) BITONIC_FAIL();
+			if (clo_hip_failed(clo_hip_memcpy_d2d_async(state->padded.ptr, work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
 			work = state->padded.ptr;
 			use_pad = 1;
 		}
@@ -105,14 +118,23 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		 * launches of ~0.1 ms measured no gain) and only in place of the caller's buffer */
 		int launches = state->launches;
 		bitonic_call call = { ks, work, numel, tiled, &launches };
-		int st = clo_graph_cache_run(&state->graph, !tiled && !use_pad, work, NULL, numel, tiled, stream, bitonic_enqueue, &call);
-		if (clo_hip_failed(st, err, tiled ? "clo_hip_bitonic_tiled" : "clo_hip_bitonic_simple")) return NULL;
+		int st = clo_graph_cache_run(&state->graph, !tiled && !use_pad && !per_kernel, work, NULL, numel, tiled, stream, bitonic_enqueue, &call);
+		if (clo_hip_failed(st, err, tiled ? "clo_hip_bitonic_tiled" : "clo_hip_bitonic_simple")) BITONIC_FAIL();
 		state->launches = launches;
 		clo_debug("%s: numel=%zu padded=%zu launches=%d", evt_name, numel, padded, launches);
 		if (use_pad)
-			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) return NULL;
+			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
 	}
+#undef BITONIC_FAIL
 
-	if (!ccl_queue_end_command(cq_exec, evt, err)) return NULL;
+	if (per_kernel) {
+		GError* e2 = NULL;
+		CCLEvent* last = clo_kernel_events_remove(&ke, &e2);
+		if (e2) { clo_gerror_propagate(err, e2); return NULL; }
+		if (last) return last;
+		evt = ccl_queue_begin_command(cq_exec, evt_name, err);   /* (no launch was made) */
+		if (!evt) return NULL;
+	}
+	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	return evt;
 }

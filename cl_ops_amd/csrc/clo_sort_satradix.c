@@ -109,8 +109,24 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		if (jit && clo_hip_failed(clo_devbuf_reserve(&data->pairs, numel * 8), err, "hipMalloc(satradix key pairs)")) return NULL;
 	}
 
-	evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
-	if (!evt) return NULL;
+	/* A profiling queue gets one event per kernel under upstream's names
+	 * (clo_sort_satradix.c:282,295,312; the counter scan's launches under the
+	 * scanner's, clo_scan_blelloch.c:158); any other queue one event per sort. */
+	static const clo_kname knames[] = {
+		{ "radix_hist", CLO_SORT_SATRADIX_KNAME_HISTOGRAM }, { "radix_ghist", CLO_SORT_SATRADIX_KNAME_HISTOGRAM },
+		{ "radix_offsets", "clo_scan_blelloch_wgscan" },
+		{ "radix_pass", CLO_SORT_SATRADIX_KNAME_SCATTER }, { "radix_sweep", CLO_SORT_SATRADIX_KNAME_SCATTER },
+		{ "radix_small", CLO_SORT_SATRADIX_KNAME_LOCALSORT },
+		{ "radix_extract", "satradix_keys" }, { "radix_gather", "satradix_gather" }
+	};
+	const int per_kernel = ccl_queue_is_profiling(cq_exec) && numel > 0;
+	clo_kernel_events ke;
+	if (per_kernel) {
+		clo_kernel_events_install(&ke, cq_exec, knames, sizeof(knames) / sizeof(knames[0]), CLO_SORT_SATRADIX_KNAME_SCATTER);
+	} else {
+		evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
+		if (!evt) return NULL;
+	}
 
 	if (numel > 0) {
 		void* src = ccl_buffer_get_device_ptr(data_in);
@@ -122,10 +138,14 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		else
 			st = clo_hip_radix_sort(src, dst, data->tmp.ptr, numel, ks->elem_size, ks->key_shift,
 				ks->key_bits, key_kind, bits_in_digit, data->workspace.ptr, data->workspace.bytes, stream);
-		if (clo_hip_failed(st, err, "clo_hip_radix_sort")) return NULL;
+		if (clo_hip_failed(st, err, "clo_hip_radix_sort")) {
+			if (per_kernel) clo_kernel_events_remove(&ke, NULL); else ccl_queue_abort_command(cq_exec, evt);
+			return NULL;
+		}
 	}
 
-	if (!ccl_queue_end_command(cq_exec, evt, err)) return NULL;
+	if (per_kernel) return clo_kernel_events_remove(&ke, err);
+	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	return evt;
 }
 
@@ -195,6 +215,24 @@ static const char* clo_sort_satradix_init(CloSort* sorter, const char* options, 
 	}
 	if (data->scan_type == NULL) data->scan_type = strdup(CLO_SORT_SATRADIX_SCAN_DEFAULT);
 	data->scan_opts = c.scan_opts ? c.scan_opts : strdup("");
+	/* Upstream hands the per-digit counters to a CloScan of this type
+	 * (clo_sort_satradix.c:94,298) and so fails at the first sort when the type or
+	 * its options are not valid. Here the counter scan is fused into the radix
+	 * kernels (clo_hip_radixw.hip: a scan in digit-major order, upstream's
+	 * counters_sum); the scanner object serves the introspection calls only.
+	 * Type and options are therefore checked now, with the scan API's own
+	 * messages, instead of being accepted and never looked at. */
+	if (strcmp(data->scan_type, "blelloch") != 0) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_IMPL_NOT_FOUND,
+			"The requested scan implementation, '%s', was not found.", data->scan_type);
+		satradix_free(data);
+		return NULL;
+	}
+	if (data->scan_opts[0] != '\0') {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "Invalid options for blelloch scan.");
+		satradix_free(data);
+		return NULL;
+	}
 	clo_sort_set_data(sorter, data);
 	return "satradix:hip";
 }

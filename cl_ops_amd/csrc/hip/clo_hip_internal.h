@@ -8,8 +8,11 @@
 
 // ---- workspace header (first CLO_WS_HEADER_BYTES of every workspace) ----
 // word 0: status (non-zero = a bounded spin gave up)
-// words 16..79: work-queue tickets, one per pass
+// word 2: epoch of the last completed call (scan), word 3: work-groups that have left
+// words 16..79: work-queue tickets
 #define CLO_WS_STATUS_OFFSET 0
+#define CLO_WS_EPOCH_WORD    2
+#define CLO_WS_DONE_WORD     3
 #define CLO_WS_TICKET_WORD   16
 #define CLO_WS_MAX_PASSES    64
 #define CLO_WS_HEADER_BYTES  512
@@ -82,12 +85,13 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 typedef unsigned long long clo_u64;
 
 // Look-back granule: one naturally aligned 8-byte word written by ONE store:
-//   bits 63..34 epoch (pass + 1; 0 = never written this call)
+//   bits 63..34 epoch of the call that wrote it (1 .. CLO_LB_EPOCH_MAX; 0 = never written)
 //   bits 33..32 state (1 = tile aggregate, 2 = inclusive prefix)
 //   bits 31..0  value
 // The data is the flag (cdna_hip_programming.md G16 R2): relaxed agent-scope
 // (sc1) store on the producer, relaxed agent-scope load polls on the consumer,
 // no fences, no separate flag word.
+#define CLO_LB_EPOCH_MAX ((1u << 30) - 1u)
 #define CLO_LB_AGG    1u
 #define CLO_LB_PREFIX 2u
 

@@ -17,9 +17,12 @@ struct timing_rec { std::string label; hipEvent_t e0, e1; };
 std::mutex g_timing_mu;
 std::vector<timing_rec> g_timing;
 bool g_timing_on = false;
+thread_local clo_hip_launch_observer g_observer = nullptr;
+thread_local void* g_observer_user = nullptr;
 }  // namespace
 
 void clo_timing_begin(const char* label, hipStream_t s) {
+	if (g_observer) g_observer(g_observer_user, label, 0, (void*) s);
 	if (!g_timing_on) return;
 	std::lock_guard<std::mutex> lk(g_timing_mu);
 	timing_rec r;
@@ -30,12 +33,20 @@ void clo_timing_begin(const char* label, hipStream_t s) {
 }
 
 void clo_timing_end(hipStream_t s) {
-	if (!g_timing_on) return;
-	std::lock_guard<std::mutex> lk(g_timing_mu);
-	if (!g_timing.empty()) (void) hipEventRecord(g_timing.back().e1, s);
+	if (g_timing_on) {
+		std::lock_guard<std::mutex> lk(g_timing_mu);
+		if (!g_timing.empty()) (void) hipEventRecord(g_timing.back().e1, s);
+	}
+	if (g_observer) g_observer(g_observer_user, nullptr, 1, (void*) s);
 }
 
 extern "C" {
+
+int clo_hip_set_launch_observer(clo_hip_launch_observer fn, void* user) {
+	g_observer = fn;
+	g_observer_user = fn ? user : nullptr;
+	return 0;
+}
 
 int clo_hip_timing_enabled(void) { return g_timing_on ? 1 : 0; }
 
@@ -154,6 +165,12 @@ int clo_hip_stream_wait_event(void* stream, void* event) {
 
 int clo_hip_graph_capture_begin(void* stream) {
 	return (int) hipStreamBeginCapture((hipStream_t) stream, hipStreamCaptureModeThreadLocal);
+}
+
+int clo_hip_stream_is_capturing(void* stream) {
+	hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing((hipStream_t) stream, &st) != hipSuccess) { (void) hipGetLastError(); return 1; }   // unknown: do not capture
+	return st != hipStreamCaptureStatusNone ? 1 : 0;
 }
 
 int clo_hip_graph_capture_end(void* stream, void** graph_exec) {

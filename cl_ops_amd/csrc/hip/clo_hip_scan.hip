@@ -44,6 +44,16 @@ __device__ __forceinline__ void store4(T* p, const T (&v)[4]) {
 	*reinterpret_cast<vec4*>(p) = x;
 }
 
+// What the look-back needs to know about this call: granules carry the call's
+// epoch in their tag (clo_hip_internal.h), so nothing written by an earlier call
+// on the same workspace can be mistaken for this call's — the workspace is
+// never cleared between calls.
+struct scan_ctl {
+	unsigned epoch;       // 1 .. CLO_LB_EPOCH_MAX
+	unsigned max_spins;   // bound of every poll loop
+	unsigned* status;     // workspace status word
+};
+
 // One look-back window, run by wave 0 (all 64 lanes): lane l inspects entry
 // (idx - l) of `state` as long as it is >= lo. Waits until every inspected
 // entry nearer than the nearest inclusive prefix is published, then returns
@@ -67,18 +77,18 @@ __device__ __forceinline__ void scan_read_entry(const clo_u64* state, long j, un
 // two single-writer arrays).
 template <typename TSum, int NG>
 __device__ TSum scan_window(const clo_u64* state, const clo_u64* alt, long idx, long lo, bool floor_is_prefix,
-	unsigned lane, bool* closed, unsigned* status) {
+	unsigned lane, bool* closed, const scan_ctl& ctl) {
 	unsigned spins = 0;
 	while (true) {
 		const long j = idx - (long) lane;
-		unsigned tag = (1u << 2) | (floor_is_prefix ? CLO_LB_PREFIX : CLO_LB_AGG);  // below lo: value 0
+		unsigned tag = (ctl.epoch << 2) | (floor_is_prefix ? CLO_LB_PREFIX : CLO_LB_AGG);  // below lo: value 0
 		TSum val = 0;
 		if (j >= lo) {
 			scan_read_entry<TSum, NG>(state, j, tag, val);
-			if (alt != nullptr && !((tag >> 2) == 1u && (tag & 3u) != 0u)) scan_read_entry<TSum, NG>(alt, j, tag, val);
+			if (alt != nullptr && !((tag >> 2) == ctl.epoch && (tag & 3u) != 0u)) scan_read_entry<TSum, NG>(alt, j, tag, val);
 		}
 		const unsigned st = tag & 3u;
-		const bool valid = (tag >> 2) == 1u && st != 0u;
+		const bool valid = (tag >> 2) == ctl.epoch && st != 0u;
 		const clo_u64 pmask = __ballot(valid && st == CLO_LB_PREFIX);
 		const clo_u64 imask = __ballot(!valid);
 		if (pmask) {
@@ -92,8 +102,8 @@ __device__ TSum scan_window(const clo_u64* state, const clo_u64* alt, long idx, 
 			*closed = false;
 			return clo_wave_reduce_sum<TSum>(val);
 		}
-		if (++spins > CLO_MAX_SPINS) {
-			if (lane == 0) atomicExch(status, 1u);
+		if (++spins > ctl.max_spins) {
+			if (lane == 0) atomicExch(ctl.status, 1u);
 			*closed = true;
 			return 0;
 		}
@@ -113,7 +123,7 @@ __device__ TSum scan_window(const clo_u64* state, const clo_u64* alt, long idx, 
 constexpr int SCAN_SUPER_LOG = 6;
 
 template <typename TSum, int NG>
-__device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsigned st, TSum v);
+__device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsigned epoch, unsigned st, TSum v);
 
 // Super-tile state lives in two arrays with one writer each (two writers on a
 // two-granule entry could leave a mixed pair): `sagg` gets the super-tile's
@@ -121,28 +131,28 @@ __device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsi
 // `sprefix` gets its inclusive prefix from the super-tile's last tile.
 template <typename TSum, int NG>
 __device__ TSum scan_lookback2(clo_u64* tstate, clo_u64* sprefix, const clo_u64* sagg, unsigned tile, TSum aggregate,
-	unsigned lane, unsigned* status) {
+	unsigned lane, const scan_ctl& ctl) {
 	const unsigned q = tile & ((1u << SCAN_SUPER_LOG) - 1u);
 	const long sup = (long) (tile >> SCAN_SUPER_LOG);
 	bool closed = false;
 	TSum excl = 0;
 	if (q != 0)
-		excl = scan_window<TSum, NG>(tstate, nullptr, (long) tile - 1, sup << SCAN_SUPER_LOG, false, lane, &closed, status);
+		excl = scan_window<TSum, NG>(tstate, nullptr, (long) tile - 1, sup << SCAN_SUPER_LOG, false, lane, &closed, ctl);
 	long idx = sup - 1;
 	while (!closed) {
-		excl += scan_window<TSum, NG>(sprefix, sagg, idx, 0, true, lane, &closed, status);
+		excl += scan_window<TSum, NG>(sprefix, sagg, idx, 0, true, lane, &closed, ctl);
 		idx -= 64;
 	}
 	if (q == (1u << SCAN_SUPER_LOG) - 1u && lane == 0)
-		scan_publish<TSum, NG>(sprefix, (unsigned) sup, CLO_LB_PREFIX, (TSum) (excl + aggregate));
+		scan_publish<TSum, NG>(sprefix, (unsigned) sup, ctl.epoch, CLO_LB_PREFIX, (TSum) (excl + aggregate));
 	return excl;
 }
 
 template <typename TSum, int NG>
-__device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsigned st, TSum v) {
+__device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsigned epoch, unsigned st, TSum v) {
 	const clo_u64 x = (clo_u64) v;
-	clo_st_agent(&state[(size_t) tile * 2], clo_lb_pack(1u, st, (unsigned) x));
-	if (NG == 2) clo_st_agent(&state[(size_t) tile * 2 + 1], clo_lb_pack(1u, st, (unsigned) (x >> 32)));
+	clo_st_agent(&state[(size_t) tile * 2], clo_lb_pack(epoch, st, (unsigned) x));
+	if (NG == 2) clo_st_agent(&state[(size_t) tile * 2 + 1], clo_lb_pack(epoch, st, (unsigned) (x >> 32)));
 }
 
 // TIn/TOut: memory types; TSum: 32- or 64-bit accumulator (sums narrower than
@@ -152,7 +162,8 @@ template <typename TIn, typename TOut, typename TSum, int ROWS, int SCAN_THREADS
 __global__ __launch_bounds__(SCAN_THREADS)
 void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n,
 	unsigned* hdr, clo_u64* state, clo_u64* sstate, clo_u64* sagg, clo_u64* sacc, int aligned, unsigned xflags,
-	const clo_u64* __restrict__ carry_in, clo_u64* __restrict__ carry_out, unsigned last_tile) {
+	const clo_u64* __restrict__ carry_in, clo_u64* __restrict__ carry_out, unsigned last_tile,
+	unsigned max_spins, size_t ws_granules) {
 
 	constexpr int SCAN_WAVES = SCAN_THREADS / 64;
 	constexpr int ROW_ELEMS = SCAN_THREADS * SCAN_VEC;
@@ -166,6 +177,16 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
+	// This call's epoch: one more than the value the previous call on this
+	// workspace left in the header (its last work-group to leave wrote it, below;
+	// clo_hip_scan_workspace_init wrote 0). Every work-group of the launch reads it
+	// before that happens again: the header only changes when all have left.
+	scan_ctl ctl;
+	ctl.epoch = __hip_atomic_load(&hdr[CLO_WS_EPOCH_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+	ctl.max_spins = max_spins;
+	ctl.status = &hdr[0];
+	const unsigned tiles = last_tile + 1u;
+
 	// value carried into this call (a chunk of a longer array): added to every output
 	const TSum carry = carry_in ? (TSum) *carry_in : (TSum) 0;
 	// a work-group draws tiles until none is left (it holds one ticket at a time)
@@ -174,7 +195,29 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	__syncthreads();
 	const unsigned tile = s_tile;
 	const size_t base = (size_t) tile * TILE;
-	if (base >= n) return;
+	if (base >= n) {
+		// Leaving. The LAST work-group to leave (every group draws exactly one
+		// ticket past the end) hands the workspace to the next call: ticket and
+		// leave counters back to 0, the epoch advanced — so no call ever clears
+		// the workspace. Once in CLO_LB_EPOCH_MAX calls the epoch wraps: then this
+		// group zeroes every granule first (nobody else is left to read them).
+		__syncthreads();   // (s_tile is rewritten)
+		if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_DONE_WORD], 1u);
+		__syncthreads();
+		if (s_tile != gridDim.x - 1u) return;
+		const bool wrap = ctl.epoch >= CLO_LB_EPOCH_MAX;
+		if (wrap) {
+			clo_u64* g = reinterpret_cast<clo_u64*>(reinterpret_cast<char*>(hdr) + CLO_WS_HEADER_BYTES);
+			for (size_t i = tid; i < ws_granules; i += SCAN_THREADS) clo_st_agent(&g[i], 0ull);
+			__syncthreads();
+		}
+		if (tid == 0) {
+			__hip_atomic_store(&hdr[CLO_WS_TICKET_WORD], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&hdr[CLO_WS_DONE_WORD], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&hdr[CLO_WS_EPOCH_WORD], wrap ? 0u : ctl.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		return;
+	}
 	const bool full = (base + TILE <= n) && aligned;
 
 	// ---- load (elem -> sum type conversion on load, blelloch.cl:79-80) ----
@@ -242,14 +285,19 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		const bool first = tile == 0 || (xflags & 1u);
 		const unsigned sup = tile >> SCAN_SUPER_LOG;
 		if (lane == 0) {
-			scan_publish<TSum, NG>(state, tile, first ? CLO_LB_PREFIX : CLO_LB_AGG, aggregate);
-			// add the aggregate to the super-tile's accumulator; the 64th arrival publishes the total
+			scan_publish<TSum, NG>(state, tile, ctl.epoch, first ? CLO_LB_PREFIX : CLO_LB_AGG, aggregate);
+			// Add the aggregate to the super-tile's accumulator; the arrival that
+			// completes the super-tile publishes the total and puts the accumulator
+			// back to 0 for the next call (it is the last one to touch it). The final
+			// super-tile of the array may hold fewer than 64 tiles.
+			const unsigned in_super = tiles - (sup << SCAN_SUPER_LOG) < (1u << SCAN_SUPER_LOG)
+				? tiles - (sup << SCAN_SUPER_LOG) : (1u << SCAN_SUPER_LOG);
 			bool last;
 			TSum total;
 			if (NG == 1) {
 				const clo_u64 old = __hip_atomic_fetch_add(&sacc[(size_t) sup * 2],
 					((clo_u64) aggregate << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				last = (unsigned) old == (1u << SCAN_SUPER_LOG) - 1u;
+				last = (unsigned) old == in_super - 1u;
 				total = (TSum) ((unsigned) (old >> 32)) + aggregate;
 			} else {
 				// RETURNING add: its result coming back means the add has been performed at
@@ -258,16 +306,20 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 					__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				asm volatile("s_waitcnt vmcnt(0)" :: "v"((unsigned) before) : "memory");
 				const clo_u64 cnt = __hip_atomic_fetch_add(&sacc[(size_t) sup * 2 + 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				last = cnt == (1ull << SCAN_SUPER_LOG) - 1ull;
+				last = cnt == (clo_u64) in_super - 1ull;
 				total = last ? (TSum) clo_ld_agent(&sacc[(size_t) sup * 2]) : (TSum) 0;
 			}
-			if (last) scan_publish<TSum, NG>(sagg, sup, CLO_LB_AGG, total);
+			if (last) {
+				scan_publish<TSum, NG>(sagg, sup, ctl.epoch, CLO_LB_AGG, total);
+				clo_st_agent(&sacc[(size_t) sup * 2], 0ull);
+				if (NG == 2) clo_st_agent(&sacc[(size_t) sup * 2 + 1], 0ull);
+			}
 		}
 		if (!first) {
-			excl = scan_lookback2<TSum, NG>(state, sstate, sagg, tile, aggregate, lane, &hdr[0]);
-			if (lane == 0) scan_publish<TSum, NG>(state, tile, CLO_LB_PREFIX, (TSum) (excl + aggregate));
+			excl = scan_lookback2<TSum, NG>(state, sstate, sagg, tile, aggregate, lane, ctl);
+			if (lane == 0) scan_publish<TSum, NG>(state, tile, ctl.epoch, CLO_LB_PREFIX, (TSum) (excl + aggregate));
 		} else if (tile == 0 && lane == 0 && (1u << SCAN_SUPER_LOG) == 1u) {
-			scan_publish<TSum, NG>(sstate, 0, CLO_LB_PREFIX, aggregate);
+			scan_publish<TSum, NG>(sstate, 0, ctl.epoch, CLO_LB_PREFIX, aggregate);
 		}
 		if (lane == 0) {
 			s_excl = excl;
@@ -303,6 +355,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 }
 
 unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never set in production
+unsigned g_scan_max_spins = CLO_MAX_SPINS;   // CLO_MAX_SPINS in the environment overrides (tests force a give-up with it)
 
 // Work-group shape by array size. Every work-group draws a ticket from one
 // counter (HIP promises no dispatch order, so tile ids cannot come from
@@ -326,7 +379,7 @@ constexpr size_t scan_tile_elems(size_t numel, int sum_size) {
 }
 
 template <typename TIn, typename TOut>
-int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, clo_u64* carry_out, void* ws, hipStream_t s) {
+int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, clo_u64* carry_out, void* ws, size_t ws_bytes, hipStream_t s) {
 	if constexpr (sizeof(TIn) > sizeof(TOut)) {
 		return CLO_HIP_EUNSUPPORTED;
 	} else {
@@ -341,30 +394,33 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		clo_u64* sagg = sstate + supers * 2;
 		clo_u64* sacc = sagg + supers * 2;
 		const int aligned = ((uintptr_t) in % (4 * sizeof(TIn)) == 0) && ((uintptr_t) out % (4 * sizeof(TOut)) == 0);
-		hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES + tiles * 16 + supers * 48, s);
-		if (e != hipSuccess) return (int) e;
+		// No clearing of the workspace: granules carry the call's epoch, accumulators
+		// and counters are put back by the kernel itself (clo_hip_scan_workspace_init
+		// zeroed everything once).
+		const size_t ws_granules = (ws_bytes - CLO_WS_HEADER_BYTES) / sizeof(clo_u64);
+		const unsigned max_spins = g_scan_max_spins;
 		clo_timing_scope timing("scan", s);
 		// as many work-groups as fit the chip at once; each draws tiles until none is left
 		const unsigned groups_big = (unsigned) (tiles < 256 ? tiles : 256), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
 		if (scan_threads(n) == 1024)
 			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3(groups_big), dim3(1024), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
-				carry_in, carry_out, (unsigned) (tiles - 1));
+				carry_in, carry_out, (unsigned) (tiles - 1), max_spins, ws_granules);
 		else
 			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, ROWS, 256>), dim3(groups_small), dim3(256), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
-				carry_in, carry_out, (unsigned) (tiles - 1));
+				carry_in, carry_out, (unsigned) (tiles - 1), max_spins, ws_granules);
 		return (int) hipGetLastError();
 	}
 }
 
 template <typename TOut>
-int dispatch_in(const void* in, void* out, size_t n, int es, int sgn, const clo_u64* ci, clo_u64* co, void* ws, hipStream_t s) {
+int dispatch_in(const void* in, void* out, size_t n, int es, int sgn, const clo_u64* ci, clo_u64* co, void* ws, size_t wsb, hipStream_t s) {
 	switch (es) {
-		case 1: return sgn ? launch_scan<int8_t, TOut>(in, out, n, ci, co, ws, s) : launch_scan<uint8_t, TOut>(in, out, n, ci, co, ws, s);
-		case 2: return sgn ? launch_scan<int16_t, TOut>(in, out, n, ci, co, ws, s) : launch_scan<uint16_t, TOut>(in, out, n, ci, co, ws, s);
-		case 4: return sgn ? launch_scan<int32_t, TOut>(in, out, n, ci, co, ws, s) : launch_scan<uint32_t, TOut>(in, out, n, ci, co, ws, s);
-		case 8: return launch_scan<uint64_t, TOut>(in, out, n, ci, co, ws, s);
+		case 1: return sgn ? launch_scan<int8_t, TOut>(in, out, n, ci, co, ws, wsb, s) : launch_scan<uint8_t, TOut>(in, out, n, ci, co, ws, wsb, s);
+		case 2: return sgn ? launch_scan<int16_t, TOut>(in, out, n, ci, co, ws, wsb, s) : launch_scan<uint16_t, TOut>(in, out, n, ci, co, ws, wsb, s);
+		case 4: return sgn ? launch_scan<int32_t, TOut>(in, out, n, ci, co, ws, wsb, s) : launch_scan<uint32_t, TOut>(in, out, n, ci, co, ws, wsb, s);
+		case 8: return launch_scan<uint64_t, TOut>(in, out, n, ci, co, ws, wsb, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }
@@ -433,6 +489,17 @@ size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
 	return CLO_WS_HEADER_BYTES + t * 16 + ((t >> SCAN_SUPER_LOG) + 1) * 48;
 }
 
+int clo_hip_scan_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+	if (!workspace || workspace_bytes < CLO_WS_HEADER_BYTES) return CLO_HIP_EARGS;
+	return (int) hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t) stream);
+}
+
+int clo_hip_scan_workspace_set_epoch(void* workspace, unsigned epoch, void* stream) {
+	if (!workspace) return CLO_HIP_EARGS;
+	return (int) hipMemsetD32Async((hipDeviceptr_t) ((char*) workspace + CLO_WS_EPOCH_WORD * sizeof(unsigned)), (int) epoch, 1,
+		(hipStream_t) stream);
+}
+
 int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t numel,
 	int elem_size, int elem_signed, int sum_size,
 	const uint64_t* carry_in_dev, uint64_t* carry_out_dev,
@@ -449,6 +516,8 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
 	{
 		const char* x = getenv("CLO_SCAN_XFLAGS");
 		g_scan_xflags = x ? (unsigned) atoi(x) : 0u;
+		const char* m = getenv("CLO_MAX_SPINS");
+		g_scan_max_spins = m ? (unsigned) strtoul(m, nullptr, 10) : CLO_MAX_SPINS;
 	}
 	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
 	if (numel / scan_tile_elems(numel, sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
@@ -457,10 +526,10 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
 	// The sum type only matters by width: two's complement addition is the
 	// same for signed and unsigned sums.
 	switch (sum_size) {
-		case 1: return dispatch_in<uint8_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
-		case 2: return dispatch_in<uint16_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
-		case 4: return dispatch_in<uint32_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
-		case 8: return dispatch_in<uint64_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, s);
+		case 1: return dispatch_in<uint8_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, workspace_bytes, s);
+		case 2: return dispatch_in<uint16_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, workspace_bytes, s);
+		case 4: return dispatch_in<uint32_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, workspace_bytes, s);
+		case 8: return dispatch_in<uint64_t>(data_in, data_out, numel, elem_size, elem_signed, ci, co, workspace, workspace_bytes, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }

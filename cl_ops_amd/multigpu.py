@@ -42,15 +42,29 @@ class HipLocalOps:
         from cl_ops_amd import _hip
         self.torch, self.clo, self._hip = torch, clo, _hip
         self.lib = _hip.lib
-        self.elem_type = elem_type                      # "uint" or "ulong"
+        if elem_type not in ("uint", "ulong"):
+            raise ValueError("the sharded sort handles unsigned 4- and 8-byte keys ('uint', 'ulong'), not %r" % (elem_type,))
+        self.elem_type = elem_type
         self.elem_size = 4 if elem_type == "uint" else 8
         self.key_bits = key_bits or 8 * self.elem_size
         self.ctx = clo.Context(device_index)
-        # run on torch's current stream so that ordering with RCCL is the stream's
-        self.stream = torch.cuda.current_stream().cuda_stream
-        self.queue = clo.Queue(self.ctx, stream=self.stream)
         self.sorter = clo.Sorter("satradix", self.ctx, elem_type)
+        self._queues = {}
         self._ws = None
+
+    # Everything runs on torch's CURRENT stream at the time of the call, so that
+    # ordering with RCCL and with the caller's own work is the stream's.
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    @property
+    def queue(self):
+        s = self.stream
+        q = self._queues.get(s)
+        if q is None:
+            q = self._queues[s] = self.clo.Queue(self.ctx, stream=s)
+        return q
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
@@ -84,7 +98,9 @@ class HipLocalOps:
 
     def close(self):
         self.sorter.close()
-        self.queue.close()
+        for q in self._queues.values():
+            q.close()
+        self._queues = {}
         self.ctx.close()
 
 
@@ -103,6 +119,39 @@ class ShardedSorter:
         self.capacity_factor = capacity_factor
         self._send = None
         self._recv = None
+        # Set to {} to have the following sorts time their phases (device events on
+        # the current stream for CUDA tensors, the host clock for CPU tensors);
+        # collect_phase_times() then returns the seconds spent per phase so far.
+        self.phase_times = None
+        self._marks = []
+
+    PHASES = ("partition", "count_exchange", "key_exchange", "local_sort")
+
+    def _mark(self, like):
+        if self.phase_times is None:
+            return
+        if like.is_cuda:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._marks.append(e)
+        else:
+            import time
+            self._marks.append(time.perf_counter())
+
+    def collect_phase_times(self):
+        """Seconds per phase summed over the sorts made since phase_times was set
+        (call after synchronising the device)."""
+        out = dict(self.phase_times or {})
+        k = len(self.PHASES) + 1
+        for i in range(0, len(self._marks) - k + 1, k):
+            m = self._marks[i:i + k]
+            for j, name in enumerate(self.PHASES):
+                dt = m[j].elapsed_time(m[j + 1]) * 1e-3 if hasattr(m[j], "elapsed_time") else m[j + 1] - m[j]
+                out[name] = out.get(name, 0.0) + dt
+        self._marks = []
+        if self.phase_times is not None:
+            self.phase_times = out
+        return out
 
     def _buffers(self, like, n):
         cap = int(n * self.capacity_factor) + 1024
@@ -152,18 +201,25 @@ class ShardedSorter:
 
         send, recv = self._buffers(local, n)
         b = self.bucket_bits
+        self._mark(local)
         counts = self.ops.msd_partition(local, send, n, b)                # step 1
+        self._mark(local)
         gathered = [torch.empty_like(counts) for _ in range(self.world)]
         dist.all_gather(gathered, counts, group=self.group)               # step 2
+        # the host needs the sizes to slice the send / receive buffers: the one
+        # device -> host round trip of a sort (G*G counters)
         matrix = torch.stack(gathered).cpu().numpy()
         sc, so, rc, ro = self.plan(matrix, self.rank)
         total = int(rc.sum())
-        if total > recv.numel():
+        if total > recv.numel():   # more skew than capacity_factor allows for: count-exact allocation
             self._recv = recv = torch.empty(total, dtype=local.dtype, device=local.device)
+        self._mark(local)
 
         self.exchange(send, recv, sc, so, rc, ro)                         # step 3
+        self._mark(local)
         if total > 0:
             self.ops.sort_inplace(recv, total)                            # step 4
+        self._mark(local)
         return recv, total
 
 
@@ -192,8 +248,11 @@ class HipScanOps:
         self.elem_size, self.elem_signed = _SCAN_NP[elem_type]
         self.sum_size = _SCAN_NP[sum_type][0]
         _hip.check(self.lib.clo_hip_set_device(device_index), "hipSetDevice")
-        self.stream = torch.cuda.current_stream().cuda_stream
         self._ws = None
+
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
 
     def reduce(self, t, n):
         """Sum of t[:n] mod 2^64 as a 1-element int64 tensor on the device."""
@@ -206,11 +265,19 @@ class HipScanOps:
         """dst[:n] = carry + exclusive scan of src[:n]; carry: 1-element int64 device tensor or None."""
         need = self.lib.clo_hip_scan_workspace_bytes(n, self.elem_size, self.sum_size)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=src.device)
+            self._ws = self.torch.zeros(need, dtype=self.torch.uint8, device=src.device)   # (= clo_hip_scan_workspace_init)
         self._hip.check(self.lib.clo_hip_scan_exclusive_carry(
             src.data_ptr(), dst.data_ptr(), n, self.elem_size, self.elem_signed, self.sum_size,
             carry.data_ptr() if carry is not None else None, None,
             self._ws.data_ptr(), self._ws.numel(), self.stream), "clo_hip_scan_exclusive_carry")
+
+    def check(self):
+        """Synchronises the stream and raises HipError(CLO_HIP_ETIMEOUT) if a scan gave up a spin."""
+        if self._ws is not None:
+            st = self.lib.clo_hip_check_status(self._ws.data_ptr(), self.stream)
+            if st != 0:
+                self._ws.zero_()
+            self._hip.check(st, "sharded scan")
 
 
 class ShardedScanner:
@@ -247,3 +314,9 @@ class ShardedScanner:
         carry = torch.tensor([self.carry_of(totals, self.rank)], dtype=torch.int64, device=local.device)
         self.ops.scan(local, out, n, carry)                                 # step 3
         return out
+
+    def check(self):
+        """After the caller has synchronised: raises if a scan kernel gave up a
+        look-back spin (the output would be wrong)."""
+        if hasattr(self.ops, "check"):
+            self.ops.check()

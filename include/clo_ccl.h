@@ -75,7 +75,10 @@ void ccl_queue_destroy(CCLQueue* cq);
 CCLDevice* ccl_queue_get_device(CCLQueue* cq, GError** err);
 CCLContext* ccl_queue_get_context(CCLQueue* cq, GError** err);
 cl_bool ccl_queue_finish(CCLQueue* cq, GError** err);
-/* Release the events the queue has handed out (cf4ocl2: ccl_queue_gc). */
+/* Release the events the queue has handed out (cf4ocl2: ccl_queue_gc). A queue
+ * created without CL_QUEUE_PROFILING_ENABLE also drops events by itself once
+ * more than 128 have piled up, keeping the 64 most recent: an event pointer is
+ * good for the next 64 commands on its queue. */
 void ccl_queue_gc(CCLQueue* cq);
 /* Not in cf4ocl2: the underlying hipStream_t. */
 void* ccl_queue_get_stream(CCLQueue* cq);
@@ -117,11 +120,38 @@ cl_bool ccl_prof_calc(CCLProf* prof, GError** err);
 /* Device time from the start of the first to the end of the last command of
  * the added queues, in nanoseconds (benchmarks/clo_sort_bench.c:201-208). */
 cl_ulong ccl_prof_get_duration(CCLProf* prof);
+/* Aggregate of the events carrying one name (cf4ocl2: CCLProfAgg): total device
+ * time of the kernels upstream enqueues under that name, e.g. "satradix_scatter"
+ * (sort/clo_sort_satradix.c:312) or "clo_scan_blelloch_wgscan"
+ * (scan/clo_scan_blelloch.c:158). Valid until the next ccl_prof_calc. */
+typedef struct ccl_prof_agg {
+	const char* event_name;
+	cl_ulong absolute_time;   /* ns */
+	double relative_time;     /* share of ccl_prof_get_duration */
+} CCLProfAgg;
+const CCLProfAgg* ccl_prof_get_agg(CCLProf* prof, const char* event_name);
+void ccl_prof_iter_agg_init(CCLProf* prof, int sort);
+const CCLProfAgg* ccl_prof_iter_agg_next(CCLProf* prof);
 
 /* Internal to the library's own drivers (clo_sort_*.c / clo_scan_*.c): open and
- * close an event around a group of launches on the queue's stream. */
+ * close an event around a group of launches on the queue's stream. An event
+ * whose command could not be enqueued is taken back with ccl_queue_abort_command
+ * (it would otherwise sit in the queue with an `end` that was never recorded). */
 CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err);
 cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err);
+void ccl_queue_abort_command(CCLQueue* cq, CCLEvent* evt);
+int ccl_queue_is_profiling(CCLQueue* cq);
+/* A kernel that waits for other work-groups bounds its spins and raises a
+ * status word in device memory when it gives up (clo_hip.h: clo_hip_check_status).
+ * The owner of that word wraps it in a cell and has every queue it enqueues on
+ * watch the cell; ccl_queue_finish, ccl_event_wait and ccl_prof_calc then read
+ * the word after synchronising and fail with CLO_ERROR_LIBRARY if it is raised. */
+typedef struct clo_status_cell clo_status_cell;
+clo_status_cell* clo_status_cell_new(void* dev_word);
+void clo_status_cell_set_word(clo_status_cell* cell, void* dev_word);   /* NULL: the memory is gone */
+int clo_status_cell_take_tripped(clo_status_cell* cell);               /* 1 once after a check found the word raised */
+void clo_status_cell_unref(clo_status_cell* cell);
+void ccl_queue_watch_status(CCLQueue* cq, clo_status_cell* cell);
 /* Make the queue's stream wait for every event of the list (does not clear). */
 cl_bool ccl_queue_wait_for(CCLQueue* cq, CCLEventWaitList* ewl, GError** err);
 

@@ -75,6 +75,7 @@ int clo_hip_stream_wait_event(void* stream, void* event);
  * makes one launch per (stage, step): 136 for 2^16 elements) is recorded once
  * and replayed with one call. begin/end bracket the launches on `stream`;
  * end instantiates the graph. */
+int clo_hip_stream_is_capturing(void* stream);   /* 1: a capture is active (or the state is unknown), 0: none */
 int clo_hip_graph_capture_begin(void* stream);
 int clo_hip_graph_capture_end(void* stream, void** graph_exec);
 int clo_hip_graph_launch(void* graph_exec, void* stream);
@@ -88,9 +89,19 @@ const char* clo_hip_error_string(int status);
  * data_out[i] = sum_{j<i} (sum_t) data_in[j], wrap-around in the sum type.
  * elem_size, sum_size in {1,2,4,8} bytes with sum_size >= elem_size (unsigned
  * widening; signed inputs: pass elem_signed=1 for sign extension).
- * workspace: clo_hip_scan_workspace_bytes() bytes of device memory, contents
- * don't-care; the call zeroes what it polls. Asynchronous on `stream`. */
+ * workspace: clo_hip_scan_workspace_bytes() bytes of device memory that
+ * clo_hip_scan_workspace_init() has zeroed ONCE (after allocating it, and again
+ * after a call that ended in CLO_HIP_ETIMEOUT); from then on the scans keep it
+ * consistent themselves — look-back entries carry the epoch of the call that
+ * wrote them, counters are put back by the last work-group to leave — so a
+ * call clears nothing. One scan at a time per workspace. Asynchronous on
+ * `stream`. */
 size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size);
+int clo_hip_scan_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* Test hook: sets the epoch the next scan on this workspace continues from
+ * (epochs run 1 .. 2^30-1, then the workspace is zeroed in-kernel and they start
+ * over); lets a test cross the wrap without 2^30 calls. */
+int clo_hip_scan_workspace_set_epoch(void* workspace, unsigned epoch, void* stream);
 int clo_hip_scan_exclusive(const void* data_in, void* data_out, size_t numel,
 	int elem_size, int elem_signed, int sum_size,
 	void* workspace, size_t workspace_bytes, void* stream);
@@ -195,12 +206,29 @@ int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs
 
 /* ---- status word of the bounded spins ----
  * The scan is the one kernel that polls other work-groups' state (decoupled
- * look-back); it bounds every spin and on give-up sets a word in its workspace
- * and finishes. This reads the word back (synchronises `stream`). Returns 0,
- * CLO_HIP_ETIMEOUT or a hip error. Meaningful for the workspaces of the scan
+ * look-back); it bounds every spin (CLO_MAX_SPINS polls; the environment
+ * variable of that name overrides the bound) and on give-up sets a word in its
+ * workspace and finishes with wrong output. This reads the word back
+ * (synchronises `stream`). Returns 0, CLO_HIP_ETIMEOUT or a hip error; after
+ * CLO_HIP_ETIMEOUT the workspace must be initialised again. The host drivers
+ * check it wherever they synchronise anyway (clo_scan_with_host_data,
+ * ccl_queue_finish, ccl_event_wait). Meaningful for the workspaces of the scan
  * and of clo_hip_msd_partition (always 0 there: no kernel of the sorts waits on
  * another work-group); clo_hip_radix_sort leaves the word untouched. */
 int clo_hip_check_status(void* workspace, void* stream);
+
+/* ---- launch observer: per-kernel events for profiling queues ----
+ * Upstream names every kernel launch it enqueues (ccl_event_set_name at
+ * sort/clo_sort_satradix.c:282,295,312, scan/clo_scan_blelloch.c:158,183,193) and
+ * CCLProf reports per name. The C-ABI calls below launch several kernels each;
+ * while an observer is installed (per calling thread), it is told about every
+ * launch: phase 0 right before (label = the kernel family: "radix_hist",
+ * "radix_offsets", "radix_pass", "radix_small", "scan", "bitonic_step", ...),
+ * phase 1 right after (label NULL), with the stream the launch went to. The
+ * host drivers use it to record one CCLEvent per kernel when the queue was
+ * created with CL_QUEUE_PROFILING_ENABLE. NULL removes it. */
+typedef void (*clo_hip_launch_observer)(void* user, const char* label, int phase, void* stream);
+int clo_hip_set_launch_observer(clo_hip_launch_observer fn, void* user);
 
 /* ---- per-kernel device timing (measurement only; bench.py's roofline leg) ----
  * While enabled, every kernel launch made by this library is bracketed by a

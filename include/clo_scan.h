@@ -27,14 +27,6 @@ typedef struct clo_scan_impl_def {
 	cl_uint (*get_num_kernels)(CloScan* scanner, GError** err);
 	const char* (*get_kernel_name)(CloScan* scanner, cl_uint i, GError** err);
 	size_t (*get_localmem_usage)(CloScan* scanner, cl_uint i, size_t lws_max, size_t numel, GError** err);
-	/* Not in upstream's struct; may be NULL. Scans `numel` elements at raw device
-	 * pointers as one chunk of a longer array: *carry_in_dev (device uint64, NULL
-	 * = 0) is added to every output, *carry_out_dev receives the next chunk's
-	 * carry. Enqueued on cq_exec as one command (so that a profiling queue sees
-	 * it like any scan). Returns CL_FALSE and sets err on failure. Used by the
-	 * pipelined clo_scan_with_host_data. */
-	cl_bool (*scan_chunk)(CloScan* scanner, CCLQueue* cq_exec, const void* in_dev, void* out_dev, size_t numel,
-		const void* carry_in_dev, void* carry_out_dev, GError** err);
 } CloScanImplDef;
 
 /* clo_scan_abstract.in.h:109-162 — note elem_type/sum_type BY VALUE. */

@@ -158,16 +158,35 @@ def test_satradix_option_errors(off, opts, msg):
 def test_satradix_options_accepted(off):
     for opts in (None, "", "radix=2", "radix=256", "radix=16,scan=blelloch", ",radix=4,"):
         clo.Sorter("satradix", off, "uint", options=opts).close()
-    s = clo.Sorter("satradix", off, "uint", options="scan=nosuchscan")
-    with pytest.raises(clo.CloError) as e:   # the scanner is created lazily, like upstream
-        s.num_kernels()
-    assert e.value.code == CLO_ERROR_IMPL_NOT_FOUND
-    s.close()
-    s = clo.Sorter("satradix", off, "uint", options="scanfoo=1")  # forwarded to blelloch, which takes no options
+    # Upstream hands the counters to a CloScan of this type at the first sort
+    # (clo_sort_satradix.c:94,298) and fails there; here the counter scan is part of
+    # the radix kernels, so type and options are checked at clo_sort_new, with the
+    # scan API's own error codes and messages, instead of being silently unused.
     with pytest.raises(clo.CloError) as e:
-        s.num_kernels()
-    assert "Invalid options for blelloch scan." in e.value.message
-    s.close()
+        clo.Sorter("satradix", off, "uint", options="scan=nosuchscan")
+    assert e.value.code == CLO_ERROR_IMPL_NOT_FOUND and "'nosuchscan'" in e.value.message
+    with pytest.raises(clo.CloError) as e:
+        clo.Sorter("satradix", off, "uint", options="scanfoo=1")  # forwarded to blelloch, which takes no options
+    assert e.value.code == CLO_ERROR_ARGS and "Invalid options for blelloch scan." in e.value.message
+
+
+def test_scan_impl_def_has_upstreams_layout():
+    """CloScanImplDef is upstream's struct (clo_scan_abstract.in.h:41-103): a name and
+    six function pointers, nothing appended — a plugin compiled against upstream's
+    header must not be read past its end. The chunk / status extensions live in a
+    private side table (clo_internal.h), which the public headers do not mention."""
+    import re
+    text = open(os.path.join(ROOT, "include", "clo_scan.h")).read()
+    body = text[text.index("typedef struct clo_scan_impl_def {"):text.index("} CloScanImplDef;")]
+    members = re.findall(r"\(\*(\w+)\)\s*\(", body)
+    assert members == ["init", "finalize", "scan_with_device_data", "get_num_kernels", "get_kernel_name",
+                       "get_localmem_usage"]
+    assert "scan_chunk" not in text
+    # the exported vtable is 7 pointers long: the word after it is not a pointer into the library's text
+    base = C.addressof(C.c_void_p.in_dll(lib, "clo_scan_blelloch_def"))
+    words = (C.c_void_p * 7).from_address(base)
+    assert all(words[i] for i in range(7))
+    assert C.string_at(words[0]) == b"blelloch"
 
 
 @pytest.mark.parametrize("opts,msg", [

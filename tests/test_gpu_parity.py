@@ -67,6 +67,7 @@ def test_scan_in_chunks_with_device_carry_and_reduce(gpu, types):
     cuts = [0, 1, 5000, 5000, 70001, 262144, n]     # includes an empty chunk
     wsb = lib.clo_hip_scan_workspace_bytes(n, edt.itemsize, sdt.itemsize)
     ws = clo.Buffer(ctx, wsb)
+    _hip.check(lib.clo_hip_scan_workspace_init(ws.ptr, wsb, q.stream), "clo_hip_scan_workspace_init")   # once per allocation
     for k in range(len(cuts) - 1):
         lo, hi = cuts[k], cuts[k + 1]
         _hip.check(lib.clo_hip_scan_exclusive_carry(src.ptr + lo * edt.itemsize, dst.ptr + lo * sdt.itemsize, hi - lo,

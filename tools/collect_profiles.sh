@@ -2,9 +2,9 @@
 # Runs ON THE GPU BOX (through gpurun): bench lines, rocprofv3 kernel stats and the two
 # PMC passes for the HBM traffic of the headline workload. Raw output goes to
 # gpurun_out/$TAG/; tools/summarize_profiles.py turns it into the files under profiles/.
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r02'
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"

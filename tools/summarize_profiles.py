@@ -40,6 +40,30 @@ def short(k):
     return k.split("(")[0].strip()
 
 
+# kernel name (as rocprofv3 prints it) -> the family label bench.py times it under
+FAMILY_OF = (("pair_kernel", "radix_pass"), ("tilehist", "radix_hist"), ("chunksum", "radix_offsets"),
+             ("chunkscan", "radix_offsets"), ("offsets", "radix_offsets"), ("ghist", "radix_ghist"), ("sweep", "radix_sweep"),
+             ("clo_scan_kernel", "scan"), ("tile_merge", "bitonic_tile"), ("presort", "bitonic_presort"),
+             ("strided2", "bitonic_strided2"), ("strided", "bitonic_strided"), ("step_kernel", "bitonic_step"))
+
+
+def families(rows, launches_of):
+    """HBM bytes per launch of each kernel family: the kernels of a family that run once per
+    family launch (the three counter-scan kernels) add up; `launches_of` = launches of the
+    family's leading kernel in the profiled run."""
+    acc = {}
+    for name, n, f, w, b in rows:
+        fam = next((lab for needle, lab in FAMILY_OF if needle in name), None)
+        if fam is None:
+            continue
+        d = acc.setdefault(fam, {"kernels": [], "bytes_total": 0, "launches": 0})
+        d["kernels"].append(name)
+        d["bytes_total"] += b * n
+        d["launches"] = max(d["launches"], n)
+    return {fam: {"kernels": d["kernels"], "hbm_bytes_per_launch": int(d["bytes_total"] / d["launches"])}
+            for fam, d in acc.items() if d["launches"]}
+
+
 def traffic_rows(workload):
     fetch, write = pmc("FETCH_SIZE", workload), pmc("WRITE_SIZE", workload)
     rows = []
@@ -71,6 +95,7 @@ with open(path, "w") as o:
         o.write("%s,%d,%.0f,%.0f,%d\n" % r)
 if pas:
     json.dump({"kernel": pas[0][0], "hbm_bytes_per_launch": pas[0][4], "fetch_size_kb": pas[0][2], "write_size_kb": pas[0][3],
+               "log2n": 28, "families": families(rows, None),
                "correction": "FETCH_SIZE x2 (gfx950; calibrated on the histogram kernel in the same run: factor %.3f), WRITE_SIZE as is" % calib,
                "source": "profiles/" + os.path.basename(path)},
               open(os.path.join(dst, "traffic_satradix_u32.json"), "w"), indent=1)
@@ -93,6 +118,7 @@ for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_merge_k
     if dom:
         d = max(dom, key=lambda r: r[1])   # the merge launches outnumber the presort
         json.dump({"kernel": d[0], "hbm_bytes_per_launch": d[4], "fetch_size_kb": d[2], "write_size_kb": d[3],
+                   "log2n": 26, "families": families(rows, None),
                    "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as is", "source": "profiles/" + os.path.basename(path)},
                   open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
     for r in rows[:4]:
