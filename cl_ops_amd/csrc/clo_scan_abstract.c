@@ -154,22 +154,26 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
  * out are issued by a helper thread; pinning the caller's memory instead
  * costs ~10 ms per GiB, more than the overlap gains.                     */
 /* ------------------------------------------------------------------ */
-#define CLO_SCAN_PIPE_CHUNK ((size_t) 1 << 22)   /* smallest chunk, elements */
+#define CLO_SCAN_PIPE_MIN_NUMEL ((size_t) 1 << 24)   /* below this one copy in, one scan, one copy out */
 #define CLO_SCAN_PIPE_CHUNK_MAX ((size_t) 1 << 24)
-#define CLO_SCAN_PIPE_MIN_CHUNKS 4               /* below this the fill/drain of the pipeline eats the gain */
 
-/* Eight chunks or more per array, 2^22 .. 2^24 elements each. Measured wall
- * times, uint -> uint, host to host: 2^26 elements 6.2 ms with chunks of 2^22 or
- * 2^23 (6.7 with 2^24), 2^28 elements 23.2-23.8 ms with 2^22 .. 2^24 (24.5 with
- * 2^25) — flat, so the larger chunk wins: its scans run the large kernel shape
- * (the reference harness prints the sum of the chunk scans: 174 GValues/s with
- * chunks of 2^22 elements, 395 with 2^24). */
+/* Chunks of the pipeline: 2 up to 2^25 elements, 4 up to 2^27, then chunks of
+ * 2^24. Every chunk scan starts on an idle stream (it waits for its copy), which
+ * costs ~20 us of launch latency inside its event pair whatever its size, and the
+ * reference harness prints the SUM of those event times (benchmarks/
+ * clo_scan_bench.c:240-278): with the 2^22-element chunks of round 1 the printed
+ * rate fell from 195 GValues/s at 2^23 elements to 172 at 2^24 and 2^25
+ * (profiles/r01_harness_sweep_scan.txt). Few, large chunks keep that figure
+ * monotone, and the wall time (measured, uint -> uint, host to host: 2^26 elements
+ * 6.2 ms with chunks of 2^22 or 2^23, 6.7 with 2^24; 2^28: 23.2-23.8 ms with 2^22
+ * .. 2^24) is flat in the chunk size. */
 static size_t scan_pipe_chunk(size_t numel) {
 	const char* x = getenv("CLO_SCAN_PIPE_CHUNK_LOG2");   /* (A/B measurements only) */
 	if (x && atoi(x) >= 16 && atoi(x) <= 28) return (size_t) 1 << atoi(x);
-	size_t c = CLO_SCAN_PIPE_CHUNK;
-	while (c < CLO_SCAN_PIPE_CHUNK_MAX && c * 8 < numel) c <<= 1;
-	return c;
+	const size_t parts = numel < ((size_t) 1 << 25) ? 2 : 4;
+	size_t c = (numel + parts - 1) / parts;
+	c = (c + 4095) & ~(size_t) 4095;   /* whole 16-KiB blocks: every chunk starts 16-byte aligned */
+	return c < CLO_SCAN_PIPE_CHUNK_MAX ? c : CLO_SCAN_PIPE_CHUNK_MAX;
 }
 
 static void scan_pipe_res_free(scan_pipe_res* r) {
@@ -350,7 +354,7 @@ cl_bool clo_scan_with_host_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* c
 	}
 	if (cq_comm == NULL) cq_comm = cq_exec;
 
-	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && numel >= CLO_SCAN_PIPE_MIN_CHUNKS * CLO_SCAN_PIPE_CHUNK && ccl_queue_get_stream(cq_exec) != NULL
+	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && numel >= CLO_SCAN_PIPE_MIN_NUMEL && ccl_queue_get_stream(cq_exec) != NULL
 		&& getenv("CLO_SCAN_NO_PIPELINE") == NULL) {   /* (the variable: A/B measurements only) */
 		status = scan_with_host_data_pipelined(scanner, cq_exec, cq_comm, data_in, data_out, numel, &err_internal);
 		if (err_internal) goto error_handler;

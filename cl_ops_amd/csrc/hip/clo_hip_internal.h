@@ -64,13 +64,18 @@ inline clo_keyx clo_keyx_make(int kind, int key_shift, int key_bits) {
 
 // Radix passes (clo_hip_radix4.hip) and their histogram / counter-scan steps
 // (clo_hip_radixw.hip).
-size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int digit_bits);
+size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int digit_bits, int key_bits);
 size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits);
 int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
 	unsigned long long* counts, void* ws, hipStream_t s);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
 	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits);
+// single-sweep passes (clo_hip_radix1.hip); ws: its own region, status: the workspace's status word
+int clo_radix1_applies(size_t n, int elem_size, int digit_bits);
+size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits);
+int clo_radix1_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift, int key_bits,
+	clo_keyx kx, void* ws, unsigned* status, hipStream_t s);
 // the tiled bitonic schedule, one translation unit per element size
 int clo_bitonic_tiled_e1(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
 int clo_bitonic_tiled_e2(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);

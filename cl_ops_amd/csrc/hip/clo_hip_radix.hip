@@ -67,7 +67,7 @@ extern "C" {
 
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits) {
 	if (digit_bits < 1 || digit_bits > 8 || key_bits < 1) return 0;
-	return clo_radix4_workspace_bytes(numel, elem_size, digit_bits);
+	return clo_radix4_workspace_bytes(numel, elem_size, digit_bits, key_bits);
 }
 
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,

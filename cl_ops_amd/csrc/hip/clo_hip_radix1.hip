@@ -1,0 +1,507 @@
+// clo_hip_radix1.hip — LSD radix passes that read every element ONCE: the
+// per-tile histogram stream of the chain-free passes (clo_hip_radix4.hip: a
+// separate kernel re-reads the whole array per pass) is replaced by digit
+// counts handed from tile to tile inside the pass kernel.
+//
+// Per sort: one kernel reads the source once and counts, for every pass, the
+// 256 global digit totals (their exclusive scan = where each digit's output
+// starts); then one "sweep" kernel per 8 key bits. Per tile it does what
+// upstream's localsort + histogram + scan + scatter do per digit
+// (sort/clo_sort_satradix.c:264-313), for two 4-bit digits at once:
+//   load -> tile histogram of the combined digit (LDS counters) -> PUBLISH it
+//   -> two stable local splits (clo_hip_radix_rank.h) -> look back for the
+//   count of every digit in all earlier tiles -> scatter.
+// Output position of an element = global digit start + count of its digit in
+// earlier tiles + its rank inside the tile: upstream's
+// counters_sum[num_wgs*d + wg] + lid - offsets[d] (sort/clo_sort_satradix.cl:253),
+// so the order is the one upstream produces (stable, ascending).
+//
+// The look-back is two-level because a dependent memory round trip costs 1-3 us
+// on this chip while tiles start every ~15 ns: a tile-to-tile chain (each tile
+// walking back over single predecessors) resolves ~1 tile per round trip and
+// measured 6.4 ms per sort in round 1. Tiles form chunks of 16:
+//   level 1  a tile sums the published histograms of the earlier tiles of its
+//            own chunk (<= 15 rows, all requested at once, no chain);
+//   level 2  every tile also adds its histogram to the chunk's accumulator with
+//            a RETURNING atomic; the arrival that completes a (chunk, digit)
+//            looks back over a WINDOW of earlier chunks (their accumulators /
+//            inclusive prefixes, all requested at once) and publishes the
+//            chunk's inclusive prefix; a tile needs the prefix of the chunk
+//            before its own.
+// One hop of level 2 covers 16 * 8 = 128 tiles. Tile numbers are tickets (HIP
+// promises no dispatch order: a tile may only wait for tiles already handed
+// out), drawn from one counter per XCD: chunk j of pool x is global chunk
+// 8*j + x, so the 16 tiles of a chunk run behind one L2, where the boundary
+// lines of neighbouring runs merge (clo_hip_radix4.hip has the measurements),
+// and the eight pools advance side by side. Which XCD a work-group is on is
+// read from the hardware (XCC_ID) and used for speed only. Every poll loop is
+// bounded (status word, as the scan).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+#include "clo_hip_radix_rank.h"
+
+namespace {
+
+constexpr int R1_CHUNK_LOG = 4;
+constexpr unsigned R1_CHUNK = 1u << R1_CHUNK_LOG;    // tiles per chunk
+constexpr int R1_WINDOW = 8;                          // chunks a level-2 hop inspects
+constexpr unsigned R1_VALID = 0x80000000u;            // 32-bit entries: bit 31 = written, bits 30..0 = count
+constexpr int R1_CNT_SHIFT = 40;                      // 64-bit accumulators: arrivals << 40 | sum
+constexpr clo_u64 R1_SUM_MASK = (1ull << R1_CNT_SHIFT) - 1ull;
+constexpr int R1_ROW = 256;                           // counters per tile / chunk row
+constexpr int R1_POOLS = 8;
+constexpr int R1_TICKET_STRIDE = 16;                  // words between the pools' ticket counters (one 64-byte line each)
+constexpr int R1_GH_THREADS = 512;
+constexpr int R1_GH_COPIES = 4;
+
+__device__ __forceinline__ unsigned r1_ld32(const unsigned* p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void r1_st32(unsigned* p, unsigned v) {
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Speed only.
+__device__ __forceinline__ unsigned r1_xcc_id() {
+	return (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+}
+
+// ---------------------------------------------------------------------------
+// Global digit totals of every pass: one read of the source.
+// ---------------------------------------------------------------------------
+template <typename E, int NP>
+__global__ __launch_bounds__(R1_GH_THREADS)
+void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_shift, unsigned key_bits,
+	unsigned* __restrict__ ghist, int aligned, clo_keyx kx, unsigned tiles_per_group) {
+	constexpr int ITEMS = pair_shape<E>::ITEMS;
+	constexpr int TILE = R1_GH_THREADS * ITEMS;
+	__shared__ unsigned s_cnt[R1_GH_COPIES][NP][R1_ROW];
+	const unsigned tid = threadIdx.x, copy = (tid >> 6) & (R1_GH_COPIES - 1);
+	for (unsigned i = tid; i < R1_GH_COPIES * NP * R1_ROW; i += R1_GH_THREADS) (&s_cnt[0][0][0])[i] = 0;
+	__syncthreads();
+	const unsigned last_bits = key_bits - 8u * (NP - 1);
+	const unsigned last_mask = (1u << last_bits) - 1u;
+	const size_t tile0 = (size_t) blockIdx.x * tiles_per_group;
+	for (unsigned t = 0; t < tiles_per_group; ++t) {
+		const size_t base = (tile0 + t) * TILE;
+		if (base >= n) break;
+		const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+		const unsigned tbase = tid * ITEMS;
+		E key[ITEMS];
+		if (count == (unsigned) TILE) {
+			load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
+		}
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			if (count == (unsigned) TILE || tbase + i < count) {
+				const E k = clo_keyx_fwd<E>(key[i], kx) >> key_shift;
+				#pragma unroll
+				for (int p = 0; p < NP; ++p) {
+					const unsigned d = (unsigned) (k >> (8 * p)) & (p == NP - 1 ? last_mask : 255u);
+					atomicAdd(&s_cnt[copy][p][d], 1u);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	for (unsigned i = tid; i < NP * R1_ROW; i += R1_GH_THREADS) {
+		unsigned v = 0;
+		#pragma unroll
+		for (int c = 0; c < R1_GH_COPIES; ++c) v += (&s_cnt[c][0][0])[i];
+		if (v) atomicAdd(&ghist[i], v);
+	}
+}
+
+// Digit totals -> digit starts (exclusive scan over the 256 digits), one work-group per pass.
+__global__ __launch_bounds__(R1_ROW)
+void clo_radix1_bases_kernel(const unsigned* __restrict__ ghist, unsigned* __restrict__ gbase) {
+	__shared__ unsigned s_w[4];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned v = ghist[blockIdx.x * R1_ROW + tid];
+	const unsigned incl = clo_wave_scan_inclusive<unsigned>(v, lane);
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	unsigned b = incl - v;
+	#pragma unroll
+	for (unsigned w = 0; w < 4; ++w) if (w < wave) b += s_w[w];
+	gbase[blockIdx.x * R1_ROW + tid] = b;
+}
+
+// ---------------------------------------------------------------------------
+// The sweep kernel: one pass on 8 key bits (two local digits of <= 4 bits).
+// ---------------------------------------------------------------------------
+struct r1_pass {
+	unsigned* agg;           // [tiles][256]   tile histograms: R1_VALID | count
+	clo_u64* cacc;           // [chunks][256]  arrivals << 40 | sum of the chunk's tile histograms
+	unsigned* cprefix;       // [chunks][256]  R1_VALID | count of the digit in all tiles up to the end of the chunk
+	unsigned* ticket;        // [8 pools], R1_TICKET_STRIDE words apart
+	const unsigned* gbase;   // [256] global start of every digit
+	unsigned* status;        // workspace status word
+	clo_u64* stamps;         // optional: 8 s_memtime stamps per tile (diagnostic builds of the probe tools)
+	unsigned tiles, max_spins;
+};
+
+template <typename E, int LB, int HB>
+__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)
+void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
+	unsigned shift, unsigned mask_lo, unsigned mask_hi, r1_pass P, int aligned, clo_keyx kx_in, clo_keyx kx_out) {
+
+	constexpr int THREADS = pair_shape<E>::THREADS;
+	constexpr int ITEMS = pair_shape<E>::ITEMS;
+	constexpr int TILE = THREADS * ITEMS;
+	constexpr int WAVES = THREADS / 64;
+	constexpr int R2 = 1 << (LB + HB);
+	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
+	static_assert(R2 <= R1_ROW && R2 <= THREADS, "one thread per combined digit");
+	static_assert(THREADS * PC_END_STRIDE >= WAVES * R1_ROW, "the tile histogram's wave counters borrow the table of ends");
+
+	__shared__ E s_stage[TILE];
+	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
+	__shared__ unsigned s_wtot[WAVES][HMAX];
+	__shared__ unsigned s_wbase[WAVES][HMAX];
+	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
+	__shared__ unsigned s_w4[4];
+	__shared__ unsigned s_tile;
+
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	clo_u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+	if (P.stamps) t0 = __builtin_amdgcn_s_memtime();
+
+	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
+	if (tid == 0) {
+		const unsigned nchunks = (P.tiles + R1_CHUNK - 1u) >> R1_CHUNK_LOG;
+		const unsigned x = r1_xcc_id();
+		unsigned tile = 0xffffffffu;
+		for (unsigned t = 0; t < (unsigned) R1_POOLS; ++t) {
+			const unsigned pool = (x + t) & (R1_POOLS - 1);
+			// (tiles of pool `pool`: chunks pool, pool + 8, ...; only the very last chunk may be partial)
+			const unsigned k = atomicAdd(&P.ticket[pool * R1_TICKET_STRIDE], 1u);
+			const unsigned c = (k >> R1_CHUNK_LOG) * R1_POOLS + pool;
+			const unsigned cand = (c << R1_CHUNK_LOG) + (k & (R1_CHUNK - 1u));
+			if (c < nchunks && cand < P.tiles) { tile = cand; break; }
+		}
+		s_tile = tile;
+	}
+	__syncthreads();
+	const unsigned tile = s_tile;
+	if (tile == 0xffffffffu) return;   // (cannot happen: as many work-groups as tiles, one valid ticket each)
+	const unsigned c = tile >> R1_CHUNK_LOG, q = tile & (R1_CHUNK - 1u);
+	const unsigned in_chunk = P.tiles - (c << R1_CHUNK_LOG) < R1_CHUNK ? P.tiles - (c << R1_CHUNK_LOG) : R1_CHUNK;
+	const size_t base = (size_t) tile * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	const bool full = count == (unsigned) TILE;
+	const unsigned tbase = tid * ITEMS;
+	const unsigned mask2 = (mask_hi << LB) | mask_lo;
+	const unsigned n32 = (unsigned) n;   // n < 2^31 here
+
+	// ---- load; histogram of the combined digit in per-wave LDS counters ----
+	unsigned* s_hist = s_end;   // [WAVES][256], gone before the first split fills the table of ends
+	#pragma unroll
+	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
+	E key[ITEMS];
+	if (full) {
+		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
+	}
+	if (kx_in.kind) {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
+	}
+	__syncthreads();
+	if (P.stamps) t1 = __builtin_amdgcn_s_memtime();
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i)
+		if (full || tbase + i < count) atomicAdd(&s_hist[wave * R1_ROW + ((unsigned) (key[i] >> shift) & mask2)], 1u);
+	__syncthreads();
+
+	// ---- publish: the tile's row, and its arrival at the chunk's accumulator ----
+	unsigned h2 = 0;
+	clo_u64 old = 0;
+	if (tid < (unsigned) R2) {
+		#pragma unroll
+		for (int w = 0; w < WAVES; ++w) h2 += s_hist[w * R1_ROW + tid];
+		r1_st32(&P.agg[(size_t) tile * R1_ROW + tid], R1_VALID | h2);
+		old = __hip_atomic_fetch_add(&P.cacc[(size_t) c * R1_ROW + tid], (1ull << R1_CNT_SHIFT) | (clo_u64) h2,
+			__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	if (P.stamps) t2 = __builtin_amdgcn_s_memtime();
+	// tile-local start of every combined digit: exclusive scan of the tile's histogram
+	const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
+	if (lane == 63 && wave < 4) s_w4[wave] = incl2;
+
+	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
+
+	unsigned dstart2 = 0;
+	if (tid < (unsigned) R2) {
+		dstart2 = incl2 - h2;
+		#pragma unroll
+		for (unsigned w = 0; w < 4; ++w) if (w < wave) dstart2 += s_w4[w];
+		// ---- level 2, by whichever tile completed (chunk, digit): look back over the
+		// earlier chunks, a window at a time, and publish the chunk's inclusive prefix ----
+		if ((unsigned) (old >> R1_CNT_SHIFT) == in_chunk - 1u) {
+			const clo_u64 total = (old & R1_SUM_MASK) + h2;
+			clo_u64 excl = 0;
+			long j = (long) c - 1;
+			unsigned spins = 0;
+			while (j >= 0) {
+				unsigned pv[R1_WINDOW];
+				clo_u64 av[R1_WINDOW];
+				#pragma unroll
+				for (int w = 0; w < R1_WINDOW; ++w) {
+					pv[w] = 0; av[w] = 0;
+					if (j - w >= 0) {
+						pv[w] = r1_ld32(&P.cprefix[(size_t) (j - w) * R1_ROW + tid]);
+						av[w] = clo_ld_agent(&P.cacc[(size_t) (j - w) * R1_ROW + tid]);
+					}
+				}
+				bool closed = false, stalled = false;
+				int used = 0;
+				#pragma unroll
+				for (int w = 0; w < R1_WINDOW; ++w) {
+					if (closed || stalled || j - w < 0) continue;
+					if (pv[w] & R1_VALID) { excl += pv[w] & ~R1_VALID; closed = true; }
+					else if ((unsigned) (av[w] >> R1_CNT_SHIFT) == R1_CHUNK) { excl += av[w] & R1_SUM_MASK; used = w + 1; }   // (every earlier chunk is full)
+					else stalled = true;
+				}
+				if (closed) break;
+				j -= used;
+				if (stalled) {
+					if (++spins > P.max_spins) { atomicExch(P.status, 1u); break; }
+					__builtin_amdgcn_s_sleep(2);
+				}
+			}
+			r1_st32(&P.cprefix[(size_t) c * R1_ROW + tid], R1_VALID | (unsigned) (excl + total));
+		}
+	}
+	if (P.stamps) t3 = __builtin_amdgcn_s_memtime();
+
+	if (mask_hi != 0) {
+		if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)
+			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
+			typedef E vec16 __attribute__((ext_vector_type(PER)));
+			#pragma unroll
+			for (int k = 0; k < ITEMS / PER; ++k) {
+				const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
+				#pragma unroll
+				for (int qq = 0; qq < PER; ++qq) key[k * PER + qq] = t[qq];
+			}
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
+		}
+		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase);
+	}
+	if (P.stamps) t4 = __builtin_amdgcn_s_memtime();
+
+	// ---- the tile's prefix: level 1 (earlier tiles of the chunk) + the prefix of the chunk before ----
+	if (tid < (unsigned) R2) {
+		unsigned v[R1_CHUNK];   // v[0]: prefix of the previous chunk; v[k]: row of tile - k
+		#pragma unroll
+		for (unsigned k = 0; k < R1_CHUNK; ++k) v[k] = R1_VALID;
+		unsigned spins = 0;
+		for (bool first = true; ; first = false) {
+			#pragma unroll
+			for (unsigned k = 0; k < R1_CHUNK; ++k) {
+				const bool want = k == 0 ? c > 0 : k <= q;
+				if (want && (first || !(v[k] & R1_VALID))) {
+					v[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + tid])
+					              : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + tid]);
+				}
+			}
+			bool all = true;
+			#pragma unroll
+			for (unsigned k = 0; k < R1_CHUNK; ++k) all = all && (v[k] & R1_VALID);
+			if (all) break;
+			if (++spins > P.max_spins) { atomicExch(P.status, 1u); break; }
+			__builtin_amdgcn_s_sleep(1);
+		}
+		unsigned excl = 0;
+		#pragma unroll
+		for (unsigned k = 0; k < R1_CHUNK; ++k) excl += v[k] & ~R1_VALID;
+		s_delta[tid] = P.gbase[tid] + excl - dstart2;
+	}
+	__syncthreads();
+	if (P.stamps) t5 = __builtin_amdgcn_s_memtime();
+
+	// ---- contiguous runs to HBM (as the pair kernel of clo_hip_radix4.hip) ----
+	constexpr int VEC = sizeof(E) >= 8 ? 1 : 4;
+	typedef E vecE __attribute__((ext_vector_type(VEC)));
+	typedef E vecE_u __attribute__((ext_vector_type(VEC), aligned(sizeof(E))));
+	#pragma unroll
+	for (int j = 0; j < ITEMS / VEC; ++j) {
+		const unsigned p = (j * THREADS + tid) * VEC;
+		if (full) {
+			const vecE vv = *reinterpret_cast<const vecE*>(&s_stage[p]);
+			const unsigned d0 = (unsigned) (vv[0] >> shift) & mask2, dl = (unsigned) (vv[VEC - 1] >> shift) & mask2;
+			const unsigned gi0 = p + s_delta[d0];
+			if (d0 == dl && gi0 <= n32 - VEC) {
+				vecE vo = vv;
+				if (kx_out.kind) {
+					#pragma unroll
+					for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(vv[k], kx_out);
+				}
+				*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
+			} else {
+				#pragma unroll
+				for (int k = 0; k < VEC; ++k) {
+					const unsigned gi = p + k + s_delta[(unsigned) (vv[k] >> shift) & mask2];
+					if (gi < n32) out[gi] = clo_keyx_inv<E>(vv[k], kx_out);
+				}
+			}
+		} else {
+			#pragma unroll
+			for (int k = 0; k < VEC; ++k) {
+				if (p + k < count) {
+					const E e = s_stage[p + k];
+					const unsigned gi = p + k + s_delta[(unsigned) (e >> shift) & mask2];
+					if (gi < n32) out[gi] = clo_keyx_inv<E>(e, kx_out);
+				}
+			}
+		}
+	}
+	if (P.stamps && tid == 0) {
+		clo_u64* st = P.stamps + (size_t) tile * 8;
+		st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3; st[4] = t4; st[5] = t5;
+		st[6] = __builtin_amdgcn_s_memtime();
+		st[7] = ((clo_u64) r1_xcc_id() << 32) | blockIdx.x;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct r1_layout { size_t ghist, gbase, tickets, pass0, per_pass, agg, cacc, cprefix, total, tiles, chunks; int passes; };
+
+r1_layout r1_make_layout(size_t n, int elem_size, int key_bits) {
+	r1_layout L;
+	const size_t tile = (size_t) 512 * (elem_size == 8 ? 8 : 16);
+	L.tiles = (n + tile - 1) / tile;
+	if (L.tiles == 0) L.tiles = 1;
+	L.chunks = (L.tiles + R1_CHUNK - 1) / R1_CHUNK;
+	L.passes = (key_bits + 7) / 8;
+	size_t off = 0;
+	L.ghist = off; off += (size_t) L.passes * R1_ROW * sizeof(unsigned);
+	L.gbase = off; off += (size_t) L.passes * R1_ROW * sizeof(unsigned);
+	L.tickets = off; off += (size_t) L.passes * R1_POOLS * R1_TICKET_STRIDE * sizeof(unsigned);
+	off = (off + 255) & ~(size_t) 255;
+	L.pass0 = off;
+	L.agg = 0;
+	L.cacc = L.agg + L.tiles * R1_ROW * sizeof(unsigned);
+	L.cprefix = L.cacc + L.chunks * R1_ROW * sizeof(clo_u64);
+	L.per_pass = (L.cprefix + L.chunks * R1_ROW * sizeof(unsigned) + 255) & ~(size_t) 255;
+	L.total = L.pass0 + L.per_pass * (size_t) L.passes;
+	return L;
+}
+
+clo_u64* g_r1_stamps = nullptr;   // diagnostic (clo_hip_radix_debug_stamps)
+size_t g_r1_stamps_tiles = 0;
+
+template <typename E, int NP>
+void r1_launch_ghist(const E* src, size_t n, int key_shift, int key_bits, unsigned* ghist, clo_keyx kx, unsigned tiles, hipStream_t s) {
+	const unsigned per = tiles > 4096u ? (tiles + 2047u) / 2048u : (tiles > 256u ? 2u : 1u);
+	const unsigned groups = (tiles + per - 1u) / per;
+	hipLaunchKernelGGL((clo_radix1_ghist_kernel<E, NP>), dim3(groups), dim3(R1_GH_THREADS), 0, s,
+		src, n, (unsigned) key_shift, (unsigned) key_bits, ghist, (int) ((uintptr_t) src % 16 == 0), kx, per);
+}
+
+template <typename E>
+int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, clo_keyx kx, void* ws, unsigned* status, hipStream_t s) {
+	const r1_layout L = r1_make_layout(n, (int) sizeof(E), key_bits);
+	char* w = (char*) ws;
+	unsigned* ghist = (unsigned*) (w + L.ghist);
+	unsigned* gbase = (unsigned*) (w + L.gbase);
+	unsigned* tickets = (unsigned*) (w + L.tickets);
+	const unsigned tiles = (unsigned) L.tiles;
+	const int passes = L.passes;
+	const clo_keyx kx_none = { 0, 0, 0 };
+	unsigned max_spins = CLO_MAX_SPINS;
+	if (const char* m = getenv("CLO_MAX_SPINS")) max_spins = (unsigned) strtoul(m, nullptr, 10);
+
+	// everything the passes publish or count in starts from zero
+	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
+	if (e != hipSuccess) return (int) e;
+	{
+		clo_timing_scope timing("radix_ghist", s);
+		switch (passes) {
+			#define CLO_R1_GH(NP) case NP: r1_launch_ghist<E, NP>(src, n, key_shift, key_bits, ghist, kx, tiles, s); break
+			CLO_R1_GH(1); CLO_R1_GH(2); CLO_R1_GH(3); CLO_R1_GH(4); CLO_R1_GH(5); CLO_R1_GH(6); CLO_R1_GH(7); CLO_R1_GH(8);
+			#undef CLO_R1_GH
+			default: return CLO_HIP_EUNSUPPORTED;
+		}
+		hipLaunchKernelGGL(clo_radix1_bases_kernel, dim3(passes), dim3(R1_ROW), 0, s, (const unsigned*) ghist, gbase);
+	}
+	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
+	const E* cur_in = src;
+	for (int p = 0; p < passes; ++p) {
+		E* cur_out;
+		if (inplace_odd) cur_out = (p % 2 == 0) ? tmp : dst;
+		else cur_out = ((passes - 1 - p) % 2 == 0) ? dst : tmp;
+		const int rem = key_bits - p * 8;
+		const int bits = rem < 8 ? rem : 8;
+		const int lo_bits = bits < 4 ? bits : 4, hi_bits = bits - lo_bits;
+		char* pw = w + L.pass0 + (size_t) p * L.per_pass;
+		r1_pass P;
+		P.agg = (unsigned*) (pw + L.agg);
+		P.cacc = (clo_u64*) (pw + L.cacc);
+		P.cprefix = (unsigned*) (pw + L.cprefix);
+		P.ticket = tickets + (size_t) p * R1_POOLS * R1_TICKET_STRIDE;
+		P.gbase = gbase + (size_t) p * R1_ROW;
+		P.status = status;
+		P.stamps = (g_r1_stamps && g_r1_stamps_tiles >= L.tiles && p == passes - 1) ? g_r1_stamps : nullptr;
+		P.tiles = tiles;
+		P.max_spins = max_spins;
+		clo_timing_scope timing("radix_sweep", s);
+		hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s,
+			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P,
+			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
+		cur_in = cur_out;
+	}
+	e = hipGetLastError();
+	if (e != hipSuccess) return (int) e;
+	if (inplace_odd) {
+		e = hipMemcpyAsync(dst, tmp, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+		if (e != hipSuccess) return (int) e;
+	}
+	return 0;
+}
+
+}  // namespace
+
+// 1: the single-sweep passes handle this sort; 0: the chain-free pair passes do
+// (clo_hip_radix4.hip). Digits of 4 or 8 bits only (radix 16: two digits per
+// sweep; radix 256: one), 4- and 8-byte elements, fewer than 2^31 of them.
+int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
+	// CLO_RADIX_SWEEP: 0 never, 1 whenever possible, unset: the library's choice (read per call: A/B runs)
+	const char* x = getenv("CLO_RADIX_SWEEP");
+	const int mode = x ? (atoi(x) != 0 ? 1 : 0) : 2;
+	if (mode == 0) return 0;
+	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
+	if (mode == 1) return n > (size_t) 512 * 8;
+	return 0;   // (default: off until it is the faster path — see DESIGN.md)
+}
+
+size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {
+	return r1_make_layout(n, elem_size, key_bits).total;
+}
+
+int clo_radix1_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift, int key_bits,
+	clo_keyx kx, void* ws, unsigned* status, hipStream_t s) {
+	if (elem_size == 4) return r1_sort_impl<uint32_t>((const uint32_t*) src, (uint32_t*) dst, (uint32_t*) tmp, n, key_shift, key_bits, kx, ws, status, s);
+	if (elem_size == 8) return r1_sort_impl<uint64_t>((const uint64_t*) src, (uint64_t*) dst, (uint64_t*) tmp, n, key_shift, key_bits, kx, ws, status, s);
+	return CLO_HIP_EUNSUPPORTED;
+}
+
+extern "C" int clo_hip_radix_debug_stamps(void* buffer, size_t tiles) {
+	g_r1_stamps = (clo_u64*) buffer;
+	g_r1_stamps_tiles = buffer ? tiles : 0;
+	return 0;
+}

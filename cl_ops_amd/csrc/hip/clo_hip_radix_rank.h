@@ -1,0 +1,214 @@
+// clo_hip_radix_rank.h — ranking with thread-private packed counters and the
+// stable local split of a tile built on it: shared by the radix pass kernels
+// (clo_hip_radix4.hip: chain-free pair passes; clo_hip_radix1.hip: single-sweep
+// passes). Device code only; every function is a template or forced inline.
+#ifndef CLO_HIP_RADIX_RANK_H
+#define CLO_HIP_RADIX_RANK_H
+
+#include <hip/hip_runtime.h>
+
+#include "clo_hip_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Ranking with thread-private packed counters.
+//
+// Ranking by wave-wide match-any costs ~40 VALU instructions per element (one
+// ballot and a 64-bit select/and per digit bit); a pass built on it measured
+// VALU-bound (SQ_INSTS_VALU = 85 per element). Here each thread owns ITEMS = 8
+// CONSECUTIVE elements and counts digits in thread-private packed counters
+// (16 digits x 4 bits in one 64-bit register), which also yield each element's
+// rank among the thread's own elements. One wave64 DPP scan of the widened
+// counters plus a cross-wave step through LDS gives, per thread, the count of
+// every digit among all earlier threads of the tile. Thread order = element
+// order, so the ranking is stable.
+// ---------------------------------------------------------------------------
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_add(unsigned x) {
+	return x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true);
+}
+
+constexpr int PC_END_STRIDE = 9;   // dwords per thread in the table of ends: 8 words of two digits each, padded to an odd stride
+
+template <int BITS> struct pc_words { static constexpr int H = (1 << BITS) >= 2 ? (1 << BITS) / 2 : 1; };
+
+template <typename E, int ITEMS>
+__device__ __forceinline__ void load_blocked(const E* __restrict__ p, E (&key)[ITEMS], bool aligned) {
+	if (aligned) {
+		typedef E vecN __attribute__((ext_vector_type(ITEMS)));
+		const vecN v = *reinterpret_cast<const vecN*>(p);
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = v[i];
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) key[i] = p[i];
+	}
+}
+
+// The thread-private 4-bit counters first widen to 8-bit fields only (4
+// digits per VGPR: even digits in one word, odd digits in the next): an
+// inclusive scan inside a row of 16 lanes cannot exceed 16 * 15 = 240. Only
+// then do they widen to 16-bit fields for the two cross-row steps; v_perm_b32
+// builds w[j] = count(2j) | count(2j+1) << 16 from one even and one odd word.
+// TWO: the thread counted in two packed counters (up to 16 elements): their
+// 8-bit images are added first, and since 16 lanes * 16 could reach 256 the
+// last in-row step (row_shr:8) runs on the 16-bit fields.
+template <int BITS, bool TWO>
+__device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned long long c2, unsigned (&w)[pc_words<BITS>::H]) {
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int NB = (1 << BITS) == 16 ? 4 : 2;   // words of 8-bit fields
+	unsigned b[NB];
+	const unsigned lo = (unsigned) c, hi = (unsigned) (c >> 32);
+	b[0] = lo & 0x0f0f0f0fu;          // digits 0,2,4,6
+	b[1] = (lo >> 4) & 0x0f0f0f0fu;   // digits 1,3,5,7
+	if constexpr (NB == 4) {
+		b[2] = hi & 0x0f0f0f0fu;
+		b[3] = (hi >> 4) & 0x0f0f0f0fu;
+	}
+	if constexpr (TWO) {
+		const unsigned lo2 = (unsigned) c2, hi2 = (unsigned) (c2 >> 32);
+		b[0] += lo2 & 0x0f0f0f0fu;
+		b[1] += (lo2 >> 4) & 0x0f0f0f0fu;
+		if constexpr (NB == 4) {
+			b[2] += hi2 & 0x0f0f0f0fu;
+			b[3] += (hi2 >> 4) & 0x0f0f0f0fu;
+		}
+	}
+	#pragma unroll
+	for (int k = 0; k < NB; ++k) {
+		unsigned x = b[k];
+		x = dpp_add<0x111, 0xF>(x);
+		x = dpp_add<0x112, 0xF>(x);
+		x = dpp_add<0x114, 0xF>(x);
+		b[k] = TWO ? x : dpp_add<0x118, 0xF>(x);
+	}
+	#pragma unroll
+	for (int j = 0; j < H; ++j) {
+		// byte (j & 3) of the even word -> bits 0..15, of the odd word -> bits 16..31
+		const unsigned sel = 0x0c040c00u + (unsigned) (j & 3) * 0x00010001u;
+		unsigned x = __builtin_amdgcn_perm(b[(j >> 2) * 2 + 1], b[(j >> 2) * 2], sel);
+		if constexpr (TWO) x = dpp_add<0x118, 0xF>(x);
+		x = dpp_add<0x142, 0xA>(x);
+		w[j] = dpp_add<0x143, 0xC>(x);
+	}
+}
+
+// One stable local split of the tile by the digit (key >> dshift) & dmask;
+// on return (after a barrier) s_stage holds the tile in digit order. The
+// thread's elements are ITEMS consecutive positions of the tile.
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX>
+__device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX]) {
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int WAVES = THREADS / 64;
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	const unsigned tbase = tid * ITEMS;
+	const bool full = count == (unsigned) (THREADS * ITEMS);
+
+	// thread-private counts, LAST element first: rr = 1 + the number of LATER
+	// elements of the thread with the same digit, so that the element's position
+	// is (end of the thread's slice of that digit) - rr. More than 8 elements
+	// per thread: two counters (4-bit fields hold up to 15).
+	static_assert(ITEMS == 8 || ITEMS == 16, "one or two packed counters");
+	unsigned long long c = 0, c2 = 0;
+	// ITEMS == 8: one register per rank; ITEMS == 16: (rank - 1) packed 4 bits each (register budget)
+	unsigned rr[ITEMS == 8 ? 8 : 2];
+	#pragma unroll
+	for (int k = 0; k < (ITEMS == 8 ? 8 : 2); ++k) rr[k] = 0;
+	#pragma unroll
+	for (int i = ITEMS - 1; i >= 8; --i) {   // (ITEMS == 16 only)
+		if (full || tbase + i < count) {
+			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
+			rr[1] |= ((unsigned) (c2 >> sh) & 15u) << (4 * (i - 8));   // count BEFORE this element = rank - 1
+			c2 += 1ull << sh;
+		}
+	}
+	#pragma unroll
+	for (int i = 7; i >= 0; --i) {
+		if (full || tbase + i < count) {
+			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
+			if (ITEMS == 8) {
+				c += 1ull << sh;
+				rr[i] = (unsigned) (c >> sh) & 15u;
+			} else {
+				rr[0] |= ((((unsigned) (c >> sh) & 15u) + ((unsigned) (c2 >> sh) & 15u)) & 15u) << (4 * i);   // <= 15
+				c += 1ull << sh;
+			}
+		}
+	}
+	unsigned w[H];
+	pc2_wave_scan<BITS, (ITEMS > 8)>(c, c2, w);
+	if (lane == 63) {
+		#pragma unroll
+		for (int j = 0; j < H; ++j) s_wtot[wave][j] = w[j];
+	}
+	__syncthreads();
+	if (wave == 0) {
+		// Wave 0 turns the wave totals into every wave's base, per digit: lane
+		// (q, wv) = (lane / 16, lane % 16) takes word 4r + q of wave wv; a DPP scan
+		// inside rows of 16 lanes runs over the waves, lane 15 of a row ends up with
+		// the digit totals of its word, and a 16-step serial prefix over those
+		// (wave-uniform values) gives the digit starts. One barrier later every
+		// thread has its bases.
+		static_assert(WAVES <= 16, "one row of 16 lanes spans the waves");
+		constexpr int ROUNDS = (H + 3) / 4;
+		const unsigned wv = lane & 15u, q = lane >> 4;
+		unsigned excl[ROUNDS], tot[ROUNDS];
+		#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+			const unsigned j = r * 4 + q;
+			const unsigned x = (j < (unsigned) H && wv < (unsigned) WAVES) ? s_wtot[wv][j] : 0u;
+			unsigned incl = dpp_add<0x111, 0xF>(x);
+			incl = dpp_add<0x112, 0xF>(incl);
+			incl = dpp_add<0x114, 0xF>(incl);
+			incl = dpp_add<0x118, 0xF>(incl);
+			excl[r] = incl - x;
+			tot[r] = incl;
+		}
+		unsigned run = 0, dstart16[H];
+		#pragma unroll
+		for (int j = 0; j < H; ++j) {
+			const unsigned t = (unsigned) __shfl((int) tot[j / 4], (j % 4) * 16 + 15, 64);   // packed totals of digits 2j, 2j+1
+			dstart16[j] = run | ((run + (t & 0xffffu)) << 16);
+			run += (t & 0xffffu) + (t >> 16);
+		}
+		#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+			unsigned mine = dstart16[r * 4];
+			#pragma unroll
+			for (int k = 1; k < 4; ++k) if (r * 4 + k < H && q == (unsigned) k) mine = dstart16[r * 4 + k];
+			const unsigned j = r * 4 + q;
+			if (j < (unsigned) H && wv < (unsigned) WAVES) s_wbase[wv][j] = mine + excl[r];
+		}
+	}
+	__syncthreads();
+	#pragma unroll
+	// the thread's 16-bit ends, thread-major with a stride of PC_END_STRIDE dwords
+	// (odd: the lanes' rows start in different banks): the lookup per element is
+	// one address (digit * 2 + row) and one ds_read_u16
+	for (int j = 0; j < H; ++j) s_end[tid * PC_END_STRIDE + j] = w[j] + s_wbase[wave][j];
+	const unsigned short* s_end16 = reinterpret_cast<const unsigned short*>(s_end) + tid * (2 * PC_END_STRIDE);
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		if (full || tbase + i < count) {
+			const unsigned d = (unsigned) (key[i] >> dshift) & dmask;
+			const unsigned end = s_end16[d];
+			const unsigned back = ITEMS == 8 ? rr[i] : ((rr[i >> 3] >> (4 * (i & 7))) & 15u) + 1u;
+			s_stage[end - back] = key[i];   // (counts of these very elements: always inside the tile)
+		}
+	}
+	__syncthreads();
+}
+
+// Shape of a tile of the pass kernels: 512 threads x 16 consecutive elements
+// (8 for 8-byte elements) = 32 KiB of LDS stage either way.
+template <typename E> struct pair_shape {
+	static constexpr int THREADS = 512;                           // tiles of 8192 (<= 4-byte elements) / 4096 elements,
+	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;         // = the tiles of clo_hip_radixw.hip's histogram
+};
+
+}  // namespace
+
+#endif

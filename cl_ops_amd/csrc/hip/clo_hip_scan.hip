@@ -378,6 +378,12 @@ constexpr size_t scan_tile_elems(size_t numel, int sum_size) {
 	return (size_t) scan_threads(numel) * SCAN_VEC * (numel >= SCAN_BIG_NUMEL ? SCAN_BIG_ROWS : scan_small_rows(sum_size));
 }
 
+// Granules a workspace for `tiles` tiles holds, and how many of them (at its
+// start) are the super-tile accumulators: two per super-tile the workspace could
+// ever serve (a workspace of G granules serves at most G / 2 tiles).
+constexpr size_t scan_ws_granules(size_t tiles) { return tiles * 2 + 8 * ((tiles >> SCAN_SUPER_LOG) + 2); }
+constexpr size_t scan_sacc_granules(size_t ws_granules) { return 2 * (ws_granules / 128 + 2); }
+
 template <typename TIn, typename TOut>
 int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, clo_u64* carry_out, void* ws, size_t ws_bytes, hipStream_t s) {
 	if constexpr (sizeof(TIn) > sizeof(TOut)) {
@@ -387,17 +393,22 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		constexpr int ROWS = scan_small_rows((int) sizeof(TOut));
 		const size_t tile = scan_tile_elems(n, (int) sizeof(TOut));
 		const size_t tiles = (n + tile - 1) / tile;
+		// Workspace: [header][accumulators][look-back entries of THIS call's tiles].
+		// The accumulators are plain counters that must start from zero — the
+		// arrival that completes one zeroes it again — so they live in a region
+		// whose place depends on the workspace's size only: the epoch-tagged entries
+		// of another call (another tile count, another layout) never land on them.
 		unsigned* hdr = (unsigned*) ws;
-		clo_u64* state = (clo_u64*) ((char*) ws + CLO_WS_HEADER_BYTES);
+		const size_t ws_granules = (ws_bytes - CLO_WS_HEADER_BYTES) / sizeof(clo_u64);
+		clo_u64* sacc = (clo_u64*) ((char*) ws + CLO_WS_HEADER_BYTES);
+		clo_u64* state = sacc + scan_sacc_granules(ws_granules);
 		const size_t supers = (tiles >> SCAN_SUPER_LOG) + 1;
 		clo_u64* sstate = state + tiles * 2;
 		clo_u64* sagg = sstate + supers * 2;
-		clo_u64* sacc = sagg + supers * 2;
 		const int aligned = ((uintptr_t) in % (4 * sizeof(TIn)) == 0) && ((uintptr_t) out % (4 * sizeof(TOut)) == 0);
 		// No clearing of the workspace: granules carry the call's epoch, accumulators
 		// and counters are put back by the kernel itself (clo_hip_scan_workspace_init
 		// zeroed everything once).
-		const size_t ws_granules = (ws_bytes - CLO_WS_HEADER_BYTES) / sizeof(clo_u64);
 		const unsigned max_spins = g_scan_max_spins;
 		clo_timing_scope timing("scan", s);
 		// as many work-groups as fit the chip at once; each draws tiles until none is left
@@ -486,7 +497,7 @@ size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
 	const size_t tile = scan_tile_elems(0, sum_size);
 	const size_t tiles = (numel + tile - 1) / tile;
 	const size_t t = tiles ? tiles : 1;
-	return CLO_WS_HEADER_BYTES + t * 16 + ((t >> SCAN_SUPER_LOG) + 1) * 48;
+	return CLO_WS_HEADER_BYTES + scan_ws_granules(t) * sizeof(clo_u64);
 }
 
 int clo_hip_scan_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {

@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Bounded look-back spins: the library's default bound (2^22 polls, seconds per give-up)
+# is sized for production; under test a wait that long is a bug, and a chain of tiles
+# timing out one after another would look like a hang. 2^16 polls is still ~0.1 s.
+os.environ.setdefault("CLO_MAX_SPINS", str(1 << 16))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
