@@ -48,7 +48,7 @@ namespace {
 
 constexpr int R1_CHUNK_LOG = 4;
 constexpr unsigned R1_CHUNK = 1u << R1_CHUNK_LOG;    // tiles per chunk
-constexpr int R1_WINDOW = 8;                          // chunks a level-2 hop inspects
+constexpr int R1_WINDOW = 8;                         // chunks a level-2 hop inspects
 constexpr unsigned R1_VALID = 0x80000000u;            // 32-bit entries: bit 31 = written, bits 30..0 = count
 constexpr int R1_CNT_SHIFT = 40;                      // 64-bit accumulators: arrivals << 40 | sum
 constexpr clo_u64 R1_SUM_MASK = (1ull << R1_CNT_SHIFT) - 1ull;
@@ -56,7 +56,7 @@ constexpr int R1_ROW = 256;                           // counters per tile / chu
 constexpr int R1_POOLS = 8;
 constexpr int R1_TICKET_STRIDE = 16;                  // words between the pools' ticket counters (one 64-byte line each)
 constexpr int R1_GH_THREADS = 512;
-constexpr int R1_GH_COPIES = 4;
+constexpr int R1_GH_COPIES = 8;
 
 __device__ __forceinline__ unsigned r1_ld32(const unsigned* p) {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -148,7 +148,9 @@ struct r1_pass {
 	unsigned tiles, max_spins;
 };
 
-template <typename E, int LB, int HB>
+// R1_EARLY: level-1 entries (the previous chunk's prefix + the nearest rows) requested
+// before the second split, so that their round trip runs under it.
+template <typename E, int LB, int HB, int R1_EARLY>
 __global__ __launch_bounds__(pair_shape<E>::THREADS, 6)
 void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi, r1_pass P, int aligned, clo_keyx kx_in, clo_keyx kx_out) {
@@ -160,7 +162,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	constexpr int R2 = 1 << (LB + HB);
 	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
 	static_assert(R2 <= R1_ROW && R2 <= THREADS, "one thread per combined digit");
-	static_assert(THREADS * PC_END_STRIDE >= WAVES * R1_ROW, "the tile histogram's wave counters borrow the table of ends");
+	static_assert(THREADS >= 2 * R1_ROW, "the digit threads are the second half of the work-group");
 
 	__shared__ E s_stage[TILE];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
@@ -173,6 +175,21 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	clo_u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
 	if (P.stamps) t0 = __builtin_amdgcn_s_memtime();
+
+	// The digits' bookkeeping (publishing, look-back) belongs to the SECOND half of
+	// the work-group, one thread per combined digit: those waves have nothing to do
+	// while wave 0 turns wave totals into wave bases inside a local split.
+	const int dg = (int) tid - (THREADS - R1_ROW);
+	const bool dthread = dg >= 0 && dg < R2;
+	const bool dwaves = wave >= (unsigned) (WAVES - R1_ROW / 64);
+	const unsigned dwave = wave - (unsigned) (WAVES - R1_ROW / 64);
+
+	// per-wave counters of the tile histogram: they borrow the head of the stage
+	// (read back before the first split writes the stage)
+	unsigned* s_hist = reinterpret_cast<unsigned*>(s_stage);
+	static_assert(sizeof(E) * TILE >= WAVES * R1_ROW * sizeof(unsigned), "the histogram fits the stage");
+	#pragma unroll
+	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
 
 	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
 	if (tid == 0) {
@@ -201,10 +218,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	const unsigned mask2 = (mask_hi << LB) | mask_lo;
 	const unsigned n32 = (unsigned) n;   // n < 2^31 here
 
-	// ---- load; histogram of the combined digit in per-wave LDS counters ----
-	unsigned* s_hist = s_end;   // [WAVES][256], gone before the first split fills the table of ends
-	#pragma unroll
-	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
+	// ---- load; count the combined digit (LDS adds, not waited for) ----
 	E key[ITEMS];
 	if (full) {
 		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
@@ -216,35 +230,39 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
 	}
-	__syncthreads();
 	if (P.stamps) t1 = __builtin_amdgcn_s_memtime();
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i)
 		if (full || tbase + i < count) atomicAdd(&s_hist[wave * R1_ROW + ((unsigned) (key[i] >> shift) & mask2)], 1u);
-	__syncthreads();
 
-	// ---- publish: the tile's row, and its arrival at the chunk's accumulator ----
-	unsigned h2 = 0;
+	// ---- first local split; between its first two barriers (all counts are in by
+	// then) the digit threads publish the tile's row and its arrival at the chunk ----
+	unsigned h2 = 0, incl2 = 0;
 	clo_u64 old = 0;
-	if (tid < (unsigned) R2) {
-		#pragma unroll
-		for (int w = 0; w < WAVES; ++w) h2 += s_hist[w * R1_ROW + tid];
-		r1_st32(&P.agg[(size_t) tile * R1_ROW + tid], R1_VALID | h2);
-		old = __hip_atomic_fetch_add(&P.cacc[(size_t) c * R1_ROW + tid], (1ull << R1_CNT_SHIFT) | (clo_u64) h2,
-			__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
+	auto publish = [&]() {
+		if (!dwaves) return;
+		if (dthread) {
+			#pragma unroll
+			for (int w = 0; w < WAVES; ++w) h2 += s_hist[w * R1_ROW + dg];
+			r1_st32(&P.agg[(size_t) tile * R1_ROW + dg], R1_VALID | h2);
+			old = __hip_atomic_fetch_add(&P.cacc[(size_t) c * R1_ROW + dg], (1ull << R1_CNT_SHIFT) | (clo_u64) h2,
+				__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		// tile-local start of every combined digit: exclusive scan of the tile's histogram
+		incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
+		if (lane == 63) s_w4[dwave] = incl2;
+	};
+	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase, publish);
 	if (P.stamps) t2 = __builtin_amdgcn_s_memtime();
-	// tile-local start of every combined digit: exclusive scan of the tile's histogram
-	const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
-	if (lane == 63 && wave < 4) s_w4[wave] = incl2;
-
-	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
 
 	unsigned dstart2 = 0;
-	if (tid < (unsigned) R2) {
+	unsigned early[R1_EARLY > 0 ? R1_EARLY : 1];   // early[0]: prefix of the previous chunk; early[k]: row of tile - k (R1_VALID | count)
+	#pragma unroll
+	for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) early[k] = R1_VALID;
+	if (dthread) {
 		dstart2 = incl2 - h2;
 		#pragma unroll
-		for (unsigned w = 0; w < 4; ++w) if (w < wave) dstart2 += s_w4[w];
+		for (unsigned w = 0; w < 4; ++w) if (w < dwave) dstart2 += s_w4[w];
 		// ---- level 2, by whichever tile completed (chunk, digit): look back over the
 		// earlier chunks, a window at a time, and publish the chunk's inclusive prefix ----
 		if ((unsigned) (old >> R1_CNT_SHIFT) == in_chunk - 1u) {
@@ -259,8 +277,8 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 				for (int w = 0; w < R1_WINDOW; ++w) {
 					pv[w] = 0; av[w] = 0;
 					if (j - w >= 0) {
-						pv[w] = r1_ld32(&P.cprefix[(size_t) (j - w) * R1_ROW + tid]);
-						av[w] = clo_ld_agent(&P.cacc[(size_t) (j - w) * R1_ROW + tid]);
+						pv[w] = r1_ld32(&P.cprefix[(size_t) (j - w) * R1_ROW + dg]);
+						av[w] = clo_ld_agent(&P.cacc[(size_t) (j - w) * R1_ROW + dg]);
 					}
 				}
 				bool closed = false, stalled = false;
@@ -279,7 +297,15 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 					__builtin_amdgcn_s_sleep(2);
 				}
 			}
-			r1_st32(&P.cprefix[(size_t) c * R1_ROW + tid], R1_VALID | (unsigned) (excl + total));
+			r1_st32(&P.cprefix[(size_t) c * R1_ROW + dg], R1_VALID | (unsigned) (excl + total));
+		}
+		// ---- the nearest rows of level 1 and the previous chunk's prefix are requested
+		// now: their round trip runs under the second split ----
+		#pragma unroll
+		for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) {
+			const bool want = k == 0 ? c > 0 : k <= q;
+			if (want) early[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + dg])
+			                            : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + dg]);
 		}
 	}
 	if (P.stamps) t3 = __builtin_amdgcn_s_memtime();
@@ -303,19 +329,19 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	if (P.stamps) t4 = __builtin_amdgcn_s_memtime();
 
 	// ---- the tile's prefix: level 1 (earlier tiles of the chunk) + the prefix of the chunk before ----
-	if (tid < (unsigned) R2) {
-		unsigned v[R1_CHUNK];   // v[0]: prefix of the previous chunk; v[k]: row of tile - k
+	if (dthread) {
+		unsigned v[R1_CHUNK];
 		#pragma unroll
-		for (unsigned k = 0; k < R1_CHUNK; ++k) v[k] = R1_VALID;
+		for (unsigned k = 0; k < R1_CHUNK; ++k) v[k] = k < (unsigned) R1_EARLY ? early[k] : 0u;
 		unsigned spins = 0;
-		for (bool first = true; ; first = false) {
+		for (;;) {
 			#pragma unroll
 			for (unsigned k = 0; k < R1_CHUNK; ++k) {
 				const bool want = k == 0 ? c > 0 : k <= q;
-				if (want && (first || !(v[k] & R1_VALID))) {
-					v[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + tid])
-					              : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + tid]);
-				}
+				if (!want) v[k] = R1_VALID;
+				else if (!(v[k] & R1_VALID))
+					v[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + dg])
+					              : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + dg]);
 			}
 			bool all = true;
 			#pragma unroll
@@ -327,7 +353,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		unsigned excl = 0;
 		#pragma unroll
 		for (unsigned k = 0; k < R1_CHUNK; ++k) excl += v[k] & ~R1_VALID;
-		s_delta[tid] = P.gbase[tid] + excl - dstart2;
+		s_delta[dg] = P.gbase[dg] + excl - dstart2;
 	}
 	__syncthreads();
 	if (P.stamps) t5 = __builtin_amdgcn_s_memtime();
@@ -425,6 +451,8 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const clo_keyx kx_none = { 0, 0, 0 };
 	unsigned max_spins = CLO_MAX_SPINS;
 	if (const char* m = getenv("CLO_MAX_SPINS")) max_spins = (unsigned) strtoul(m, nullptr, 10);
+	int early = 8;   // (CLO_R1_EARLY: A/B measurements)
+	if (const char* m = getenv("CLO_R1_EARLY")) early = atoi(m);
 
 	// everything the passes publish or count in starts from zero
 	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
@@ -460,9 +488,11 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		P.tiles = tiles;
 		P.max_spins = max_spins;
 		clo_timing_scope timing("radix_sweep", s);
-		hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s,
-			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P,
-			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
+		#define CLO_R1_SWEEP(EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, EARLY>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s, \
+			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P, \
+			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none)
+		if (early == 0) CLO_R1_SWEEP(0); else if (early <= 4) CLO_R1_SWEEP(4); else CLO_R1_SWEEP(8);
+		#undef CLO_R1_SWEEP
 		cur_in = cur_out;
 	}
 	e = hipGetLastError();

@@ -173,33 +173,34 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 // sort costs a dozen dependent launches however small the array). One local
 // split per digit, the tile stays in LDS / registers in between.
 // ---------------------------------------------------------------------------
-constexpr int SMALL_THREADS = 512;
-constexpr int SMALL_ITEMS = 8;
-constexpr int SMALL_TILE = SMALL_THREADS * SMALL_ITEMS;
+// Two shapes: 512 threads x 8 elements (up to 4096 elements) and 1024 x 16 (1024
+// x 8 for 8-byte elements: a 64 KiB stage either way) for up to 16384 / 8192.
+constexpr int SMALL_TILE = 512 * 8;
+template <typename E> struct small_big { static constexpr int THREADS = 1024, ITEMS = sizeof(E) == 8 ? 8 : 16, TILE = THREADS * ITEMS; };
 
-template <typename E, int BITS>
-__global__ __launch_bounds__(SMALL_THREADS)
+template <typename E, int BITS, int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS)
 void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift, unsigned key_bits, clo_keyx kx) {
 	constexpr int H = pc_words<BITS>::H;
-	constexpr int WAVES = SMALL_THREADS / 64;
-	__shared__ E s_stage[SMALL_TILE];
-	__shared__ unsigned s_end[SMALL_THREADS * PC_END_STRIDE];
+	constexpr int WAVES = THREADS / 64;
+	__shared__ E s_stage[THREADS * ITEMS];
+	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][H];
 	__shared__ unsigned s_wbase[WAVES][H];
 
-	const unsigned tbase = threadIdx.x * SMALL_ITEMS;
-	E key[SMALL_ITEMS];
+	const unsigned tbase = threadIdx.x * ITEMS;
+	E key[ITEMS];
 	#pragma unroll
-	for (int i = 0; i < SMALL_ITEMS; ++i) key[i] = (tbase + i < n) ? clo_keyx_fwd<E>(in[tbase + i], kx) : (E) 0;
+	for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < n) ? clo_keyx_fwd<E>(in[tbase + i], kx) : (E) 0;
 	for (unsigned done = 0; done < key_bits; done += BITS) {
 		const unsigned bits = key_bits - done < (unsigned) BITS ? key_bits - done : (unsigned) BITS;
-		pc_local_split<E, BITS, SMALL_THREADS, SMALL_ITEMS, H>(key, key_shift + done, (1u << bits) - 1u, n,
+		pc_local_split<E, BITS, THREADS, ITEMS, H>(key, key_shift + done, (1u << bits) - 1u, n,
 			s_stage, s_end, s_wtot, s_wbase);
 		#pragma unroll
-		for (int i = 0; i < SMALL_ITEMS; ++i) if (tbase + i < n) key[i] = s_stage[tbase + i];
+		for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) key[i] = s_stage[tbase + i];
 	}
 	#pragma unroll
-	for (int i = 0; i < SMALL_ITEMS; ++i) if (tbase + i < n) out[tbase + i] = clo_keyx_inv<E>(key[i], kx);
+	for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) out[tbase + i] = clo_keyx_inv<E>(key[i], kx);
 }
 
 // ---------------------------------------------------------------------------
@@ -346,8 +347,14 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 template <typename E>
 int small_dispatch(const void* src, void* dst, size_t n, int key_shift, int key_bits, int digit_bits, clo_keyx kx, hipStream_t s) {
 	clo_timing_scope timing("radix_small", s);
-	#define CLO_SMALL(B) case B: hipLaunchKernelGGL((clo_radix4_small_kernel<E, B>), dim3(1), dim3(SMALL_THREADS), 0, s, \
-		(const E*) src, (E*) dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx); break
+	#define CLO_SMALL(B) case B: \
+		if (n <= (size_t) SMALL_TILE) \
+			hipLaunchKernelGGL((clo_radix4_small_kernel<E, B, 512, 8>), dim3(1), dim3(512), 0, s, \
+				(const E*) src, (E*) dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx); \
+		else \
+			hipLaunchKernelGGL((clo_radix4_small_kernel<E, B, small_big<E>::THREADS, small_big<E>::ITEMS>), dim3(1), dim3(small_big<E>::THREADS), 0, s, \
+				(const E*) src, (E*) dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx); \
+		break
 	switch (digit_bits) {
 		CLO_SMALL(1); CLO_SMALL(2); CLO_SMALL(3); CLO_SMALL(4);
 		default: return CLO_HIP_EUNSUPPORTED;
@@ -402,7 +409,8 @@ size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
 
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
 	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s) {
-	if (n <= (size_t) SMALL_TILE && digit_bits <= 4) {   // one launch for the whole sort
+	const size_t small_max = elem_size == 8 ? (size_t) small_big<uint64_t>::TILE : (size_t) small_big<uint32_t>::TILE;
+	if (n <= small_max && digit_bits <= 4) {   // one launch for the whole sort
 		switch (elem_size) {
 			case 1: return small_dispatch<uint8_t>(src, dst, n, key_shift, key_bits, digit_bits, kx, s);
 			case 2: return small_dispatch<uint16_t>(src, dst, n, key_shift, key_bits, digit_bits, kx, s);

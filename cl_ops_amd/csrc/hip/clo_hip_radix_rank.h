@@ -98,9 +98,14 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned lon
 // One stable local split of the tile by the digit (key >> dshift) & dmask;
 // on return (after a barrier) s_stage holds the tile in digit order. The
 // thread's elements are ITEMS consecutive positions of the tile.
-template <typename E, int BITS, int THREADS, int ITEMS, int HMAX>
+// `mid`: work placed between the first two barriers, where only wave 0 is busy
+// (it turns the wave totals into wave bases) — every thread calls it, it picks
+// its own waves; it must not touch s_wtot / s_wbase / s_end.
+struct pc_no_mid { __device__ __forceinline__ void operator()() const {} };
+
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid>
 __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
-	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX]) {
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid = Mid()) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -183,6 +188,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 			if (j < (unsigned) H && wv < (unsigned) WAVES) s_wbase[wv][j] = mine + excl[r];
 		}
 	}
+	mid();
 	__syncthreads();
 	#pragma unroll
 	// the thread's 16-bit ends, thread-major with a stride of PC_END_STRIDE dwords

@@ -30,3 +30,30 @@ class NumpyLocalOps:
         import oracle_lib as O
         v = self._view(t, n)
         v[:] = O.stable_sort(v.copy())
+
+
+def host_staged_sorter_class():
+    """ShardedSorter whose all-to-all goes through host memory over gloo: for tests that put
+    two ranks on ONE GPU (RCCL refuses two ranks on one device). Everything else — partition,
+    count exchange plan, local sort — is the product path."""
+    import torch
+    import torch.distributed as dist
+    from cl_ops_amd.multigpu import ShardedSorter
+
+    class HostStaged(ShardedSorter):
+        def exchange(self, send, recv, sc, so, rc, ro):
+            hs, hr = send.cpu(), torch.empty(recv.numel(), dtype=recv.dtype)
+            r = self.rank
+            hr[ro[r]:ro[r] + rc[r]] = hs[so[r]:so[r] + sc[r]]
+            ops = []
+            for k in range(1, self.world):
+                dst, src = (r + k) % self.world, (r - k) % self.world
+                if sc[dst] > 0:
+                    ops.append(dist.P2POp(dist.isend, hs[so[dst]:so[dst] + sc[dst]].contiguous(), dst))
+                if rc[src] > 0:
+                    ops.append(dist.P2POp(dist.irecv, hr[ro[src]:ro[src] + rc[src]], src))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            recv.copy_(hr)
+
+    return HostStaged

@@ -242,3 +242,72 @@ def test_full_size_satradix_u64_2p28_shard_of_config_5(gpu):
     assert torch.equal(before, dst)
     for x in (s, bsrc, bdst):
         x.close()
+
+
+# ----------------------------------------------------------------------------
+# two ranks on the one GPU of this box, config 5's element type at scale, skewed
+# ----------------------------------------------------------------------------
+
+def _skewed_u64_worker(rank, world, port, log2n, out_dir):
+    import torch
+    import torch.distributed as dist
+    from cl_ops_amd.multigpu import HipLocalOps
+    from numpy_ops import host_staged_sorter_class
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n = 1 << log2n
+        rng = np.random.default_rng(500 + rank)
+        a = rng.integers(0, np.iinfo(np.uint64).max, n, dtype=np.uint64, endpoint=True)
+        # 85 % of BOTH ranks' keys get the top bit set: rank 1 receives ~1.7 n keys,
+        # more than capacity_factor (1.25) provides for -> the count-exact reallocation
+        force = rng.random(n) < 0.7
+        a[force] |= np.uint64(1) << np.uint64(63)
+        local = torch.from_numpy(a.view(np.int64)).cuda()
+        ops = HipLocalOps("ulong", 0)
+        ss = host_staged_sorter_class()(ops)
+        out, m = ss.sort(local, n)
+        torch.cuda.synchronize()
+        got = out[:m].cpu().numpy().view(np.uint64)
+        ok_sorted = bool(np.all(got[:-1] <= got[1:]))
+        ok_bucket = bool(np.all((got >> np.uint64(63)) == rank))
+        stats = np.array([m, int(got.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(got)),
+                          int(a.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(a)),
+                          int(ok_sorted), int(ok_bucket), int(m > int(n * ss.capacity_factor) + 1024)], dtype=np.uint64)
+        np.save(os.path.join(out_dir, "stats_%d.npy" % rank), stats)
+        # exact check of one slice by value: keys whose top 16 bits are (rank << 15) | 0x1234
+        top = np.uint64((rank << 15) | 0x1234)
+        np.save(os.path.join(out_dir, "slice_in_%d.npy" % rank), a[(a >> np.uint64(48)) == top])
+        np.save(os.path.join(out_dir, "slice_out_%d.npy" % rank), got[(got >> np.uint64(48)) == top])
+        other = np.uint64(((1 - rank) << 15) | 0x1234)
+        np.save(os.path.join(out_dir, "slice_for_peer_%d.npy" % rank), a[(a >> np.uint64(48)) == other])
+        assert np.array_equal(local.cpu().numpy().view(np.uint64), a)   # the shard is only read
+        ops.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_skewed_u64_2p27_each_on_one_gpu(gpu, tmp_path):
+    """MSD partition -> exchange plan -> local satradix with 2^27 uint64 keys per rank and a
+    bucket that overflows the receive capacity; the all-to-all alone is staged through the
+    host (RCCL refuses two ranks on one device)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    log2n = 27
+    mp.spawn(_skewed_u64_worker, args=(2, port, log2n, str(tmp_path)), nprocs=2, join=True)
+    st = [np.load(tmp_path / ("stats_%d.npy" % r)) for r in range(2)]
+    n = 1 << log2n
+    assert int(st[0][0]) + int(st[1][0]) == 2 * n                                  # nothing lost
+    assert (int(st[0][1]) + int(st[1][1])) % (1 << 64) == (int(st[0][3]) + int(st[1][3])) % (1 << 64)
+    assert int(st[0][2]) ^ int(st[1][2]) == int(st[0][4]) ^ int(st[1][4])
+    assert all(int(s_[5]) == 1 and int(s_[6]) == 1 for s_ in st)                  # sorted, and rank r holds bucket r
+    assert int(st[1][7]) == 1, "the skew did not exceed the receive capacity: %d keys" % int(st[1][0])
+    for r in range(2):
+        exp = np.sort(np.concatenate([np.load(tmp_path / ("slice_in_%d.npy" % r)),
+                                      np.load(tmp_path / ("slice_for_peer_%d.npy" % (1 - r)))]))
+        assert np.array_equal(np.load(tmp_path / ("slice_out_%d.npy" % r)), exp)

@@ -55,12 +55,15 @@ def run(mode, steps=20):
         c, tot = _hip.timing_read(lab)
         if c:
             parts[lab] = round(tot / c, 4)
-    print("sweep=%s  %s 2^%d: %.3f ms/sort  %.0f Mkeys/s  correct=%s  per launch (ms): %s"
-          % (mode, kind, log2n, ms, n / ms / 1e3, ok, parts), flush=True)
+    print("sweep=%s early=%s  %s 2^%d: %.3f ms/sort  %.0f Mkeys/s  correct=%s  per launch (ms): %s"
+          % (mode, os.environ.get("CLO_R1_EARLY", "-"), kind, log2n, ms, n / ms / 1e3, ok, parts), flush=True)
     return s
 
 
 run("0").close()
+os.environ["CLO_R1_EARLY"] = "0"
+run("1").close()
+os.environ["CLO_R1_EARLY"] = "8"
 s = run("1")
 
 # ---- stamps of the last pass's tiles ----
@@ -74,7 +77,7 @@ q.finish()
 lib.clo_hip_radix_debug_stamps(None, 0)
 a = st.cpu().numpy().reshape(tiles, 8)
 t = a[:, :7].astype(np.float64)
-names = ["ticket+load", "hist+publish", "split lo+resolver", "split hi", "look-back wait", "scatter issue"]
+names = ["ticket+load", "counts+split lo+publish", "resolver+early loads", "split hi", "look-back wait", "scatter issue"]
 d = np.diff(t, axis=1)
 clk = 100e6   # s_memtime ticks at the shader clock? printed raw: convert with the kernel's duration below
 life = t[:, 6] - t[:, 0]
