@@ -38,6 +38,9 @@ typedef struct {
 	clo_devbuf tmp;       /* ping-pong partner of the array being sorted */
 	clo_devbuf workspace; /* per-tile histograms, offsets, chunk sums */
 	clo_devbuf pairs;     /* (ordered key, index) pairs of a run-time compiled get_key */
+	clo_status_cell* status;  /* the workspace's status word, for the sorts whose kernels poll (clo_hip_radix_polls) */
+	void* ws_ready;           /* the allocation whose header (status word) has been cleared */
+	size_t ws_ready_bytes;
 	void* last_stream;
 } clo_sort_satradix_data;
 
@@ -107,6 +110,17 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, jit ? numel * 8 : bytes), err, "hipMalloc(satradix aux)")) return NULL;
 		if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws_bytes), err, "hipMalloc(satradix workspace)")) return NULL;
 		if (jit && clo_hip_failed(clo_devbuf_reserve(&data->pairs, numel * 8), err, "hipMalloc(satradix key pairs)")) return NULL;
+		if (data->ws_ready != data->workspace.ptr || data->ws_ready_bytes != data->workspace.bytes) {   /* a fresh allocation: its status word is garbage */
+			if (clo_hip_failed(clo_hip_memset_async(data->workspace.ptr, 0, 512, stream), err, "hipMemsetAsync")) return NULL;
+			data->ws_ready = data->workspace.ptr;
+			data->ws_ready_bytes = data->workspace.bytes;
+		}
+		if (clo_hip_radix_polls(numel, jit ? 8 : ks->elem_size, bits_in_digit)) {
+			/* tile-to-tile look-back inside the passes: a give-up must not pass as success */
+			clo_status_cell_set_word(data->status, data->workspace.ptr);
+			if (clo_status_cell_take_tripped(data->status)) clo_debug("SATRADIX: the previous sort on this sorter gave up a spin");
+			ccl_queue_watch_status(cq_exec, data->status);
+		}
 	}
 
 	/* A profiling queue gets one event per kernel under upstream's names
@@ -195,6 +209,8 @@ static void satradix_free(clo_sort_satradix_data* data) {
 	free(data->scan_type);
 	free(data->scan_opts);
 	if (data->scanner) clo_scan_destroy(data->scanner);
+	clo_status_cell_set_word(data->status, NULL);
+	clo_status_cell_unref(data->status);
 	clo_devbuf_release(&data->tmp);
 	clo_devbuf_release(&data->workspace);
 	clo_devbuf_release(&data->pairs);
@@ -207,6 +223,7 @@ static const char* clo_sort_satradix_init(CloSort* sorter, const char* options, 
 	clo_sort_satradix_data* data = (clo_sort_satradix_data*) calloc(1, sizeof(*data));
 	if (!data) return NULL;
 	data->radix = 16;
+	data->status = clo_status_cell_new(NULL);
 	satradix_opt_ctx c = { data, NULL, 0 };
 	if (!clo_parse_options(options, satradix_option, &c, "satradix", err)) {
 		free(c.scan_opts);

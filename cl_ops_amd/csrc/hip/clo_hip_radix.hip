@@ -70,6 +70,10 @@ size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, 
 	return clo_radix4_workspace_bytes(numel, elem_size, digit_bits, key_bits);
 }
 
+int clo_hip_radix_polls(size_t numel, int elem_size, int digit_bits) {
+	return clo_radix1_applies(numel, elem_size, digit_bits) ? 1 : 0;
+}
+
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits,
 	void* workspace, size_t workspace_bytes, void* stream) {

@@ -46,8 +46,7 @@
 
 namespace {
 
-constexpr int R1_CHUNK_LOG = 4;
-constexpr unsigned R1_CHUNK = 1u << R1_CHUNK_LOG;    // tiles per chunk
+constexpr int R1_CHUNK_LOG_DEFAULT = 4;              // 16 tiles per chunk (a template parameter of the sweep kernel)
 constexpr int R1_WINDOW = 8;                         // chunks a level-2 hop inspects
 constexpr unsigned R1_VALID = 0x80000000u;            // 32-bit entries: bit 31 = written, bits 30..0 = count
 constexpr int R1_CNT_SHIFT = 40;                      // 64-bit accumulators: arrivals << 40 | sum
@@ -150,7 +149,7 @@ struct r1_pass {
 
 // R1_EARLY: level-1 entries (the previous chunk's prefix + the nearest rows) requested
 // before the second split, so that their round trip runs under it.
-template <typename E, int LB, int HB, int R1_EARLY>
+template <typename E, int LB, int HB, int R1_CHUNK_LOG, int R1_EARLY>
 __global__ __launch_bounds__(pair_shape<E>::THREADS, 6)
 void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi, r1_pass P, int aligned, clo_keyx kx_in, clo_keyx kx_out) {
@@ -161,6 +160,8 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	constexpr int WAVES = THREADS / 64;
 	constexpr int R2 = 1 << (LB + HB);
 	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
+	constexpr unsigned R1_CHUNK = 1u << R1_CHUNK_LOG;    // tiles per chunk
+	static_assert(R1_EARLY <= (int) R1_CHUNK, "at most the whole level 1");
 	static_assert(R2 <= R1_ROW && R2 <= THREADS, "one thread per combined digit");
 	static_assert(THREADS >= 2 * R1_ROW, "the digit threads are the second half of the work-group");
 
@@ -206,7 +207,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		}
 		s_tile = tile;
 	}
-	__syncthreads();
+	clo_lds_barrier();
 	const unsigned tile = s_tile;
 	if (tile == 0xffffffffu) return;   // (cannot happen: as many work-groups as tiles, one valid ticket each)
 	const unsigned c = tile >> R1_CHUNK_LOG, q = tile & (R1_CHUNK - 1u);
@@ -355,7 +356,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		for (unsigned k = 0; k < R1_CHUNK; ++k) excl += v[k] & ~R1_VALID;
 		s_delta[dg] = P.gbase[dg] + excl - dstart2;
 	}
-	__syncthreads();
+	clo_lds_barrier();
 	if (P.stamps) t5 = __builtin_amdgcn_s_memtime();
 
 	// ---- contiguous runs to HBM (as the pair kernel of clo_hip_radix4.hip) ----
@@ -407,12 +408,18 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 // ---------------------------------------------------------------------------
 struct r1_layout { size_t ghist, gbase, tickets, pass0, per_pass, agg, cacc, cprefix, total, tiles, chunks; int passes; };
 
+int r1_chunk_log() {   // CLO_R1_CHUNK_LOG: 3 or 4 (A/B measurements)
+	const char* m = getenv("CLO_R1_CHUNK_LOG");
+	const int v = m ? atoi(m) : R1_CHUNK_LOG_DEFAULT;
+	return v == 3 ? 3 : 4;
+}
+
 r1_layout r1_make_layout(size_t n, int elem_size, int key_bits) {
 	r1_layout L;
 	const size_t tile = (size_t) 512 * (elem_size == 8 ? 8 : 16);
 	L.tiles = (n + tile - 1) / tile;
 	if (L.tiles == 0) L.tiles = 1;
-	L.chunks = (L.tiles + R1_CHUNK - 1) / R1_CHUNK;
+	L.chunks = (L.tiles + 7) / 8;   // (sized for the smaller chunk)
 	L.passes = (key_bits + 7) / 8;
 	size_t off = 0;
 	L.ghist = off; off += (size_t) L.passes * R1_ROW * sizeof(unsigned);
@@ -451,6 +458,7 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const clo_keyx kx_none = { 0, 0, 0 };
 	unsigned max_spins = CLO_MAX_SPINS;
 	if (const char* m = getenv("CLO_MAX_SPINS")) max_spins = (unsigned) strtoul(m, nullptr, 10);
+	const int chunk_log = r1_chunk_log();
 	int early = 8;   // (CLO_R1_EARLY: A/B measurements)
 	if (const char* m = getenv("CLO_R1_EARLY")) early = atoi(m);
 
@@ -488,10 +496,10 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		P.tiles = tiles;
 		P.max_spins = max_spins;
 		clo_timing_scope timing("radix_sweep", s);
-		#define CLO_R1_SWEEP(EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, EARLY>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s, \
+		#define CLO_R1_SWEEP(CL, EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL, EARLY>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s, \
 			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P, \
 			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none)
-		if (early == 0) CLO_R1_SWEEP(0); else if (early <= 4) CLO_R1_SWEEP(4); else CLO_R1_SWEEP(8);
+		if (chunk_log == 3) CLO_R1_SWEEP(3, 8); else if (early == 0) CLO_R1_SWEEP(4, 0); else CLO_R1_SWEEP(4, 8);
 		#undef CLO_R1_SWEEP
 		cur_in = cur_out;
 	}

@@ -11,6 +11,15 @@
 
 namespace {
 
+// Work-group barrier that orders LDS traffic only: global loads requested before
+// it stay in flight across it (a __syncthreads() makes every wave wait for ALL its
+// outstanding memory operations first; the splits below exchange nothing but LDS).
+__device__ __forceinline__ void clo_lds_barrier() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---------------------------------------------------------------------------
 // Ranking with thread-private packed counters.
 //
@@ -149,7 +158,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		#pragma unroll
 		for (int j = 0; j < H; ++j) s_wtot[wave][j] = w[j];
 	}
-	__syncthreads();
+	clo_lds_barrier();
 	if (wave == 0) {
 		// Wave 0 turns the wave totals into every wave's base, per digit: lane
 		// (q, wv) = (lane / 16, lane % 16) takes word 4r + q of wave wv; a DPP scan
@@ -189,7 +198,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		}
 	}
 	mid();
-	__syncthreads();
+	clo_lds_barrier();
 	#pragma unroll
 	// the thread's 16-bit ends, thread-major with a stride of PC_END_STRIDE dwords
 	// (odd: the lanes' rows start in different banks): the lookup per element is
@@ -205,7 +214,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 			s_stage[end - back] = key[i];   // (counts of these very elements: always inside the tile)
 		}
 	}
-	__syncthreads();
+	clo_lds_barrier();
 }
 
 // Shape of a tile of the pass kernels: 512 threads x 16 consecutive elements

@@ -134,6 +134,11 @@ int clo_hip_reduce_sum(const void* data_in, size_t numel, int elem_size, int ele
  * size. dst may equal src (in place); tmp must be distinct from both. src is
  * left untouched when dst != src. Asynchronous on `stream`. */
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits);
+/* 1 if the kernels of such a sort wait for other work-groups (the single-sweep
+ * passes hand digit counts from tile to tile; every spin is bounded and a give-up
+ * raises the workspace's status word: clo_hip_check_status), 0 if none does (the
+ * chain-free passes). */
+int clo_hip_radix_polls(size_t numel, int elem_size, int digit_bits);
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits,
 	void* workspace, size_t workspace_bytes, void* stream);
@@ -214,7 +219,9 @@ int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs
  * check it wherever they synchronise anyway (clo_scan_with_host_data,
  * ccl_queue_finish, ccl_event_wait). Meaningful for the workspaces of the scan
  * and of clo_hip_msd_partition (always 0 there: no kernel of the sorts waits on
- * another work-group); clo_hip_radix_sort leaves the word untouched. */
+ * another work-group) and of clo_hip_radix_sort when clo_hip_radix_polls() says
+ * its kernels poll — the caller clears the first 512 bytes of that workspace once
+ * after allocating it, the sorts never clear the word themselves. */
 int clo_hip_check_status(void* workspace, void* stream);
 
 /* ---- launch observer: per-kernel events for profiling queues ----

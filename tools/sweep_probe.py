@@ -55,16 +55,18 @@ def run(mode, steps=20):
         c, tot = _hip.timing_read(lab)
         if c:
             parts[lab] = round(tot / c, 4)
-    print("sweep=%s early=%s  %s 2^%d: %.3f ms/sort  %.0f Mkeys/s  correct=%s  per launch (ms): %s"
-          % (mode, os.environ.get("CLO_R1_EARLY", "-"), kind, log2n, ms, n / ms / 1e3, ok, parts), flush=True)
+    print("sweep=%s chunk_log=%s early=%s  %s 2^%d: %.3f ms/sort  %.0f Mkeys/s  correct=%s  per launch (ms): %s"
+          % (mode, os.environ.get("CLO_R1_CHUNK_LOG", "-"), os.environ.get("CLO_R1_EARLY", "-"), kind, log2n, ms, n / ms / 1e3, ok, parts), flush=True)
     return s
 
 
 run("0").close()
-os.environ["CLO_R1_EARLY"] = "0"
-run("1").close()
-os.environ["CLO_R1_EARLY"] = "8"
-s = run("1")
+for cl, early in (("4", "0"), ("3", "8"), ("4", "8")):
+    os.environ["CLO_R1_EARLY"] = early
+    os.environ["CLO_R1_CHUNK_LOG"] = cl
+    s = run("1")
+    if (cl, early) != ("4", "8"):
+        s.close()
 
 # ---- stamps of the last pass's tiles ----
 lib.clo_hip_radix_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
