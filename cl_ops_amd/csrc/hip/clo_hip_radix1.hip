@@ -185,12 +185,21 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	const bool dwaves = wave >= (unsigned) (WAVES - R1_ROW / 64);
 	const unsigned dwave = wave - (unsigned) (WAVES - R1_ROW / 64);
 
-	// per-wave counters of the tile histogram: they borrow the head of the stage
-	// (read back before the first split writes the stage)
+	// Counters of the tile histogram: they borrow the stage (read back before the
+	// first split writes it). 32 copies of every bin, copy = lane mod 32, laid out
+	// bin-major: the 32 lanes an LDS instruction serves together hit 32 different
+	// banks and never the same address — an LDS add occupies its bank for many
+	// cycles, and with one copy per wave (lanes colliding on banks ~3.5 deep) the
+	// adds alone cost a quarter of a tile's life.
 	unsigned* s_hist = reinterpret_cast<unsigned*>(s_stage);
-	static_assert(sizeof(E) * TILE >= WAVES * R1_ROW * sizeof(unsigned), "the histogram fits the stage");
-	#pragma unroll
-	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
+	constexpr int HCOPIES = 32;
+	static_assert(sizeof(E) * TILE >= R1_ROW * HCOPIES * sizeof(unsigned), "the histogram fits the stage");
+	{
+		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+		const vec4u z = { 0u, 0u, 0u, 0u };
+		#pragma unroll
+		for (int k = 0; k < R1_ROW * HCOPIES / 4 / THREADS; ++k) reinterpret_cast<vec4u*>(s_hist)[k * THREADS + tid] = z;
+	}
 
 	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
 	if (tid == 0) {
@@ -234,7 +243,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	if (P.stamps) t1 = __builtin_amdgcn_s_memtime();
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i)
-		if (full || tbase + i < count) atomicAdd(&s_hist[wave * R1_ROW + ((unsigned) (key[i] >> shift) & mask2)], 1u);
+		if (full || tbase + i < count) atomicAdd(&s_hist[(((unsigned) (key[i] >> shift) & mask2) << 5) + (lane & 31u)], 1u);
 
 	// ---- first local split; between its first two barriers (all counts are in by
 	// then) the digit threads publish the tile's row and its arrival at the chunk ----
@@ -243,8 +252,14 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	auto publish = [&]() {
 		if (!dwaves) return;
 		if (dthread) {
+			typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+			const vec4u* row = reinterpret_cast<const vec4u*>(s_hist + (dg << 5));
 			#pragma unroll
-			for (int w = 0; w < WAVES; ++w) h2 += s_hist[w * R1_ROW + dg];
+			for (int k = 0; k < HCOPIES / 4; ++k) {   // (rotated: the lanes' rows are 128 bytes apart)
+				const vec4u x = row[(k + dg) & (HCOPIES / 4 - 1)];
+				h2 += x[0] + x[1] + x[2] + x[3];
+				if (k == HCOPIES / 8 - 1) __builtin_amdgcn_sched_barrier(0);   // (two batches of reads: 16 live registers, not 32)
+			}
 			r1_st32(&P.agg[(size_t) tile * R1_ROW + dg], R1_VALID | h2);
 			old = __hip_atomic_fetch_add(&P.cacc[(size_t) c * R1_ROW + dg], (1ull << R1_CNT_SHIFT) | (clo_u64) h2,
 				__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -300,14 +315,6 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 			}
 			r1_st32(&P.cprefix[(size_t) c * R1_ROW + dg], R1_VALID | (unsigned) (excl + total));
 		}
-		// ---- the nearest rows of level 1 and the previous chunk's prefix are requested
-		// now: their round trip runs under the second split ----
-		#pragma unroll
-		for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) {
-			const bool want = k == 0 ? c > 0 : k <= q;
-			if (want) early[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + dg])
-			                            : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + dg]);
-		}
 	}
 	if (P.stamps) t3 = __builtin_amdgcn_s_memtime();
 
@@ -325,7 +332,21 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 			#pragma unroll
 			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
 		}
-		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase);
+		// The nearest rows of level 1 and the previous chunk's prefix are requested from
+		// INSIDE the second split (its idle slot for the digit waves): late enough for
+		// rows published a moment ago to have become visible (a store takes 1-2 us to
+		// show, and the tile before this one is only ~0.2 us ahead), early enough for
+		// the round trip (~2.5 us) to run under the rest of the split.
+		auto request = [&]() {
+			if (!dthread) return;
+			#pragma unroll
+			for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) {
+				const bool want = k == 0 ? c > 0 : k <= q;
+				if (want) early[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + dg])
+				                            : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + dg]);
+			}
+		};
+		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase, request);
 	}
 	if (P.stamps) t4 = __builtin_amdgcn_s_memtime();
 
