@@ -55,7 +55,6 @@ constexpr int R1_ROW = 256;                           // counters per tile / chu
 constexpr int R1_POOLS = 8;
 constexpr int R1_TICKET_STRIDE = 16;                  // words between the pools' ticket counters (one 64-byte line each)
 constexpr int R1_GH_THREADS = 512;
-constexpr int R1_GH_COPIES = 8;
 
 __device__ __forceinline__ unsigned r1_ld32(const unsigned* p) {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -78,9 +77,14 @@ void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_sh
 	unsigned* __restrict__ ghist, int aligned, clo_keyx kx, unsigned tiles_per_group) {
 	constexpr int ITEMS = pair_shape<E>::ITEMS;
 	constexpr int TILE = R1_GH_THREADS * ITEMS;
-	__shared__ unsigned s_cnt[R1_GH_COPIES][NP][R1_ROW];
-	const unsigned tid = threadIdx.x, copy = (tid >> 6) & (R1_GH_COPIES - 1);
-	for (unsigned i = tid; i < R1_GH_COPIES * NP * R1_ROW; i += R1_GH_THREADS) (&s_cnt[0][0][0])[i] = 0;
+	// Counters: 16-bit, two digits per dword, COPIES copies of every dword (copy = lane
+	// mod COPIES, dword-major): with 32 copies the 32 lanes an LDS instruction serves
+	// together never share a bank (see the sweep kernel). A work-group counts at most
+	// 16 tiles before it flushes: <= 8192 keys per copy, so 16 bits hold any count.
+	constexpr int COPIES = NP <= 4 ? 32 : 16;   // 16 KiB (8 KiB) of LDS per pass
+	__shared__ unsigned s_cnt[NP * (R1_ROW / 2) * COPIES];
+	const unsigned tid = threadIdx.x, cp = tid & (COPIES - 1);
+	for (unsigned i = tid; i < (unsigned) (NP * (R1_ROW / 2) * COPIES); i += R1_GH_THREADS) s_cnt[i] = 0;
 	__syncthreads();
 	const unsigned last_bits = key_bits - 8u * (NP - 1);
 	const unsigned last_mask = (1u << last_bits) - 1u;
@@ -104,17 +108,22 @@ void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_sh
 				#pragma unroll
 				for (int p = 0; p < NP; ++p) {
 					const unsigned d = (unsigned) (k >> (8 * p)) & (p == NP - 1 ? last_mask : 255u);
-					atomicAdd(&s_cnt[copy][p][d], 1u);
+					atomicAdd(&s_cnt[((unsigned) p * (R1_ROW / 2) + (d >> 1)) * COPIES + cp], 1u << ((d & 1u) * 16u));
 				}
 			}
 		}
 	}
 	__syncthreads();
-	for (unsigned i = tid; i < NP * R1_ROW; i += R1_GH_THREADS) {
-		unsigned v = 0;
+	for (unsigned i = tid; i < (unsigned) (NP * R1_ROW / 2); i += R1_GH_THREADS) {   // i: (pass, digit pair)
+		unsigned even = 0, odd = 0;
 		#pragma unroll
-		for (int c = 0; c < R1_GH_COPIES; ++c) v += (&s_cnt[c][0][0])[i];
-		if (v) atomicAdd(&ghist[i], v);
+		for (int c = 0; c < COPIES; ++c) {
+			const unsigned x = s_cnt[i * COPIES + ((c + i) & (COPIES - 1))];   // (rotated: rows are whole bank rounds apart)
+			even += x & 0xffffu;
+			odd += x >> 16;
+		}
+		if (even) atomicAdd(&ghist[2 * i], even);
+		if (odd) atomicAdd(&ghist[2 * i + 1], odd);
 	}
 }
 
@@ -185,21 +194,15 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	const bool dwaves = wave >= (unsigned) (WAVES - R1_ROW / 64);
 	const unsigned dwave = wave - (unsigned) (WAVES - R1_ROW / 64);
 
-	// Counters of the tile histogram: they borrow the stage (read back before the
-	// first split writes it). 32 copies of every bin, copy = lane mod 32, laid out
-	// bin-major: the 32 lanes an LDS instruction serves together hit 32 different
-	// banks and never the same address — an LDS add occupies its bank for many
-	// cycles, and with one copy per wave (lanes colliding on banks ~3.5 deep) the
-	// adds alone cost a quarter of a tile's life.
+	// per-wave counters of the tile histogram: they borrow the head of the stage
+	// (read back before the first split writes the stage). 32 bank-private copies of
+	// every bin (no two lanes of an LDS instruction on one bank) measured SLOWER
+	// (13 470 vs 12 600 ticks for counting + first split): the LDS add unit itself,
+	// ~2 lanes per clock, is the limit, not its bank conflicts.
 	unsigned* s_hist = reinterpret_cast<unsigned*>(s_stage);
-	constexpr int HCOPIES = 32;
-	static_assert(sizeof(E) * TILE >= R1_ROW * HCOPIES * sizeof(unsigned), "the histogram fits the stage");
-	{
-		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
-		const vec4u z = { 0u, 0u, 0u, 0u };
-		#pragma unroll
-		for (int k = 0; k < R1_ROW * HCOPIES / 4 / THREADS; ++k) reinterpret_cast<vec4u*>(s_hist)[k * THREADS + tid] = z;
-	}
+	static_assert(sizeof(E) * TILE >= WAVES * R1_ROW * sizeof(unsigned), "the histogram fits the stage");
+	#pragma unroll
+	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
 
 	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
 	if (tid == 0) {
@@ -243,7 +246,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	if (P.stamps) t1 = __builtin_amdgcn_s_memtime();
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i)
-		if (full || tbase + i < count) atomicAdd(&s_hist[(((unsigned) (key[i] >> shift) & mask2) << 5) + (lane & 31u)], 1u);
+		if (full || tbase + i < count) atomicAdd(&s_hist[wave * R1_ROW + ((unsigned) (key[i] >> shift) & mask2)], 1u);
 
 	// ---- first local split; between its first two barriers (all counts are in by
 	// then) the digit threads publish the tile's row and its arrival at the chunk ----
@@ -252,14 +255,8 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	auto publish = [&]() {
 		if (!dwaves) return;
 		if (dthread) {
-			typedef unsigned vec4u __attribute__((ext_vector_type(4)));
-			const vec4u* row = reinterpret_cast<const vec4u*>(s_hist + (dg << 5));
 			#pragma unroll
-			for (int k = 0; k < HCOPIES / 4; ++k) {   // (rotated: the lanes' rows are 128 bytes apart)
-				const vec4u x = row[(k + dg) & (HCOPIES / 4 - 1)];
-				h2 += x[0] + x[1] + x[2] + x[3];
-				if (k == HCOPIES / 8 - 1) __builtin_amdgcn_sched_barrier(0);   // (two batches of reads: 16 live registers, not 32)
-			}
+			for (int w = 0; w < WAVES; ++w) h2 += s_hist[w * R1_ROW + dg];
 			r1_st32(&P.agg[(size_t) tile * R1_ROW + dg], R1_VALID | h2);
 			old = __hip_atomic_fetch_add(&P.cacc[(size_t) c * R1_ROW + dg], (1ull << R1_CNT_SHIFT) | (clo_u64) h2,
 				__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -342,8 +339,9 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 			#pragma unroll
 			for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) {
 				const bool want = k == 0 ? c > 0 : k <= q;
-				if (want) early[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + dg])
-				                            : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + dg]);
+				const unsigned* a = !want ? &P.agg[(size_t) tile * R1_ROW + dg]   // (own row: valid, ignored)
+					: (k == 0 ? &P.cprefix[(size_t) (c - 1) * R1_ROW + dg] : &P.agg[(size_t) (tile - k) * R1_ROW + dg]);
+				early[k] = r1_ld32(a);
 			}
 		};
 		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase, request);
@@ -352,25 +350,38 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 
 	// ---- the tile's prefix: level 1 (earlier tiles of the chunk) + the prefix of the chunk before ----
 	if (dthread) {
+		// Entry k: 0 = the previous chunk's inclusive prefix, k >= 1 = the row of tile - k.
+		// Entries this tile does not need read its OWN row instead (published long
+		// ago, so valid) and count as zero: every load of a round is then unconditional
+		// and the compiler issues the round as one batch — with a branch around each
+		// load it waited for each before issuing the next, a round trip apiece.
+		const unsigned* addr[R1_CHUNK];
 		unsigned v[R1_CHUNK];
 		#pragma unroll
-		for (unsigned k = 0; k < R1_CHUNK; ++k) v[k] = k < (unsigned) R1_EARLY ? early[k] : 0u;
+		for (unsigned k = 0; k < R1_CHUNK; ++k) {
+			const bool want = k == 0 ? c > 0 : k <= q;
+			addr[k] = !want ? &P.agg[(size_t) tile * R1_ROW + dg]
+				: (k == 0 ? &P.cprefix[(size_t) (c - 1) * R1_ROW + dg] : &P.agg[(size_t) (tile - k) * R1_ROW + dg]);
+			v[k] = k < (unsigned) R1_EARLY ? early[k] : (want ? 0u : R1_VALID);
+		}
 		unsigned spins = 0;
 		for (;;) {
-			#pragma unroll
-			for (unsigned k = 0; k < R1_CHUNK; ++k) {
-				const bool want = k == 0 ? c > 0 : k <= q;
-				if (!want) v[k] = R1_VALID;
-				else if (!(v[k] & R1_VALID))
-					v[k] = k == 0 ? r1_ld32(&P.cprefix[(size_t) (c - 1) * R1_ROW + dg])
-					              : r1_ld32(&P.agg[(size_t) (tile - k) * R1_ROW + dg]);
-			}
 			bool all = true;
 			#pragma unroll
 			for (unsigned k = 0; k < R1_CHUNK; ++k) all = all && (v[k] & R1_VALID);
 			if (all) break;
+			if (spins != 0) __builtin_amdgcn_s_sleep(1);
 			if (++spins > P.max_spins) { atomicExch(P.status, 1u); break; }
-			__builtin_amdgcn_s_sleep(1);
+			unsigned nv[R1_CHUNK];
+			#pragma unroll
+			for (unsigned k = 0; k < R1_CHUNK; ++k) nv[k] = r1_ld32(addr[k]);
+			#pragma unroll
+			for (unsigned k = 0; k < R1_CHUNK; ++k) if (!(v[k] & R1_VALID)) v[k] = nv[k];
+		}
+		#pragma unroll
+		for (unsigned k = 0; k < R1_CHUNK; ++k) {
+			const bool want = k == 0 ? c > 0 : k <= q;
+			if (!want) v[k] = R1_VALID;
 		}
 		unsigned excl = 0;
 		#pragma unroll
@@ -461,7 +472,8 @@ size_t g_r1_stamps_tiles = 0;
 
 template <typename E, int NP>
 void r1_launch_ghist(const E* src, size_t n, int key_shift, int key_bits, unsigned* ghist, clo_keyx kx, unsigned tiles, hipStream_t s) {
-	const unsigned per = tiles > 4096u ? (tiles + 2047u) / 2048u : (tiles > 256u ? 2u : 1u);
+	unsigned per = tiles > 4096u ? (tiles + 2047u) / 2048u : (tiles > 256u ? 2u : 1u);
+	if (per > 16u) per = 16u;   // (16-bit counters: at most 16 tiles between flushes)
 	const unsigned groups = (tiles + per - 1u) / per;
 	hipLaunchKernelGGL((clo_radix1_ghist_kernel<E, NP>), dim3(groups), dim3(R1_GH_THREADS), 0, s,
 		src, n, (unsigned) key_shift, (unsigned) key_bits, ghist, (int) ((uintptr_t) src % 16 == 0), kx, per);

@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int RW_THREADS = 512;
-constexpr int RW_WAVES = RW_THREADS / 64;
 constexpr int RW_CHUNK = 128;   // tiles per chunk of the counter scan
 
 // 32 KiB LDS stage for 4- and 8-byte elements
@@ -41,13 +40,19 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	constexpr int VB = ITEMS * (int) sizeof(E) >= 16 ? 16 : ITEMS * (int) sizeof(E);   // bytes per vector load
 	constexpr int VECS = ITEMS * (int) sizeof(E) / VB;
 	constexpr int PER = VB / (int) sizeof(E);
-	__shared__ unsigned s_cnt[RW_WAVES][R];
-	const unsigned tid = threadIdx.x, wave = tid >> 6;
+	// 32 copies of every counter, copy = lane mod 32, bin-major: the 32 lanes an LDS
+	// instruction serves together hit 32 different banks and never one address (an
+	// LDS add holds its bank for many cycles; one copy per wave, lanes colliding on
+	// banks, made the adds a co-bottleneck of this otherwise streaming kernel).
+	constexpr int COPIES = 32;
+	__shared__ unsigned s_cnt[R * COPIES];
+	const unsigned tid = threadIdx.x, lane = tid & 63u;
 	const size_t base = (size_t) blockIdx.x * TILE;
 	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-	for (unsigned i = tid; i < RW_WAVES * R; i += RW_THREADS) (&s_cnt[0][0])[i] = 0;
+	for (unsigned i = tid; i < (unsigned) (R * COPIES); i += RW_THREADS) s_cnt[i] = 0;
 	__syncthreads();
 	const unsigned tbase = tid * ITEMS;
+	const unsigned cp = lane & (COPIES - 1);
 	if (count == (unsigned) TILE && aligned) {
 		typedef E vecE __attribute__((ext_vector_type(PER)));   // (`aligned`: the source is 16-byte aligned)
 		const vecE* p = reinterpret_cast<const vecE*>(in + base + tbase);
@@ -58,19 +63,24 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 		for (int k = 0; k < VECS; ++k) {
 			#pragma unroll
 			for (int q = 0; q < PER; ++q)
-				atomicAdd(&s_cnt[wave][(unsigned) (clo_keyx_fwd<E>(v[k][q], kx) >> shift) & mask], 1u);
+				atomicAdd(&s_cnt[(((unsigned) (clo_keyx_fwd<E>(v[k][q], kx) >> shift) & mask) << 5) + cp], 1u);
 		}
 	} else {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
 			if (tbase + i < count)
-				atomicAdd(&s_cnt[wave][(unsigned) (clo_keyx_fwd<E>(in[base + tbase + i], kx) >> shift) & mask], 1u);
+				atomicAdd(&s_cnt[(((unsigned) (clo_keyx_fwd<E>(in[base + tbase + i], kx) >> shift) & mask) << 5) + cp], 1u);
 	}
 	__syncthreads();
 	for (unsigned d = tid; d < (unsigned) R; d += RW_THREADS) {
+		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+		const vec4u* row = reinterpret_cast<const vec4u*>(&s_cnt[d * COPIES]);
 		unsigned h = 0;
 		#pragma unroll
-		for (int w = 0; w < RW_WAVES; ++w) h += s_cnt[w][d];
+		for (int k = 0; k < COPIES / 4; ++k) {   // (rotated: the lanes' rows are 128 bytes apart)
+			const vec4u x = row[(k + d) & (COPIES / 4 - 1)];
+			h += x[0] + x[1] + x[2] + x[3];
+		}
 		thist[(size_t) blockIdx.x * R + d] = h;
 	}
 }
@@ -278,4 +288,4 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 	return (int) hipGetLastError();
 }
 
-size_t clo_radixw_lds_bytes(int digit_bits) { return RW_WAVES * ((size_t) 1 << digit_bits) * sizeof(unsigned); }
+size_t clo_radixw_lds_bytes(int digit_bits) { return 32 * ((size_t) 1 << digit_bits) * sizeof(unsigned); }
