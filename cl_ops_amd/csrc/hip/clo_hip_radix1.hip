@@ -364,6 +364,9 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 				: (k == 0 ? &P.cprefix[(size_t) (c - 1) * R1_ROW + dg] : &P.agg[(size_t) (tile - k) * R1_ROW + dg]);
 			v[k] = k < (unsigned) R1_EARLY ? early[k] : (want ? 0u : R1_VALID);
 		}
+		// Rounds of loads, each issued as batches of four entries; a batch is skipped
+		// when the tile needs none of it (q is the same for the whole work-group: a
+		// scalar branch, the loads inside stay unconditional).
 		unsigned spins = 0;
 		for (;;) {
 			bool all = true;
@@ -372,11 +375,19 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 			if (all) break;
 			if (spins != 0) __builtin_amdgcn_s_sleep(1);
 			if (++spins > P.max_spins) { atomicExch(P.status, 1u); break; }
-			unsigned nv[R1_CHUNK];
 			#pragma unroll
-			for (unsigned k = 0; k < R1_CHUNK; ++k) nv[k] = r1_ld32(addr[k]);
-			#pragma unroll
-			for (unsigned k = 0; k < R1_CHUNK; ++k) if (!(v[k] & R1_VALID)) v[k] = nv[k];
+			for (unsigned g = 0; g < R1_CHUNK / 4; ++g) {
+				if (g != 0 && q < 4 * g) continue;   // (entries 4g .. 4g+3 are rows of tile - 4g ...: not needed)
+				if (spins == 1 && 4 * g + 3 < (unsigned) R1_EARLY) {   // requested already: reload only if something is missing
+					const bool have = (v[4 * g] & v[4 * g + 1] & v[4 * g + 2] & v[4 * g + 3] & R1_VALID) != 0;
+					if (__builtin_amdgcn_ballot_w64(!have) == 0) continue;
+				}
+				unsigned nv[4];
+				#pragma unroll
+				for (unsigned k = 0; k < 4; ++k) nv[k] = r1_ld32(addr[4 * g + k]);
+				#pragma unroll
+				for (unsigned k = 0; k < 4; ++k) if (!(v[4 * g + k] & R1_VALID)) v[4 * g + k] = nv[k];
+			}
 		}
 		#pragma unroll
 		for (unsigned k = 0; k < R1_CHUNK; ++k) {
