@@ -351,6 +351,9 @@ int small_dispatch(const void* src, void* dst, size_t n, int key_shift, int key_
 		if (n <= (size_t) SMALL_TILE) \
 			hipLaunchKernelGGL((clo_radix4_small_kernel<E, B, 512, 8>), dim3(1), dim3(512), 0, s, \
 				(const E*) src, (E*) dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx); \
+		else if (n <= (size_t) 1024 * 8) \
+			hipLaunchKernelGGL((clo_radix4_small_kernel<E, B, 1024, 8>), dim3(1), dim3(1024), 0, s, \
+				(const E*) src, (E*) dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx); \
 		else \
 			hipLaunchKernelGGL((clo_radix4_small_kernel<E, B, small_big<E>::THREADS, small_big<E>::ITEMS>), dim3(1), dim3(small_big<E>::THREADS), 0, s, \
 				(const E*) src, (E*) dst, (unsigned) n, (unsigned) key_shift, (unsigned) key_bits, kx); \

@@ -110,11 +110,14 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned lon
 // `mid`: work placed between the first two barriers, where only wave 0 is busy
 // (it turns the wave totals into wave bases) — every thread calls it, it picks
 // its own waves; it must not touch s_wtot / s_wbase / s_end.
+// `counted`: called by every thread right after it has counted its own elements,
+// with the two packed counters (4 bits per digit; c2 only for ITEMS == 16).
 struct pc_no_mid { __device__ __forceinline__ void operator()() const {} };
+struct pc_no_counted { __device__ __forceinline__ void operator()(unsigned long long, unsigned long long) const {} };
 
-template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid>
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid, typename Counted = pc_no_counted>
 __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
-	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid = Mid()) {
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid = Mid(), Counted counted = Counted()) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -152,6 +155,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 			}
 		}
 	}
+	counted(c, c2);
 	unsigned w[H];
 	pc2_wave_scan<BITS, (ITEMS > 8)>(c, c2, w);
 	if (lane == 63) {

@@ -37,6 +37,19 @@ __device__ __forceinline__ void load4(const T* p, T (&v)[4]) {
 	vec4 x = *reinterpret_cast<const vec4*>(p);
 	v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
 }
+// (experiments: non-temporal variants, CLO_SCAN_XFLAGS bits 2 / 4)
+template <typename T>
+__device__ __forceinline__ void load4_nt(const T* p, T (&v)[4]) {
+	typedef T vec4 __attribute__((ext_vector_type(4)));
+	vec4 x = __builtin_nontemporal_load(reinterpret_cast<const vec4*>(p));
+	v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+}
+template <typename T>
+__device__ __forceinline__ void store4_nt(T* p, const T (&v)[4]) {
+	typedef T vec4 __attribute__((ext_vector_type(4)));
+	vec4 x; x.x = v[0]; x.y = v[1]; x.z = v[2]; x.w = v[3];
+	__builtin_nontemporal_store(x, reinterpret_cast<vec4*>(p));
+}
 template <typename T>
 __device__ __forceinline__ void store4(T* p, const T (&v)[4]) {
 	typedef T vec4 __attribute__((ext_vector_type(4)));
@@ -226,7 +239,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		#pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
 			TIn t[4];
-			load4<TIn>(in + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			if (xflags & 2u) load4_nt<TIn>(in + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			else load4<TIn>(in + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
 			#pragma unroll
 			for (int c = 0; c < 4; ++c) v[r][c] = (TSum) t[c];
 		}
@@ -337,7 +351,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		for (int r = 0; r < ROWS; ++r) {
 			const TSum o = tile_excl + lane_excl[r];
 			TOut t[4] = { (TOut) o, (TOut) (o + v[r][0]), (TOut) (o + v[r][1]), (TOut) (o + v[r][2]) };
-			store4<TOut>(out + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			if (xflags & 4u) store4_nt<TOut>(out + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			else store4<TOut>(out + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
 		}
 	} else {
 		#pragma unroll

@@ -55,17 +55,16 @@ def run(mode, steps=20):
         c, tot = _hip.timing_read(lab)
         if c:
             parts[lab] = round(tot / c, 4)
-    print("sweep=%s chunk_log=%s early=%s  %s 2^%d: %.3f ms/sort  %.0f Mkeys/s  correct=%s  per launch (ms): %s"
-          % (mode, os.environ.get("CLO_R1_CHUNK_LOG", "-"), os.environ.get("CLO_R1_EARLY", "-"), kind, log2n, ms, n / ms / 1e3, ok, parts), flush=True)
+    print("sweep=%s chunk_log=%s  %s 2^%d: %.3f ms/sort  %.0f Mkeys/s  correct=%s  per launch (ms): %s"
+          % (mode, os.environ.get("CLO_R1_CHUNK_LOG", "-"), kind, log2n, ms, n / ms / 1e3, ok, parts), flush=True)
     return s
 
 
 run("0").close()
-for cl, early in (("4", "0"), ("3", "8"), ("4", "8")):
-    os.environ["CLO_R1_EARLY"] = early
+for cl in ("3", "4"):
     os.environ["CLO_R1_CHUNK_LOG"] = cl
     s = run("1")
-    if (cl, early) != ("4", "8"):
+    if cl != "4":
         s.close()
 
 # ---- stamps of the last pass's tiles ----
@@ -79,13 +78,13 @@ q.finish()
 lib.clo_hip_radix_debug_stamps(None, 0)
 a = st.cpu().numpy().reshape(tiles, 8)
 t = a[:, :7].astype(np.float64)
-names = ["ticket+load", "counts+split lo+publish", "resolver+early loads", "split hi", "look-back wait", "scatter issue"]
+names = ["ticket + load issue", "load latency + split 1", "-", "split 2 (+ row adds, publish)", "look-back (requests, wait)", "scatter issue"]
 d = np.diff(t, axis=1)
 clk = 100e6   # s_memtime ticks at the shader clock? printed raw: convert with the kernel's duration below
 life = t[:, 6] - t[:, 0]
 print("tiles %d; stamps in s_memtime ticks (median / mean / p90 per phase):" % tiles)
 for k, nm in enumerate(names):
-    print("  %-20s %8.0f %8.0f %8.0f   %4.1f %% of a tile's life" % (nm, np.median(d[:, k]), d[:, k].mean(), np.percentile(d[:, k], 90),
+    print("  %-30s %8.0f %8.0f %8.0f   %4.1f %% of a tile's life" % (nm, np.median(d[:, k]), d[:, k].mean(), np.percentile(d[:, k], 90),
                                                                    100 * d[:, k].mean() / life.mean()))
 print("  tile life            %8.0f %8.0f %8.0f" % (np.median(life), life.mean(), np.percentile(life, 90)))
 span = t[:, 6].max() - t[:, 0].min()
