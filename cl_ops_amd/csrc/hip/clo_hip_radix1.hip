@@ -63,13 +63,6 @@ __device__ __forceinline__ void r1_st32(unsigned* p, unsigned v) {
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Where the 16-bit counter of second-split digit h sits in a row of the tile's joint
-// histogram: rows hold the thread-private byte counters in the order they come out
-// of the packed nibbles — words of digits {0,2,4,6}, {1,3,5,7}, {8,..,14}, {9,..,15},
-// each widened to two dwords of two 16-bit fields.
-__device__ __forceinline__ unsigned r1_joint_dword(unsigned h) { return (((h >> 3) * 2u + (h & 1u)) << 1) + ((h >> 2) & 1u); }
-__device__ __forceinline__ unsigned r1_joint_half(unsigned h) { return (h >> 1) & 1u; }
-
 // XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Speed only.
 __device__ __forceinline__ unsigned r1_xcc_id() {
 	return (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
@@ -163,7 +156,9 @@ struct r1_pass {
 	unsigned tiles, max_spins;
 };
 
-template <typename E, int LB, int HB, int R1_CHUNK_LOG>
+// R1_EARLY: level-1 entries (the previous chunk's prefix + the nearest rows) requested
+// before the second split, so that their round trip runs under it.
+template <typename E, int LB, int HB, int R1_CHUNK_LOG, int R1_EARLY>
 __global__ __launch_bounds__(pair_shape<E>::THREADS, 6)
 void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi, r1_pass P, int aligned, clo_keyx kx_in, clo_keyx kx_out) {
@@ -175,9 +170,9 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	constexpr int R2 = 1 << (LB + HB);
 	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
 	constexpr unsigned R1_CHUNK = 1u << R1_CHUNK_LOG;    // tiles per chunk
+	static_assert(R1_EARLY <= (int) R1_CHUNK, "at most the whole level 1");
 	static_assert(R2 <= R1_ROW && R2 <= THREADS, "one thread per combined digit");
 	static_assert(THREADS >= 2 * R1_ROW, "the digit threads are the second half of the work-group");
-	static_assert(LB <= 4 && HB <= 4, "16 rows of 16 sixteen-bit counters");
 
 	__shared__ E s_stage[TILE];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
@@ -186,16 +181,6 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
 	__shared__ unsigned s_w4[4];
 	__shared__ unsigned s_tile;
-	// The tile's histogram of the combined digit, as 16 rows (first-split digit) of 16
-	// sixteen-bit counters (second-split digit). It is NOT counted element by element:
-	// LDS adds run at ~4 lanes per clock on this chip, and 8192 of them per tile cost a
-	// quarter of the tile's life (measured: clo_hip_radix1.hip history in DESIGN.md).
-	// After the first split the tile is sorted by the first digit, so a thread's
-	// consecutive elements nearly always share it; the second split counts the
-	// thread's elements by the second digit anyway (packed counters), and those 16
-	// counts go into the thread's row with four 64-bit adds. Only the threads that
-	// straddle two rows (<= 15 per tile) add element by element.
-	__shared__ __attribute__((aligned(8))) unsigned s_joint[16 * 8];
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	clo_u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
@@ -208,7 +193,16 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	const bool dthread = dg >= 0 && dg < R2;
 	const bool dwaves = wave >= (unsigned) (WAVES - R1_ROW / 64);
 	const unsigned dwave = wave - (unsigned) (WAVES - R1_ROW / 64);
-	if (tid < 16 * 8) s_joint[tid] = 0;
+
+	// per-wave counters of the tile histogram: they borrow the head of the stage
+	// (read back before the first split writes the stage). 32 bank-private copies of
+	// every bin (no two lanes of an LDS instruction on one bank) measured SLOWER
+	// (13 470 vs 12 600 ticks for counting + first split): the LDS add unit itself,
+	// ~2 lanes per clock, is the limit, not its bank conflicts.
+	unsigned* s_hist = reinterpret_cast<unsigned*>(s_stage);
+	static_assert(sizeof(E) * TILE >= WAVES * R1_ROW * sizeof(unsigned), "the histogram fits the stage");
+	#pragma unroll
+	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
 
 	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
 	if (tid == 0) {
@@ -237,7 +231,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	const unsigned mask2 = (mask_hi << LB) | mask_lo;
 	const unsigned n32 = (unsigned) n;   // n < 2^31 here
 
-	// ---- load ----
+	// ---- load; count the combined digit (LDS adds, not waited for) ----
 	E key[ITEMS];
 	if (full) {
 		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
@@ -250,45 +244,19 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
 	}
 	if (P.stamps) t1 = __builtin_amdgcn_s_memtime();
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i)
+		if (full || tbase + i < count) atomicAdd(&s_hist[wave * R1_ROW + ((unsigned) (key[i] >> shift) & mask2)], 1u);
 
-	// ---- hooks of the split that finishes the tile's order (the second one; the only
-	// one when the pass has a single digit): row adds after counting, and between its
-	// first two barriers the digit threads read the histogram and PUBLISH it ----
-	// (a last pass of <= 4 bits has mask_hi == 0: its second split moves nothing and counts everything as digit 0)
-	const unsigned hs = shift + LB, hm = mask_hi;   // the counted digit
+	// ---- first local split; between its first two barriers (all counts are in by
+	// then) the digit threads publish the tile's row and its arrival at the chunk ----
 	unsigned h2 = 0, incl2 = 0;
 	clo_u64 old = 0;
-	int my_row = -1;   // the row all of this thread's elements share, or -1 (none / two rows: handled before the split)
-	auto counted = [&](unsigned long long cc, unsigned long long cc2) {
-		if (my_row < 0) return;
-		// the thread's 16 counts as bytes: words of digits {0,2,4,6}, {1,3,5,7}, {8,..,14}, {9,..,15}
-		unsigned b[4];
-		const unsigned lo = (unsigned) cc, hi = (unsigned) (cc >> 32);
-		b[0] = lo & 0x0f0f0f0fu;
-		b[1] = (lo >> 4) & 0x0f0f0f0fu;
-		b[2] = hi & 0x0f0f0f0fu;
-		b[3] = (hi >> 4) & 0x0f0f0f0fu;
-		if (ITEMS > 8) {
-			const unsigned lo2 = (unsigned) cc2, hi2 = (unsigned) (cc2 >> 32);
-			b[0] += lo2 & 0x0f0f0f0fu;
-			b[1] += (lo2 >> 4) & 0x0f0f0f0fu;
-			b[2] += hi2 & 0x0f0f0f0fu;
-			b[3] += (hi2 >> 4) & 0x0f0f0f0fu;
-		}
-		unsigned long long* row = reinterpret_cast<unsigned long long*>(&s_joint[my_row * 8]);
-		#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const unsigned d0 = __builtin_amdgcn_perm(0u, b[k], 0x0c010c00u);   // bytes 0, 1 -> 16-bit fields
-			const unsigned d1 = __builtin_amdgcn_perm(0u, b[k], 0x0c030c02u);   // bytes 2, 3
-			const unsigned long long v = ((unsigned long long) d1 << 32) | d0;
-			if (v) atomicAdd(&row[k], v);
-		}
-	};
 	auto publish = [&]() {
 		if (!dwaves) return;
 		if (dthread) {
-			const unsigned h = (unsigned) dg >> LB, l = (unsigned) dg & ((1u << LB) - 1u);
-			h2 = (s_joint[l * 8 + r1_joint_dword(h)] >> (16u * r1_joint_half(h))) & 0xffffu;
+			#pragma unroll
+			for (int w = 0; w < WAVES; ++w) h2 += s_hist[w * R1_ROW + dg];
 			r1_st32(&P.agg[(size_t) tile * R1_ROW + dg], R1_VALID | h2);
 			old = __hip_atomic_fetch_add(&P.cacc[(size_t) c * R1_ROW + dg], (1ull << R1_CNT_SHIFT) | (clo_u64) h2,
 				__ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -297,81 +265,17 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
 		if (lane == 63) s_w4[dwave] = incl2;
 	};
+	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase, publish);
+	if (P.stamps) t2 = __builtin_amdgcn_s_memtime();
 
-	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
-	if (P.stamps) t2 = t3 = __builtin_amdgcn_s_memtime();
-	if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)
-		constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
-		typedef E vec16 __attribute__((ext_vector_type(PER)));
-		#pragma unroll
-		for (int k = 0; k < ITEMS / PER; ++k) {
-			const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
-			#pragma unroll
-			for (int qq = 0; qq < PER; ++qq) key[k * PER + qq] = t[qq];
-		}
-	} else {
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
-	}
-	if (full || tbase < count) {
-		const unsigned r_first = (unsigned) (key[0] >> shift) & mask_lo;
-		unsigned r_last = (unsigned) (key[ITEMS - 1] >> shift) & mask_lo;
-		if (!full) {
-			#pragma unroll
-			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) r_last = (unsigned) (key[i] >> shift) & mask_lo;
-		}
-		if (r_first == r_last) {
-			my_row = (int) r_first;
-		} else {   // a thread across two rows (at most 15 per tile): element by element
-			#pragma unroll
-			for (int i = 0; i < ITEMS; ++i) {
-				if (full || tbase + i < count) {
-					const unsigned l = (unsigned) (key[i] >> shift) & mask_lo, h = (unsigned) (key[i] >> hs) & hm;
-					atomicAdd(&s_joint[l * 8 + r1_joint_dword(h)], 1u << (16u * r1_joint_half(h)));
-				}
-			}
-		}
-	}
-	pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase, publish, counted);
-	if (P.stamps) t4 = __builtin_amdgcn_s_memtime();
-
-	// ---- the tile's prefix ----
+	unsigned dstart2 = 0;
+	unsigned early[R1_EARLY > 0 ? R1_EARLY : 1];   // early[0]: prefix of the previous chunk; early[k]: row of tile - k (R1_VALID | count)
+	#pragma unroll
+	for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) early[k] = R1_VALID;
 	if (dthread) {
-		unsigned dstart2 = incl2 - h2;
+		dstart2 = incl2 - h2;
 		#pragma unroll
 		for (unsigned w = 0; w < 4; ++w) if (w < dwave) dstart2 += s_w4[w];
-
-		// What this tile needs: the rows of the earlier tiles of its chunk (level 1), the
-		// total of the chunk before (its accumulator, complete once all its tiles have
-		// arrived — long ago: they are a whole chunk ahead) and the inclusive prefix of
-		// the chunk before that. Requested first, as batches of unconditional loads
-		// (q and c are the same for the whole work-group: scalar branches around
-		// batches, no branch around a load — the compiler waits for a branched load
-		// before it issues the next one).
-		unsigned rows[R1_CHUNK];     // rows[r]: row of tile - 1 - r
-		#pragma unroll
-		for (unsigned r = 0; r < R1_CHUNK; ++r) rows[r] = r < q ? 0u : R1_VALID;
-		unsigned pv = c >= 2 ? 0u : R1_VALID;                                  // cprefix[c - 2]
-		clo_u64 av = c >= 1 ? 0ull : ((clo_u64) R1_CHUNK << R1_CNT_SHIFT);     // cacc[c - 1]
-		const unsigned* const myrow = &P.agg[(size_t) tile * R1_ROW + dg];
-		auto request = [&](bool first) {
-			if (c >= 1 && (first || (unsigned) (av >> R1_CNT_SHIFT) != R1_CHUNK)) av = clo_ld_agent(&P.cacc[(size_t) (c - 1) * R1_ROW + dg]);
-			if (c >= 2 && (first || !(pv & R1_VALID))) pv = r1_ld32(&P.cprefix[(size_t) (c - 2) * R1_ROW + dg]);
-			#pragma unroll
-			for (unsigned g = 0; g < R1_CHUNK / 4; ++g) {
-				if (q <= 4 * g) continue;
-				unsigned nv[4];
-				#pragma unroll
-				for (unsigned k = 0; k < 4; ++k) {
-					const unsigned r = 4 * g + k;
-					nv[k] = r1_ld32(r < q ? myrow - (size_t) (r + 1) * R1_ROW : myrow);   // (own row: valid, ignored)
-				}
-				#pragma unroll
-				for (unsigned k = 0; k < 4; ++k) if (!(rows[4 * g + k] & R1_VALID)) rows[4 * g + k] = nv[k];
-			}
-		};
-		request(true);
-
 		// ---- level 2, by whichever tile completed (chunk, digit): look back over the
 		// earlier chunks, a window at a time, and publish the chunk's inclusive prefix ----
 		if ((unsigned) (old >> R1_CNT_SHIFT) == in_chunk - 1u) {
@@ -380,14 +284,14 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 			long j = (long) c - 1;
 			unsigned spins = 0;
 			while (j >= 0) {
-				unsigned wpv[R1_WINDOW];
-				clo_u64 wav[R1_WINDOW];
+				unsigned pv[R1_WINDOW];
+				clo_u64 av[R1_WINDOW];
 				#pragma unroll
 				for (int w = 0; w < R1_WINDOW; ++w) {
-					wpv[w] = 0; wav[w] = 0;
+					pv[w] = 0; av[w] = 0;
 					if (j - w >= 0) {
-						wpv[w] = r1_ld32(&P.cprefix[(size_t) (j - w) * R1_ROW + dg]);
-						wav[w] = clo_ld_agent(&P.cacc[(size_t) (j - w) * R1_ROW + dg]);
+						pv[w] = r1_ld32(&P.cprefix[(size_t) (j - w) * R1_ROW + dg]);
+						av[w] = clo_ld_agent(&P.cacc[(size_t) (j - w) * R1_ROW + dg]);
 					}
 				}
 				bool closed = false, stalled = false;
@@ -395,8 +299,8 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 				#pragma unroll
 				for (int w = 0; w < R1_WINDOW; ++w) {
 					if (closed || stalled || j - w < 0) continue;
-					if (wpv[w] & R1_VALID) { excl += wpv[w] & ~R1_VALID; closed = true; }
-					else if ((unsigned) (wav[w] >> R1_CNT_SHIFT) == R1_CHUNK) { excl += wav[w] & R1_SUM_MASK; used = w + 1; }   // (every earlier chunk is full)
+					if (pv[w] & R1_VALID) { excl += pv[w] & ~R1_VALID; closed = true; }
+					else if ((unsigned) (av[w] >> R1_CNT_SHIFT) == R1_CHUNK) { excl += av[w] & R1_SUM_MASK; used = w + 1; }   // (every earlier chunk is full)
 					else stalled = true;
 				}
 				if (closed) break;
@@ -408,21 +312,91 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 			}
 			r1_st32(&P.cprefix[(size_t) c * R1_ROW + dg], R1_VALID | (unsigned) (excl + total));
 		}
+	}
+	if (P.stamps) t3 = __builtin_amdgcn_s_memtime();
 
-		// ---- consume what was requested; poll again for what had not been published yet ----
+	if (mask_hi != 0) {
+		if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)
+			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
+			typedef E vec16 __attribute__((ext_vector_type(PER)));
+			#pragma unroll
+			for (int k = 0; k < ITEMS / PER; ++k) {
+				const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
+				#pragma unroll
+				for (int qq = 0; qq < PER; ++qq) key[k * PER + qq] = t[qq];
+			}
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
+		}
+		// The nearest rows of level 1 and the previous chunk's prefix are requested from
+		// INSIDE the second split (its idle slot for the digit waves): late enough for
+		// rows published a moment ago to have become visible (a store takes 1-2 us to
+		// show, and the tile before this one is only ~0.2 us ahead), early enough for
+		// the round trip (~2.5 us) to run under the rest of the split.
+		auto request = [&]() {
+			if (!dthread) return;
+			#pragma unroll
+			for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) {
+				const bool want = k == 0 ? c > 0 : k <= q;
+				const unsigned* a = !want ? &P.agg[(size_t) tile * R1_ROW + dg]   // (own row: valid, ignored)
+					: (k == 0 ? &P.cprefix[(size_t) (c - 1) * R1_ROW + dg] : &P.agg[(size_t) (tile - k) * R1_ROW + dg]);
+				early[k] = r1_ld32(a);
+			}
+		};
+		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase, request);
+	}
+	if (P.stamps) t4 = __builtin_amdgcn_s_memtime();
+
+	// ---- the tile's prefix: level 1 (earlier tiles of the chunk) + the prefix of the chunk before ----
+	if (dthread) {
+		// Entry k: 0 = the previous chunk's inclusive prefix, k >= 1 = the row of tile - k.
+		// Entries this tile does not need read its OWN row instead (published long
+		// ago, so valid) and count as zero: every load of a round is then unconditional
+		// and the compiler issues the round as one batch — with a branch around each
+		// load it waited for each before issuing the next, a round trip apiece.
+		const unsigned* addr[R1_CHUNK];
+		unsigned v[R1_CHUNK];
+		#pragma unroll
+		for (unsigned k = 0; k < R1_CHUNK; ++k) {
+			const bool want = k == 0 ? c > 0 : k <= q;
+			addr[k] = !want ? &P.agg[(size_t) tile * R1_ROW + dg]
+				: (k == 0 ? &P.cprefix[(size_t) (c - 1) * R1_ROW + dg] : &P.agg[(size_t) (tile - k) * R1_ROW + dg]);
+			v[k] = k < (unsigned) R1_EARLY ? early[k] : (want ? 0u : R1_VALID);
+		}
+		// Rounds of loads, each issued as batches of four entries; a batch is skipped
+		// when the tile needs none of it (q is the same for the whole work-group: a
+		// scalar branch, the loads inside stay unconditional).
 		unsigned spins = 0;
 		for (;;) {
-			bool all = (pv & R1_VALID) && (unsigned) (av >> R1_CNT_SHIFT) == R1_CHUNK;
+			bool all = true;
 			#pragma unroll
-			for (unsigned r = 0; r < R1_CHUNK; ++r) all = all && (rows[r] & R1_VALID);
+			for (unsigned k = 0; k < R1_CHUNK; ++k) all = all && (v[k] & R1_VALID);
 			if (all) break;
+			if (spins != 0) __builtin_amdgcn_s_sleep(1);
 			if (++spins > P.max_spins) { atomicExch(P.status, 1u); break; }
-			__builtin_amdgcn_s_sleep(1);
-			request(false);
+			#pragma unroll
+			for (unsigned g = 0; g < R1_CHUNK / 4; ++g) {
+				if (g != 0 && q < 4 * g) continue;   // (entries 4g .. 4g+3 are rows of tile - 4g ...: not needed)
+				if (spins == 1 && 4 * g + 3 < (unsigned) R1_EARLY) {   // requested already: reload only if something is missing
+					const bool have = (v[4 * g] & v[4 * g + 1] & v[4 * g + 2] & v[4 * g + 3] & R1_VALID) != 0;
+					if (__builtin_amdgcn_ballot_w64(!have) == 0) continue;
+				}
+				unsigned nv[4];
+				#pragma unroll
+				for (unsigned k = 0; k < 4; ++k) nv[k] = r1_ld32(addr[4 * g + k]);
+				#pragma unroll
+				for (unsigned k = 0; k < 4; ++k) if (!(v[4 * g + k] & R1_VALID)) v[4 * g + k] = nv[k];
+			}
 		}
-		unsigned excl = (c >= 2 ? pv & ~R1_VALID : 0u) + (c >= 1 ? (unsigned) (av & R1_SUM_MASK) : 0u);
 		#pragma unroll
-		for (unsigned r = 0; r < R1_CHUNK; ++r) if (r < q) excl += rows[r] & ~R1_VALID;
+		for (unsigned k = 0; k < R1_CHUNK; ++k) {
+			const bool want = k == 0 ? c > 0 : k <= q;
+			if (!want) v[k] = R1_VALID;
+		}
+		unsigned excl = 0;
+		#pragma unroll
+		for (unsigned k = 0; k < R1_CHUNK; ++k) excl += v[k] & ~R1_VALID;
 		s_delta[dg] = P.gbase[dg] + excl - dstart2;
 	}
 	clo_lds_barrier();
@@ -529,6 +503,8 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned max_spins = CLO_MAX_SPINS;
 	if (const char* m = getenv("CLO_MAX_SPINS")) max_spins = (unsigned) strtoul(m, nullptr, 10);
 	const int chunk_log = r1_chunk_log();
+	int early = 8;   // (CLO_R1_EARLY: A/B measurements)
+	if (const char* m = getenv("CLO_R1_EARLY")) early = atoi(m);
 
 	// everything the passes publish or count in starts from zero
 	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
@@ -564,10 +540,10 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		P.tiles = tiles;
 		P.max_spins = max_spins;
 		clo_timing_scope timing("radix_sweep", s);
-		#define CLO_R1_SWEEP(CL) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s, \
+		#define CLO_R1_SWEEP(CL, EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL, EARLY>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s, \
 			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P, \
 			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none)
-		if (chunk_log == 3) CLO_R1_SWEEP(3); else CLO_R1_SWEEP(4);
+		if (chunk_log == 3) CLO_R1_SWEEP(3, 8); else if (early == 0) CLO_R1_SWEEP(4, 0); else CLO_R1_SWEEP(4, 8);
 		#undef CLO_R1_SWEEP
 		cur_in = cur_out;
 	}
@@ -593,14 +569,14 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
-	// The library's choice (measured): between 64 and 1024 tiles
-	// (2^19 .. 2^23 4-byte elements) the sweeps take 10-40 % less time than the
+	// The library's choice (measured): between 128 and 1024 tiles
+	// (2^20 .. 2^23 4-byte elements) the sweeps take 15-40 % less time than the
 	// chain-free passes — 7 launches instead of 12 at sizes that are launch-bound,
 	// and a look-back over few tiles; above that the two are within 3 % of each other
 	// (the sweep's tile histogram and its one exposed round trip cost what the
 	// separate histogram kernel costs), and the chain-free passes keep the sort free
 	// of any wait between work-groups.
-	return tiles >= 64 && tiles <= 1024;
+	return tiles >= 128 && tiles <= 1024;
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

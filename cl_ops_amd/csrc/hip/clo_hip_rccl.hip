@@ -1,0 +1,78 @@
+// clo_hip_rccl.hip — the RCCL part of the thin C-ABI (include/clo_hip.h): what the
+// sharded sort (include/clo_shard.h) exchanges between the GPUs of a node over
+// xGMI. New functionality — the reference is single-device
+// (sort/clo_sort_abstract.c:335 creates its queue on device 0).
+//
+// Two collectives, both stream-ordered on the caller's stream:
+//   * all-gather of a few uint64 per rank (the bucket counts);
+//   * all-to-all(v) as ONE group of ncclSend / ncclRecv pairs: xGMI is point to
+//     point, every pair of GPUs has its own link, so the world-1 transfers of a
+//     rank run side by side; peers are visited in ring order (rank + k, rank - k)
+//     so that all ranks post matching operations in a compatible order.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "clo_hip.h"
+
+static_assert(sizeof(ncclUniqueId) == CLO_HIP_RCCL_ID_BYTES, "clo_hip.h carries the id as 128 opaque bytes");
+
+namespace {
+// RCCL statuses travel as negative numbers below the CLO_HIP_E* range
+inline int rccl_status(ncclResult_t r) { return r == ncclSuccess ? 0 : CLO_HIP_ERCCL - (int) r; }
+}
+
+extern "C" {
+
+int clo_hip_rccl_unique_id(void* id_out) {
+	if (!id_out) return CLO_HIP_EARGS;
+	ncclUniqueId id;
+	const ncclResult_t r = ncclGetUniqueId(&id);
+	if (r == ncclSuccess) memcpy(id_out, &id, sizeof(id));
+	return rccl_status(r);
+}
+
+int clo_hip_rccl_comm_create(void** comm, const void* id_in, int rank, int world) {
+	if (!comm || !id_in || world < 1 || rank < 0 || rank >= world) return CLO_HIP_EARGS;
+	ncclUniqueId id;
+	memcpy(&id, id_in, sizeof(id));
+	ncclComm_t c = nullptr;
+	const ncclResult_t r = ncclCommInitRank(&c, world, id, rank);   // on the calling thread's current device
+	*comm = r == ncclSuccess ? (void*) c : nullptr;
+	return rccl_status(r);
+}
+
+int clo_hip_rccl_comm_destroy(void* comm) {
+	return comm ? rccl_status(ncclCommDestroy((ncclComm_t) comm)) : 0;
+}
+
+int clo_hip_rccl_all_gather_u64(void* comm, const uint64_t* send_dev, uint64_t* recv_dev, size_t count, void* stream) {
+	if (!comm || !send_dev || !recv_dev) return CLO_HIP_EARGS;
+	return rccl_status(ncclAllGather(send_dev, recv_dev, count, ncclUint64, (ncclComm_t) comm, (hipStream_t) stream));
+}
+
+int clo_hip_rccl_all_to_all_v(void* comm, int rank, int world,
+	const void* send_dev, const size_t* send_bytes, const size_t* send_offset_bytes,
+	void* recv_dev, const size_t* recv_bytes, const size_t* recv_offset_bytes, void* stream) {
+	if (!comm || !send_bytes || !send_offset_bytes || !recv_bytes || !recv_offset_bytes) return CLO_HIP_EARGS;
+	ncclComm_t c = (ncclComm_t) comm;
+	hipStream_t s = (hipStream_t) stream;
+	// this rank's own bucket never leaves the GPU
+	if (send_bytes[rank] != recv_bytes[rank]) return CLO_HIP_EARGS;
+	if (send_bytes[rank]) {
+		const hipError_t e = hipMemcpyAsync((char*) recv_dev + recv_offset_bytes[rank], (const char*) send_dev + send_offset_bytes[rank],
+			send_bytes[rank], hipMemcpyDeviceToDevice, s);
+		if (e != hipSuccess) return (int) e;
+	}
+	ncclResult_t r = ncclGroupStart();
+	for (int k = 1; k < world && r == ncclSuccess; ++k) {
+		const int dst = (rank + k) % world, src = (rank - k + world) % world;
+		if (send_bytes[dst]) r = ncclSend((const char*) send_dev + send_offset_bytes[dst], send_bytes[dst], ncclUint8, dst, c, s);
+		if (r == ncclSuccess && recv_bytes[src]) r = ncclRecv((char*) recv_dev + recv_offset_bytes[src], recv_bytes[src], ncclUint8, src, c, s);
+	}
+	const ncclResult_t r2 = ncclGroupEnd();
+	return rccl_status(r != ncclSuccess ? r : r2);
+}
+
+}  // extern "C"

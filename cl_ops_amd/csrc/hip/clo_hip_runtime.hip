@@ -202,7 +202,9 @@ const char* clo_hip_error_string(int status) {
 		case CLO_HIP_EUNSUPPORTED: return "clo_hip: unsupported type or option";
 		case CLO_HIP_EWORKSPACE: return "clo_hip: workspace too small";
 		case CLO_HIP_ETIMEOUT: return "clo_hip: in-kernel look-back spin timed out";
-		default: return status > 0 ? hipGetErrorString((hipError_t) status) : "clo_hip: unknown error";
+		default:
+			if (status <= CLO_HIP_ERCCL) return "clo_hip: RCCL reported an error (status = CLO_HIP_ERCCL - ncclResult_t)";
+			return status > 0 ? hipGetErrorString((hipError_t) status) : "clo_hip: unknown error";
 	}
 }
 

@@ -26,6 +26,7 @@ extern "C" {
 #define CLO_HIP_EUNSUPPORTED (-2)  /* type/option not built into this library */
 #define CLO_HIP_EWORKSPACE (-3)  /* workspace too small */
 #define CLO_HIP_ETIMEOUT   (-4)  /* an in-kernel bounded spin gave up (see clo_hip_check_status) */
+#define CLO_HIP_ERCCL      (-100) /* RCCL failures: CLO_HIP_ERCCL - ncclResult_t */
 
 /* ---- device / runtime (replaces ccl_context_*, ccl_queue_*, ccl_buffer_*,
  *      ccl_event_*, ccl_prof_* as used at sort/clo_sort_abstract.c:335-395,
@@ -156,6 +157,22 @@ int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_siz
 	int key_shift, int key_bits, int bucket_bits, uint64_t* counts_dev,
 	void* workspace, size_t workspace_bytes, void* stream);
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits);
+
+/* ---- RCCL over xGMI: the two collectives of the sharded sort (include/clo_shard.h;
+ *      new functionality, the reference is single-device). One communicator per
+ *      process = per GPU; the 128-byte id is made by one rank and handed to the
+ *      others by whatever side channel the launcher has. Both calls are ordered on
+ *      `stream`. all_to_all_v: rank r's bytes [send_offset[p], +send_bytes[p]) go to
+ *      peer p and land at its [recv_offset[r], +recv_bytes[r]); ONE group of
+ *      ncclSend / ncclRecv pairs, every pair on its own xGMI link. ---- */
+#define CLO_HIP_RCCL_ID_BYTES 128
+int clo_hip_rccl_unique_id(void* id_out);
+int clo_hip_rccl_comm_create(void** comm, const void* id_in, int rank, int world);
+int clo_hip_rccl_comm_destroy(void* comm);
+int clo_hip_rccl_all_gather_u64(void* comm, const uint64_t* send_dev, uint64_t* recv_dev, size_t count, void* stream);
+int clo_hip_rccl_all_to_all_v(void* comm, int rank, int world,
+	const void* send_dev, const size_t* send_bytes, const size_t* send_offset_bytes,
+	void* recv_dev, const size_t* recv_bytes, const size_t* recv_offset_bytes, void* stream);
 
 /* ---- bitonic sorts (replace the launch loops of
  *      sort/clo_sort_sbitonic.c:102-118 / sort/clo_sort_sbitonic.cl:38-69 and
