@@ -81,6 +81,9 @@ def parse_args(argv=None):
                     help="N > 1: which legs to run (both = weak + strong + the uint64 leg of config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2n", type=int, default=None)
+    ap.add_argument("--exchange", default="torch", choices=["torch", "c"],
+                    help="N > 1: the exchange through torch.distributed (batched isend/irecv on RCCL) or through the "
+                         "library's own C API over RCCL (include/clo_shard.h)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / exchange-plan test on CPU (gloo); not a measurement")
     return ap.parse_args(argv)
 
@@ -285,7 +288,7 @@ class _Backend:
         return float(t.item())
 
 
-def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix):
+def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix, exchange="torch"):
     """K timed distributed sorts of n_local keys per rank; returns the leg's record
     (on every rank; only rank 0's is printed)."""
     torch, dist = be.torch, be.dist
@@ -294,7 +297,11 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     workload = "satradix_u32" if es == 4 else "satradix_u64"
     host = make_input(workload, n_local, seed + rank)
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to(be.device)
-    sharded = ShardedSorter(be.ops(etype, local_rank))
+    if exchange == "c" and not be.dry:
+        from cl_ops_amd.multigpu import CShardedSorter
+        sharded = CShardedSorter(etype, local_rank, options="radix=%d" % radix)
+    else:
+        sharded = ShardedSorter(be.ops(etype, local_rank))
 
     def step():
         return sharded.sort(src, n_local)      # the shard is only read: partition into the send buffer
@@ -338,11 +345,14 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     ok = ok and int(a[:, 5].sum(dtype=np.uint64)) == int(a[:, 6].sum(dtype=np.uint64))             # same multiset (sum mod 2^64)
     ones = torch.ones(1, dtype=torch.int64, device=be.device)
     dist.all_reduce(ones)
-    sharded.ops.close() if hasattr(sharded.ops, "close") else None
+    if hasattr(sharded, "close"):
+        sharded.close()
+    elif hasattr(sharded.ops, "close"):
+        sharded.ops.close()
     del src
     return {"value": round(n_local * world * steps / t_max / 1e6, 1), "unit": "Mkeys/s",
             "ms_per_step": round(t_max / steps * 1e3, 4), "elements_per_gpu": n_local, "elements_total": n_local * world,
-            "dtype": "u32" if es == 4 else "u64", "radix": radix, "correct": ok,
+            "dtype": "u32" if es == 4 else "u64", "radix": radix, "correct": ok, "exchange": exchange,
             "ranks_seen": {"world_size": dist.get_world_size(), "allreduce_of_ones": int(ones.item())},
             "largest_bucket_over_mean": round(float(a[:, 2].max()) / n_local, 4),
             "phases_ms": {k: round(v * 1e3, 4) for k, v in phases.items()}}
@@ -358,7 +368,7 @@ def main_sharded(args, world, rank, local_rank):
     n = 1 << log2n
     wbits = world.bit_length() - 1
     legs = {}
-    common = (args.steps, args.warmup, args.seed, rank, world, local_rank, args.radix)
+    common = (args.steps, args.warmup, args.seed, rank, world, local_rank, args.radix, args.exchange)
     if args.scaling in ("weak", "both"):
         legs["weak"] = run_sharded_leg(be, etype, n, *common)
     if args.scaling in ("strong", "both"):
@@ -379,7 +389,8 @@ def main_sharded(args, world, rank, local_rank):
                                       world, args.radix),
                        "elements_per_gpu": head["elements_per_gpu"], "radix": args.radix,
                        "parallelism": "msd-bucket-exchange x%d (RCCL send/recv all-to-all) + local satradix" % world,
-                       "api": "cl_ops_amd.multigpu.ShardedSorter over clo_hip_msd_partition + clo_sort_with_device_data"},
+                       "api": "clo_shard_sort_with_device_data (C API over RCCL)" if args.exchange == "c" else
+                              "cl_ops_amd.multigpu.ShardedSorter over clo_hip_msd_partition + clo_sort_with_device_data"},
             "correct": ok, "ranks_seen": head["ranks_seen"], "phases_ms": head["phases_ms"],
         }
         for k, v in legs.items():

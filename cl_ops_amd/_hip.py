@@ -81,6 +81,12 @@ _sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER
 _sig("clo_hip_bitonic_jit_destroy", None, vp)
 _sig("clo_hip_bitonic_jit_sort", ci, vp, vp, sz, ci, C.POINTER(ci), vp)
 _sig("clo_hip_check_status", ci, vp, vp)
+_sig("clo_hip_rccl_unique_id", ci, vp)
+_sig("clo_hip_rccl_comm_create", ci, C.POINTER(vp), vp, ci, ci)
+_sig("clo_hip_rccl_comm_destroy", ci, vp)
+_sig("clo_hip_rccl_all_gather_u64", ci, vp, vp, vp, sz, vp)
+_sig("clo_hip_rccl_all_to_all_v", ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp)
+_sig("clo_hip_set_launch_observer", ci, vp, vp)
 _sig("clo_hip_radix_jit_create", ci, ci, ci, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
 _sig("clo_hip_radix_jit_destroy", None, vp)
 _sig("clo_hip_radix_jit_sort", ci, vp, vp, vp, vp, vp, sz, ci, vp, sz, vp)

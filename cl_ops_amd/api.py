@@ -132,6 +132,27 @@ _sig("clo_scan_get_kernel_name", C.c_char_p, vp, _u32, _E)
 _sig("clo_scan_get_localmem_usage", sz, vp, _u32, sz, sz, _E)
 
 
+# ---- sharded sort (include/clo_shard.h) ----
+SHARD_AG = C.CFUNCTYPE(ci, vp, vp, vp, sz, vp)
+SHARD_A2A = C.CFUNCTYPE(ci, vp, vp, C.POINTER(sz), C.POINTER(sz), vp, C.POINTER(sz), C.POINTER(sz), vp)
+SHARD_DESTROY = C.CFUNCTYPE(None, vp)
+
+
+class ShardTransportStruct(C.Structure):
+    _fields_ = [("user", vp), ("rank", ci), ("world", ci), ("all_gather_u64", SHARD_AG), ("all_to_all_v", SHARD_A2A),
+                ("destroy", SHARD_DESTROY)]
+
+
+_sig("clo_shard_rccl_unique_id", _u32, vp, _E)
+_sig("clo_shard_transport_new_rccl", C.POINTER(ShardTransportStruct), vp, ci, ci, _E)
+_sig("clo_shard_transport_destroy", None, C.POINTER(ShardTransportStruct))
+_sig("clo_shard_sort_new", vp, vp, C.POINTER(ShardTransportStruct), ci, C.c_char_p, _E)
+_sig("clo_shard_sort_destroy", None, vp)
+_sig("clo_shard_sort_with_device_data", vp, vp, vp, vp, sz, C.POINTER(vp), C.POINTER(sz), _E)
+_sig("clo_shard_sort_get_phase_ms", None, vp, C.POINTER(C.c_double * 4))
+_sig("clo_shard_plan", None, C.POINTER(C.c_uint64), ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
+
+
 class CloError(RuntimeError):
     """A GError reported by the library: .domain (string), .code, .message."""
 
@@ -394,6 +415,83 @@ class Scanner:
     def close(self):
         if self.h:
             lib.clo_scan_destroy(self.h)
+            self.h = None
+
+
+class ShardTransport:
+    """CloShardTransport: RCCL over xGMI (`ShardTransport.rccl(id, rank, world)`), or two Python
+    callables moving the same bytes (`ShardTransport.custom(rank, world, all_gather, all_to_all_v)`:
+    tests with two ranks on one GPU, where RCCL cannot be used)."""
+
+    def __init__(self, ptr, keep=None, owned=True):
+        self.ptr, self._keep, self._owned = ptr, keep, owned
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        err = _Err()
+        lib.clo_shard_rccl_unique_id(buf, err.ref)
+        err.raise_if_set()
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, unique_id, rank, world):
+        err = _Err()
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        p = lib.clo_shard_transport_new_rccl(buf, rank, world, err.ref)
+        err.raise_if_set()
+        if not p:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_shard_transport_new_rccl returned NULL")
+        return cls(p)
+
+    @classmethod
+    def custom(cls, rank, world, all_gather_u64, all_to_all_v):
+        """all_gather_u64(send_ptr, recv_ptr, count, stream) -> status;
+        all_to_all_v(send_ptr, send_bytes, send_off, recv_ptr, recv_bytes, recv_off, stream) -> status
+        (the four arrays as Python lists of `world` ints)."""
+        def ag(user, s, r, count, stream):
+            return int(all_gather_u64(s, r, count, stream) or 0)
+
+        def a2a(user, s, sb, so, r, rb, ro, stream):
+            return int(all_to_all_v(s, [sb[i] for i in range(world)], [so[i] for i in range(world)], r,
+                                    [rb[i] for i in range(world)], [ro[i] for i in range(world)], stream) or 0)
+        st = ShardTransportStruct(None, rank, world, SHARD_AG(ag), SHARD_A2A(a2a), SHARD_DESTROY())
+        return cls(C.pointer(st), keep=(st, ag, a2a), owned=False)
+
+    def close(self):
+        if self.ptr and self._owned:
+            lib.clo_shard_transport_destroy(self.ptr)
+        self.ptr = None
+
+
+class ShardSort:
+    """CloShardSort (include/clo_shard.h): MSD bucket exchange + local satradix behind the C API."""
+
+    def __init__(self, ctx, transport, elem_type, options=None):
+        err = _Err()
+        self.h = lib.clo_shard_sort_new(ctx.h, transport.ptr, clo_type(elem_type), _b(options), err.ref)
+        err.raise_if_set()
+        if not self.h:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_shard_sort_new returned NULL")
+        self.ctx, self.transport = ctx, transport
+
+    def with_device_data(self, q_exec, data_in, numel):
+        """-> (device pointer of this rank's sorted bucket, its length); the memory belongs to the object."""
+        out, m = vp(), sz(0)
+        err = _Err()
+        lib.clo_shard_sort_with_device_data(self.h, q_exec.h, data_in.h if data_in is not None else None, numel,
+                                            C.byref(out), C.byref(m), err.ref)
+        err.raise_if_set()
+        return lib.ccl_buffer_get_device_ptr(out), m.value
+
+    def phase_ms(self):
+        a = (C.c_double * 4)()
+        lib.clo_shard_sort_get_phase_ms(self.h, C.byref(a))
+        return dict(zip(("partition", "count_exchange", "key_exchange", "local_sort"), a))
+
+    def close(self):
+        if self.h:
+            lib.clo_shard_sort_destroy(self.h)
             self.h = None
 
 

@@ -320,3 +320,87 @@ class ShardedScanner:
         look-back spin (the output would be wrong)."""
         if hasattr(self.ops, "check"):
             self.ops.check()
+
+
+# ---------------------------------------------------------------------------
+# The same sharded sort behind the C API (include/clo_shard.h): partition, count
+# exchange, RCCL all-to-all(v) and local sort are driven by C (clo_shard.c); Python
+# only hands over device pointers and, once per process group, carries RCCL's
+# 128-byte id from rank 0 to the others.
+# ---------------------------------------------------------------------------
+
+class _DeviceView:
+    """Device memory owned by the C object, as something torch.as_tensor() can wrap without a copy."""
+
+    def __init__(self, ptr, count, elem_size):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<i%d" % elem_size, "data": (ptr, False), "version": 2}
+
+
+class CShardedSorter:
+    """Interface of ShardedSorter (sort(local, n) -> (tensor, m)), implementation in C over RCCL.
+    `transport`: a cl_ops_amd.ShardTransport to use instead of RCCL (tests)."""
+
+    PHASES = ShardedSorter.PHASES
+
+    def __init__(self, elem_type, device_index, group=None, options=None, transport=None):
+        import torch
+        import torch.distributed as dist
+        import cl_ops_amd as clo
+        self.torch, self.clo = torch, clo
+        if elem_type not in ("uint", "ulong"):
+            raise ValueError("the sharded sort handles unsigned 4- and 8-byte keys ('uint', 'ulong'), not %r" % (elem_type,))
+        self.elem_size = 4 if elem_type == "uint" else 8
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.ctx = clo.Context(device_index)
+        self._own_transport = transport is None
+        if transport is None:
+            if self.rank == 0:
+                uid = torch.frombuffer(bytearray(clo.ShardTransport.unique_id()), dtype=torch.uint8)
+            else:
+                uid = torch.zeros(128, dtype=torch.uint8)
+            if self.world > 1:
+                on_gpu = dist.get_backend(group) == "nccl"
+                t = uid.cuda() if on_gpu else uid
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = t.cpu()
+            transport = clo.ShardTransport.rccl(bytes(uid.numpy().tobytes()), self.rank, self.world)
+        self.transport = transport
+        self.ss = clo.ShardSort(self.ctx, transport, elem_type, options)
+        self._queues = {}
+        self.phase_times = None
+
+    @property
+    def queue(self):
+        s = self.torch.cuda.current_stream().cuda_stream
+        q = self._queues.get(s)
+        if q is None:
+            q = self._queues[s] = self.clo.Queue(self.ctx, stream=s)
+        return q
+
+    def sort(self, local, n=None):
+        n = local.numel() if n is None else n
+        buf = self.clo.Buffer(self.ctx, max(n, 1) * self.elem_size, device_ptr=local.data_ptr()) if n else None
+        try:
+            ptr, m = self.ss.with_device_data(self.queue, buf, n)
+        finally:
+            if buf is not None:
+                buf.close()
+        if self.phase_times is not None and self.world > 1:
+            for k, v in self.ss.phase_ms().items():      # (synchronises: phase legs only)
+                self.phase_times[k] = self.phase_times.get(k, 0.0) + v * 1e-3
+        if m == 0:
+            return self.torch.empty(0, dtype=local.dtype, device=local.device), 0
+        return self.torch.as_tensor(_DeviceView(ptr, m, self.elem_size), device=local.device).view(local.dtype), m
+
+    def collect_phase_times(self):
+        return dict(self.phase_times or {})
+
+    def close(self):
+        self.ss.close()
+        for q in self._queues.values():
+            q.close()
+        self._queues = {}
+        if self._own_transport:
+            self.transport.close()
+        self.ctx.close()

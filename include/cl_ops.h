@@ -10,5 +10,6 @@
 #include "clo_scan.h"
 #include "clo_sort.h"
 #include "clo_hip.h"
+#include "clo_shard.h"
 
 #endif

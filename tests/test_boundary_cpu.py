@@ -273,3 +273,29 @@ def test_workspace_sizes_are_sane():
     assert lib.clo_hip_scan_workspace_bytes(1 << 26, 4, 4) < 1 << 20
     assert lib.clo_hip_bitonic_padded_numel(1000) == 1024
     assert lib.clo_hip_error_string(-4).decode().startswith("clo_hip")
+
+
+def test_shard_plan_matches_the_python_plan():
+    """clo_shard_plan (C, include/clo_shard.h) == ShardedSorter.plan (cl_ops_amd/multigpu.py)."""
+    from cl_ops_amd.multigpu import ShardedSorter
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 4, 8):
+        m = rng.integers(0, 1000, (world, world), dtype=np.uint64)
+        arr = C.c_size_t * world
+        for r in range(world):
+            a, b, c, d = arr(), arr(), arr(), arr()
+            lib.clo_shard_plan(np.ascontiguousarray(m).ctypes.data_as(C.POINTER(C.c_uint64)), world, r, a, b, c, d)
+            sc, so, rc, ro = ShardedSorter.plan(m.astype(np.int64), r)
+            assert (list(a), list(b), list(c), list(d)) == (list(sc), list(so), list(rc), list(ro))
+
+
+def test_shard_sort_argument_errors(off):
+    tr = clo.ShardTransport.custom(0, 3, lambda *a: 0, lambda *a: 0)
+    with pytest.raises(clo.CloError) as e:
+        clo.ShardSort(off, tr, "uint")
+    assert e.value.code == CLO_ERROR_ARGS and "world size" in e.value.message
+    tr = clo.ShardTransport.custom(0, 2, lambda *a: 0, lambda *a: 0)
+    with pytest.raises(clo.CloError) as e:
+        clo.ShardSort(off, tr, "float")
+    assert e.value.code == CLO_ERROR_ARGS
+    clo.ShardSort(off, tr, "ulong", options="radix=256").close()

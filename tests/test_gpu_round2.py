@@ -311,3 +311,111 @@ def test_two_ranks_skewed_u64_2p27_each_on_one_gpu(gpu, tmp_path):
         exp = np.sort(np.concatenate([np.load(tmp_path / ("slice_in_%d.npy" % r)),
                                       np.load(tmp_path / ("slice_for_peer_%d.npy" % (1 - r)))]))
         assert np.array_equal(np.load(tmp_path / ("slice_out_%d.npy" % r)), exp)
+
+
+# ----------------------------------------------------------------------------
+# the sharded sort behind the C API (include/clo_shard.h)
+# ----------------------------------------------------------------------------
+
+def test_c_shard_sort_world_one_over_rccl(gpu):
+    """One rank: RCCL communicator of size 1 (id, init, destroy are the real calls), the
+    sort is a copy + local satradix; the input is left untouched."""
+    import torch
+    import cl_ops_amd as clo
+    from cl_ops_amd.multigpu import CShardedSorter
+    for et, dt, tdt in (("uint", np.uint32, np.int32), ("ulong", np.uint64, np.int64)):
+        a = np.random.default_rng(3).integers(0, np.iinfo(dt).max, 300007, dtype=dt, endpoint=True)
+        t = torch.from_numpy(a.view(tdt).copy()).cuda()
+        s = CShardedSorter(et, 0)
+        out, m = s.sort(t)
+        torch.cuda.synchronize()
+        assert m == a.size and np.array_equal(out.cpu().numpy().view(dt), np.sort(a))
+        assert np.array_equal(t.cpu().numpy().view(dt), a)
+        s.close()
+
+
+def _c_shard_worker(rank, world, port, n, out_dir):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import cl_ops_amd as clo
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    from cl_ops_amd.multigpu import CShardedSorter
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        # a transport that moves the same bytes through host memory over gloo (RCCL
+        # refuses two ranks on one device); everything else is the C code under test
+        def d2h(ptr, nbytes, stream):
+            h = np.empty(nbytes, dtype=np.uint8)
+            _hip.check(lib.clo_hip_memcpy_d2h_async(h.ctypes.data, ptr, nbytes, stream))
+            _hip.check(lib.clo_hip_stream_synchronize(stream))
+            return h
+
+        def h2d(ptr, h, stream):
+            h = np.ascontiguousarray(h)
+            _hip.check(lib.clo_hip_memcpy_h2d_async(ptr, h.ctypes.data, h.nbytes, stream))
+            _hip.check(lib.clo_hip_stream_synchronize(stream))
+
+        def all_gather(send, recv, count, stream):
+            mine = torch.from_numpy(d2h(send, 8 * count, stream))
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            h2d(recv, torch.cat(parts).numpy(), stream)
+            return 0
+
+        def all_to_all_v(send, sb, so, recv, rb, ro, stream):
+            hs = d2h(send, max(sum(sb), 1), stream) if sum(sb) else np.empty(0, np.uint8)
+            hr = np.empty(max(sum(rb), 1), dtype=np.uint8)
+            hr[ro[rank]:ro[rank] + rb[rank]] = hs[so[rank]:so[rank] + sb[rank]]
+            ops, keep = [], []
+            for k in range(1, world):
+                dst, src = (rank + k) % world, (rank - k) % world
+                if sb[dst]:
+                    t = torch.from_numpy(hs[so[dst]:so[dst] + sb[dst]].copy())
+                    keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, dst))
+                if rb[src]:
+                    t = torch.empty(rb[src], dtype=torch.uint8)
+                    keep.append((t, src))
+                    ops.append(dist.P2POp(dist.irecv, t, src))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            for x in keep:
+                if isinstance(x, tuple):
+                    hr[ro[x[1]]:ro[x[1]] + rb[x[1]]] = x[0].numpy()
+            if sum(rb):
+                h2d(recv, hr[:sum(rb)], stream)
+            return 0
+
+        tr = clo.ShardTransport.custom(rank, world, all_gather, all_to_all_v)
+        a = np.random.default_rng(70 + rank).integers(0, np.iinfo(np.uint64).max, n + 1000 * rank, dtype=np.uint64, endpoint=True)
+        if rank == 1:
+            a[: a.size // 2] |= np.uint64(1) << np.uint64(63)      # uneven buckets
+        local = torch.from_numpy(a.view(np.int64).copy()).cuda()
+        s = CShardedSorter("ulong", 0, transport=tr)
+        for _ in range(2):                                          # the second call reuses every buffer
+            out, m = s.sort(local)
+            torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), a)
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), out.cpu().numpy().view(np.uint64)[:m])
+        assert np.array_equal(local.cpu().numpy().view(np.uint64), a)
+        s.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c_shard_sort_two_ranks_on_one_gpu(gpu, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_c_shard_worker, args=(2, port, 200000, str(tmp_path)), nprocs=2, join=True)
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(2)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)]
+    assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
+    assert np.all(outs[0] >> np.uint64(63) == 0) and np.all(outs[1] >> np.uint64(63) == 1)
