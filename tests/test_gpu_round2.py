@@ -114,18 +114,24 @@ def test_profiling_queue_gets_one_event_per_kernel(gpu):
     n = 1 << 20
     a = O.bench_rand(0, "uint", n)
     src = clo.Buffer(ctx, n * 4)
-    src.write(qp, a)
-    clo.Profiler(qp).duration_ns()          # (drop the copy's event)
-
     s = clo.Sorter("satradix", ctx, "uint")
-    s.with_device_data(qp, src, None, n)
-    prof = clo.Profiler(qp)
-    total = prof.duration_ns()
-    agg = prof.aggregates()
-    assert set(agg) == {"satradix_histogram", "clo_scan_blelloch_wgscan", "satradix_scatter"}, agg
-    assert sum(agg.values()) == total and all(v > 0 for v in agg.values())
-    assert np.array_equal(src.read(qp, np.uint32, n), np.sort(a))
+    # 2^18 elements: chain-free passes (histogram, counter scan, scatter per digit pair);
+    # 2^20: single-sweep passes (one up-front histogram, then scatters that hand the
+    # counts from tile to tile: no counter-scan kernel)
+    for m, names in ((1 << 18, {"satradix_histogram", "clo_scan_blelloch_wgscan", "satradix_scatter"}),
+                     (n, {"satradix_histogram", "satradix_scatter"})):
+        src.write(qp, a[:m])
+        clo.Profiler(qp).duration_ns()          # (drop the copy's event)
+        s.with_device_data(qp, src, None, m)
+        prof = clo.Profiler(qp)
+        total = prof.duration_ns()
+        agg = prof.aggregates()
+        assert set(agg) == names, (m, agg)
+        assert sum(agg.values()) == total and all(v > 0 for v in agg.values())
+        assert np.array_equal(src.read(qp, np.uint32, m), np.sort(a[:m]))
+        prof.close()
     s.close()
+    prof = clo.Profiler(qp)
 
     sc = clo.Scanner("blelloch", ctx, "uint", "uint")
     dst = clo.Buffer(ctx, n * 4)
