@@ -13,6 +13,19 @@ for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic sbitonic; do
 	python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
 	echo "bench $w done"
 done
+# the single-sweep passes forced on for the headline size (the library uses them for 2^20..2^23 elements by itself)
+CLO_RADIX_SWEEP=1 python3 "$ROOT/bench.py" --workload satradix_u32 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_satradix_u32_sweep.json" 2> "$OUT/bench_satradix_u32_sweep.err" || exit 1
+CLO_RADIX_SWEEP=1 python3 "$ROOT/bench.py" --workload satradix_u64 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_satradix_u64_sweep.json" 2> "$OUT/bench_satradix_u64_sweep.err" || exit 1
+echo "bench sweep done"
+export CLO_RADIX_SWEEP=1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_satradix_u32_sweep" --output-format csv -- \
+	python3 "$ROOT/bench.py" --workload satradix_u32 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_satradix_u32_sweep.json" 2> "$OUT/trace_satradix_u32_sweep.log" || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+	rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_satradix_u32_sweep" --output-format csv -- \
+		python3 "$ROOT/bench.py" --workload satradix_u32 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${c}_satradix_u32_sweep.json" 2> "$OUT/pmc_${c}_satradix_u32_sweep.log" || exit 1
+done
+unset CLO_RADIX_SWEEP
+echo "trace + pmc sweep done"
 for w in satradix_u32 satradix_pairs scan abitonic; do
 	rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" --output-format csv -- \
 		python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_$w.json" 2> "$OUT/trace_$w.log" || exit 1
@@ -34,3 +47,7 @@ B="$ROOT/benchmarks/bin"
 "$B/clo_hip_sort_bench" -a gselect -t uint -n 16 -r 5 > "$OUT/harness_gselect.txt" 2>&1 || exit 1
 "$B/clo_hip_scan_bench" -t uint -y uint -n 27 -r 5 > "$OUT/harness_scan.txt" 2>&1 || exit 1
 echo "harness sweeps done"
+python3 "$ROOT/tools/sweep_sizes.py" > "$OUT/sweep_sizes.txt" 2>&1 || exit 1
+python3 "$ROOT/tools/sweep_probe.py" 28 u32 > "$OUT/sweep_probe_u32.txt" 2>&1 || exit 1
+python3 "$ROOT/tools/sweep_probe.py" 28 u64 > "$OUT/sweep_probe_u64.txt" 2>&1 || exit 1
+echo "sweep probes done"

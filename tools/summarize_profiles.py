@@ -20,7 +20,8 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
     line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
     open(os.path.join(dst, "%s_%s" % (tag, os.path.basename(f))), "w").write(line + "\n")
 
-names = {"satradix_u32": "satradix_u32_2p28", "satradix_pairs": "satradix_pairs", "scan": "scan", "abitonic": "abitonic"}
+names = {"satradix_u32": "satradix_u32_2p28", "satradix_pairs": "satradix_pairs", "scan": "scan", "abitonic": "abitonic",
+         "satradix_u32_sweep": "satradix_u32_2p28_sweep"}
 for w, out in names.items():
     st = glob.glob(os.path.join(src, "trace_" + w, "*", "*kernel_stats.csv"))
     if st:
@@ -99,6 +100,26 @@ if pas:
                "correction": "FETCH_SIZE x2 (gfx950; calibrated on the histogram kernel in the same run: factor %.3f), WRITE_SIZE as is" % calib,
                "source": "profiles/" + os.path.basename(path)},
               open(os.path.join(dst, "traffic_satradix_u32.json"), "w"), indent=1)
+# the single-sweep passes (CLO_RADIX_SWEEP=1 runs): own table, families merged into the same JSON
+try:
+    srows = traffic_rows("satradix_u32_sweep")
+    spath = os.path.join(dst, "%s_satradix_u32_2p28_sweep_pmc_hbm_traffic.csv" % tag)
+    with open(spath, "w") as o:
+        o.write(HEADER % ("satradix_u32 (CLO_RADIX_SWEEP=1)", "(Same x2 as calibrated on the histogram kernel of the chain-free run.)"))
+        for r in srows:
+            o.write("%s,%d,%.0f,%.0f,%d\n" % r)
+    tj = os.path.join(dst, "traffic_satradix_u32.json")
+    d = json.load(open(tj))
+    d["families"].update(families(srows, None))
+    json.dump(d, open(tj, "w"), indent=1)
+    for r in srows[:4]:
+        print("sweep", r)
+except ValueError:
+    pass
+for extra in ("sweep_sizes.txt", "sweep_probe_u32.txt", "sweep_probe_u64.txt"):
+    f = os.path.join(src, extra)
+    if os.path.exists(f):
+        open(os.path.join(dst, "%s_%s" % (tag, extra)), "w").write("".join(l for l in open(f) if "amdgpu.ids" not in l))
 print("profiles/ refreshed from", src)
 for r in rows[:6]:
     print(r)
