@@ -256,7 +256,7 @@ static int queue_check_status(CCLQueue* cq, GError** err) {
 			c->tripped = 1;
 			clo_hip_memset_async(c->dev_word, 0, sizeof(unsigned), cq->stream);
 			if (ok) clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY,
-				"A scan kernel gave up waiting for another work-group's prefix (bounded look-back spin): "
+				"A kernel gave up waiting for another work-group's counts (bounded look-back spin): "
 				"the data this queue produced since its last synchronisation is not valid");
 			ok = 0;
 		} else if (st != 0 && ok) {

@@ -200,8 +200,13 @@ static void sort_warmup(CloSort* sorter, const char* type, size_t elem_size) {
 	for (int i = 0; i < 4; ++i) if (strcmp(type, kinds[i]) == 0) k = i;
 	if (k < 0 || done[k][e]) return;
 	done[k][e] = 1;
-	const size_t sizes[2] = { 16, k == 0 ? 20000 : (k == 3 ? 2048 : 32768) };
-	for (int i = 0; i < 2; ++i) {
+	/* satradix has three families of kernels, each in a code object of its own:
+	 * the one-launch sort (<= 2^14 elements), the chain-free passes, and the
+	 * single-sweep passes the library uses from 128 tiles on (4 MiB of elements) */
+	const size_t sizes[3] = { 16, k == 0 ? 20000 : (k == 3 ? 2048 : 32768),
+		k == 0 && elem_size >= 4 ? ((size_t) 4 << 20) / elem_size : 0 };
+	for (int i = 0; i < 3; ++i) {
+		if (sizes[i] == 0) continue;
 		void* in = calloc(sizes[i], elem_size);
 		void* out = malloc(sizes[i] * elem_size);
 		GError* err = NULL;

@@ -115,9 +115,11 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 			data->ws_ready = data->workspace.ptr;
 			data->ws_ready_bytes = data->workspace.bytes;
 		}
+		/* the queues that watch this sorter's status word must never be left with the
+		 * address of a workspace that has been reallocated since */
+		clo_status_cell_set_word(data->status, data->workspace.ptr);
 		if (clo_hip_radix_polls(numel, jit ? 8 : ks->elem_size, bits_in_digit)) {
 			/* tile-to-tile look-back inside the passes: a give-up must not pass as success */
-			clo_status_cell_set_word(data->status, data->workspace.ptr);
 			if (clo_status_cell_take_tripped(data->status)) clo_debug("SATRADIX: the previous sort on this sorter gave up a spin");
 			ccl_queue_watch_status(cq_exec, data->status);
 		}

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic sbitonic; do
-	python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
+	python3 "$ROOT/bench.py" --workload $w --steps 30 --warmup 3 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
 	echo "bench $w done"
 done
 # the single-sweep passes forced on for the headline size (the library uses them for 2^20..2^23 elements by itself)
