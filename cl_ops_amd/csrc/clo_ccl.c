@@ -34,6 +34,7 @@ struct ccl_event {
 	char name[48];
 	void* start;             /* hip events; start only when profiling */
 	void* end;
+	int start_borrowed;      /* start is the `end` of the command before (a chain of kernels): not ours to destroy */
 };
 
 /* A device status word some kernel of this queue's commands may raise (the
@@ -207,7 +208,7 @@ void ccl_queue_gc(CCLQueue* cq) {
 	struct ccl_event* e = cq->events;
 	while (e) {
 		struct ccl_event* next = e->next;
-		clo_hip_event_destroy(e->start);
+		if (!e->start_borrowed) clo_hip_event_destroy(e->start);
 		clo_hip_event_destroy(e->end);
 		free(e);
 		e = next;
@@ -299,19 +300,30 @@ void* ccl_queue_get_stream(CCLQueue* cq) { return cq ? cq->stream : NULL; }
 int ccl_queue_is_profiling(CCLQueue* cq) { return cq ? cq->profiling : 0; }
 
 static void event_free(struct ccl_event* e) {
-	clo_hip_event_destroy(e->start);
+	if (!e->start_borrowed) clo_hip_event_destroy(e->start);
 	clo_hip_event_destroy(e->end);
 	free(e);
 }
 
 CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err) {
+	return ccl_queue_begin_command_after(cq, name, NULL, err);
+}
+
+/* `after` (may be NULL): the command enqueued right before this one on the same
+ * queue, of the same group of launches. On a profiling queue the new command's
+ * time then runs from `after`'s end — one marker between two kernels instead of
+ * two, and the durations of the group add up to its span exactly. */
+CCLEvent* ccl_queue_begin_command_after(CCLQueue* cq, const char* name, CCLEvent* after, GError** err) {
 	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }
 	if (!use_device(cq->ctx, err)) return NULL;
 	struct ccl_event* e = (struct ccl_event*) calloc(1, sizeof(*e));
 	if (!e) return NULL;
 	ccl_event_set_name(e, name);
 	if (hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) { free(e); return NULL; }
-	if (cq->profiling) {
+	if (cq->profiling && after != NULL && after->cq == cq && after->end != NULL) {
+		e->start = after->end;
+		e->start_borrowed = 1;
+	} else if (cq->profiling) {
 		if (hip_failed(clo_hip_event_create(&e->start), err, "hipEventCreate")
 			|| hip_failed(clo_hip_event_record(e->start, cq->stream), err, "hipEventRecord")) {
 			clo_hip_event_destroy(e->start);

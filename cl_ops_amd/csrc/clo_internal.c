@@ -73,7 +73,7 @@ static void kernel_events_observer(void* user, const char* label, int phase, voi
 		const char* name = ke->other;
 		for (size_t i = 0; i < ke->nmap; ++i)
 			if (strcmp(ke->map[i].label, label) == 0) { name = ke->map[i].name; break; }
-		ke->open = ccl_queue_begin_command(ke->cq, name, NULL);
+		ke->open = ccl_queue_begin_command_after(ke->cq, name, ke->last, NULL);
 		if (!ke->open) ke->failed = 1;
 	} else if (ke->open) {
 		if (!ccl_queue_end_command(ke->cq, ke->open, NULL)) {

@@ -174,7 +174,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	static_assert(R2 <= R1_ROW && R2 <= THREADS, "one thread per combined digit");
 	static_assert(THREADS >= 2 * R1_ROW, "the digit threads are the second half of the work-group");
 
-	__shared__ E s_stage[TILE];
+	__shared__ __attribute__((aligned(16))) E s_stage[TILE];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][HMAX];
 	__shared__ unsigned s_wbase[WAVES][HMAX];

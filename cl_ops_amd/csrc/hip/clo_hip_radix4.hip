@@ -61,7 +61,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
 	static_assert(R2 <= 256 && R2 <= THREADS, "one thread per combined digit, scanned by the first four waves");
 
-	__shared__ E s_stage[TILE];
+	__shared__ __attribute__((aligned(16))) E s_stage[TILE];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][HMAX];
 	__shared__ unsigned s_wbase[WAVES][HMAX];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(THREADS)
 void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift, unsigned key_bits, clo_keyx kx) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
-	__shared__ E s_stage[THREADS * ITEMS];
+	__shared__ __attribute__((aligned(16))) E s_stage[THREADS * ITEMS];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][H];
 	__shared__ unsigned s_wbase[WAVES][H];
@@ -196,8 +196,22 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 		const unsigned bits = key_bits - done < (unsigned) BITS ? key_bits - done : (unsigned) BITS;
 		pc_local_split<E, BITS, THREADS, ITEMS, H>(key, key_shift + done, (1u << bits) - 1u, n,
 			s_stage, s_end, s_wtot, s_wbase);
-		#pragma unroll
-		for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) key[i] = s_stage[tbase + i];
+		// the thread's slice back into registers, as 16-byte LDS reads where the slice
+		// is that long (element-wise reads at this lane stride conflict 8-way); slots
+		// past n hold nothing anyone looks at
+		if constexpr (ITEMS * sizeof(E) >= 16) {
+			constexpr int PER = 16 / (int) sizeof(E);
+			typedef E vec16 __attribute__((ext_vector_type(PER)));
+			#pragma unroll
+			for (int k = 0; k < ITEMS / PER; ++k) {
+				const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) key[k * PER + q] = t[q];
+			}
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) key[i] = s_stage[tbase + i];
+		}
 	}
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) if (tbase + i < n) out[tbase + i] = clo_keyx_inv<E>(key[i], kx);

@@ -138,6 +138,9 @@ const CCLProfAgg* ccl_prof_iter_agg_next(CCLProf* prof);
  * whose command could not be enqueued is taken back with ccl_queue_abort_command
  * (it would otherwise sit in the queue with an `end` that was never recorded). */
 CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err);
+/* The same for a command that follows `after` directly in a group of launches:
+ * its profiled time starts where `after` ended (one marker between two kernels). */
+CCLEvent* ccl_queue_begin_command_after(CCLQueue* cq, const char* name, CCLEvent* after, GError** err);
 cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err);
 void ccl_queue_abort_command(CCLQueue* cq, CCLEvent* evt);
 int ccl_queue_is_profiling(CCLQueue* cq);
