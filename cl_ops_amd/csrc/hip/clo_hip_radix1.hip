@@ -63,11 +63,6 @@ __device__ __forceinline__ void r1_st32(unsigned* p, unsigned v) {
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Speed only.
-__device__ __forceinline__ unsigned r1_xcc_id() {
-	return (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
-}
-
 // ---------------------------------------------------------------------------
 // Global digit totals of every pass: one read of the source.
 // ---------------------------------------------------------------------------
@@ -207,7 +202,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
 	if (tid == 0) {
 		const unsigned nchunks = (P.tiles + R1_CHUNK - 1u) >> R1_CHUNK_LOG;
-		const unsigned x = r1_xcc_id();
+		const unsigned x = clo_xcc_id();
 		unsigned tile = 0xffffffffu;
 		for (unsigned t = 0; t < (unsigned) R1_POOLS; ++t) {
 			const unsigned pool = (x + t) & (R1_POOLS - 1);
@@ -442,7 +437,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		clo_u64* st = P.stamps + (size_t) tile * 8;
 		st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3; st[4] = t4; st[5] = t5;
 		st[6] = __builtin_amdgcn_s_memtime();
-		st[7] = ((clo_u64) r1_xcc_id() << 32) | blockIdx.x;
+		st[7] = ((clo_u64) clo_xcc_id() << 32) | blockIdx.x;
 	}
 }
 

@@ -221,6 +221,11 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 	clo_lds_barrier();
 }
 
+// XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Used for speed only.
+__device__ __forceinline__ unsigned clo_xcc_id() {
+	return (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+}
+
 // Shape of a tile of the pass kernels: 512 threads x 16 consecutive elements
 // (8 for 8-byte elements) = 32 KiB of LDS stage either way.
 template <typename E> struct pair_shape {

@@ -49,20 +49,24 @@ FAMILY_OF = (("pair_kernel", "radix_pass"), ("tilehist", "radix_hist"), ("chunks
 
 
 def families(rows, launches_of):
-    """HBM bytes per launch of each kernel family: the kernels of a family that run once per
-    family launch (the three counter-scan kernels) add up; `launches_of` = launches of the
-    family's leading kernel in the profiled run."""
+    """HBM bytes per launch of each kernel family. Template instances of ONE kernel are
+    alternatives (averaged over their launches); DIFFERENT kernels of a family run once each
+    per family launch (the three counter-scan kernels) and add up."""
     acc = {}
     for name, n, f, w, b in rows:
         fam = next((lab for needle, lab in FAMILY_OF if needle in name), None)
         if fam is None:
             continue
-        d = acc.setdefault(fam, {"kernels": [], "bytes_total": 0, "launches": 0})
+        base = name.split("<")[0]
+        d = acc.setdefault(fam, {}).setdefault(base, {"kernels": [], "bytes_total": 0, "launches": 0})
         d["kernels"].append(name)
         d["bytes_total"] += b * n
-        d["launches"] = max(d["launches"], n)
-    return {fam: {"kernels": d["kernels"], "hbm_bytes_per_launch": int(d["bytes_total"] / d["launches"])}
-            for fam, d in acc.items() if d["launches"]}
+        d["launches"] += n
+    out = {}
+    for fam, bases in acc.items():
+        out[fam] = {"kernels": [k for d in bases.values() for k in d["kernels"]],
+                    "hbm_bytes_per_launch": int(sum(d["bytes_total"] / d["launches"] for d in bases.values() if d["launches"]))}
+    return out
 
 
 def traffic_rows(workload):
