@@ -69,7 +69,8 @@ __device__ __forceinline__ void r1_st32(unsigned* p, unsigned v) {
 template <typename E, int NP>
 __global__ __launch_bounds__(R1_GH_THREADS)
 void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_shift, unsigned key_bits,
-	unsigned* __restrict__ ghist, int aligned, clo_keyx kx, unsigned tiles_per_group) {
+	unsigned* __restrict__ ghist, unsigned* __restrict__ gbase, unsigned* __restrict__ done,
+	int aligned, clo_keyx kx, unsigned tiles_per_group) {
 	constexpr int ITEMS = pair_shape<E>::ITEMS;
 	constexpr int TILE = R1_GH_THREADS * ITEMS;
 	// Counters: 16-bit, two digits per dword, COPIES copies of every dword (copy = lane
@@ -120,21 +121,32 @@ void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_sh
 		if (even) atomicAdd(&ghist[2 * i], even);
 		if (odd) atomicAdd(&ghist[2 * i + 1], odd);
 	}
-}
-
-// Digit totals -> digit starts (exclusive scan over the 256 digits), one work-group per pass.
-__global__ __launch_bounds__(R1_ROW)
-void clo_radix1_bases_kernel(const unsigned* __restrict__ ghist, unsigned* __restrict__ gbase) {
-	__shared__ unsigned s_w[4];
-	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const unsigned v = ghist[blockIdx.x * R1_ROW + tid];
-	const unsigned incl = clo_wave_scan_inclusive<unsigned>(v, lane);
-	if (lane == 63) s_w[wave] = incl;
+	// The work-group that finishes last turns the totals into digit starts (an
+	// exclusive scan over the 256 digits of every pass): no kernel of its own.
+	__shared__ unsigned s_last, s_w[4];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this group's adds before its arrival
 	__syncthreads();
-	unsigned b = incl - v;
-	#pragma unroll
-	for (unsigned w = 0; w < 4; ++w) if (w < wave) b += s_w[w];
-	gbase[blockIdx.x * R1_ROW + tid] = b;
+	if (tid == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u;
+	__syncthreads();
+	if (!s_last) return;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	const unsigned lane = tid & 63u, wave = tid >> 6;
+	for (int p = 0; p < NP; ++p) {
+		unsigned v = 0, incl = 0;
+		if (tid < (unsigned) R1_ROW) {
+			v = __hip_atomic_load(&ghist[p * R1_ROW + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			incl = clo_wave_scan_inclusive<unsigned>(v, lane);
+			if (lane == 63) s_w[wave] = incl;
+		}
+		__syncthreads();
+		if (tid < (unsigned) R1_ROW) {
+			unsigned b = incl - v;
+			#pragma unroll
+			for (unsigned w = 0; w < 4; ++w) if (w < wave) b += s_w[w];
+			gbase[p * R1_ROW + tid] = b;
+		}
+		__syncthreads();
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -444,7 +456,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct r1_layout { size_t ghist, gbase, tickets, pass0, per_pass, agg, cacc, cprefix, total, tiles, chunks; int passes; };
+struct r1_layout { size_t ghist, gbase, tickets, done, pass0, per_pass, agg, cacc, cprefix, total, tiles, chunks; int passes; };
 
 int r1_chunk_log() {   // CLO_R1_CHUNK_LOG: 3 or 4 (A/B measurements)
 	const char* m = getenv("CLO_R1_CHUNK_LOG");
@@ -463,6 +475,7 @@ r1_layout r1_make_layout(size_t n, int elem_size, int key_bits) {
 	L.ghist = off; off += (size_t) L.passes * R1_ROW * sizeof(unsigned);
 	L.gbase = off; off += (size_t) L.passes * R1_ROW * sizeof(unsigned);
 	L.tickets = off; off += (size_t) L.passes * R1_POOLS * R1_TICKET_STRIDE * sizeof(unsigned);
+	L.done = off; off += 64;
 	off = (off + 255) & ~(size_t) 255;
 	L.pass0 = off;
 	L.agg = 0;
@@ -477,12 +490,13 @@ clo_u64* g_r1_stamps = nullptr;   // diagnostic (clo_hip_radix_debug_stamps)
 size_t g_r1_stamps_tiles = 0;
 
 template <typename E, int NP>
-void r1_launch_ghist(const E* src, size_t n, int key_shift, int key_bits, unsigned* ghist, clo_keyx kx, unsigned tiles, hipStream_t s) {
+void r1_launch_ghist(const E* src, size_t n, int key_shift, int key_bits, unsigned* ghist, unsigned* gbase, unsigned* done,
+	clo_keyx kx, unsigned tiles, hipStream_t s) {
 	unsigned per = tiles > 4096u ? (tiles + 2047u) / 2048u : (tiles > 256u ? 2u : 1u);
 	if (per > 16u) per = 16u;   // (16-bit counters: at most 16 tiles between flushes)
 	const unsigned groups = (tiles + per - 1u) / per;
 	hipLaunchKernelGGL((clo_radix1_ghist_kernel<E, NP>), dim3(groups), dim3(R1_GH_THREADS), 0, s,
-		src, n, (unsigned) key_shift, (unsigned) key_bits, ghist, (int) ((uintptr_t) src % 16 == 0), kx, per);
+		src, n, (unsigned) key_shift, (unsigned) key_bits, ghist, gbase, done, (int) ((uintptr_t) src % 16 == 0), kx, per);
 }
 
 template <typename E>
@@ -507,12 +521,11 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	{
 		clo_timing_scope timing("radix_ghist", s);
 		switch (passes) {
-			#define CLO_R1_GH(NP) case NP: r1_launch_ghist<E, NP>(src, n, key_shift, key_bits, ghist, kx, tiles, s); break
+			#define CLO_R1_GH(NP) case NP: r1_launch_ghist<E, NP>(src, n, key_shift, key_bits, ghist, gbase, (unsigned*) (w + L.done), kx, tiles, s); break
 			CLO_R1_GH(1); CLO_R1_GH(2); CLO_R1_GH(3); CLO_R1_GH(4); CLO_R1_GH(5); CLO_R1_GH(6); CLO_R1_GH(7); CLO_R1_GH(8);
 			#undef CLO_R1_GH
 			default: return CLO_HIP_EUNSUPPORTED;
 		}
-		hipLaunchKernelGGL(clo_radix1_bases_kernel, dim3(passes), dim3(R1_ROW), 0, s, (const unsigned*) ghist, gbase);
 	}
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
 	const E* cur_in = src;
@@ -564,14 +577,14 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
-	// The library's choice (measured): between 128 and 1024 tiles
-	// (2^20 .. 2^23 4-byte elements) the sweeps take 15-40 % less time than the
-	// chain-free passes — 7 launches instead of 12 at sizes that are launch-bound,
-	// and a look-back over few tiles; above that the two are within 3 % of each other
+	// The library's choice (measured): from 4 to 1024 tiles (2^15 ..
+	// 2^23 4-byte elements) the sort is launch-bound and the sweeps need 6 launches
+	// instead of 12: the same time up to 2^18, 10-40 % less from 2^19 on (and half
+	// the events on a profiling queue); above that the two are within 3 % of each other
 	// (the sweep's tile histogram and its one exposed round trip cost what the
 	// separate histogram kernel costs), and the chain-free passes keep the sort free
 	// of any wait between work-groups.
-	return tiles >= 128 && tiles <= 1024;
+	return tiles >= 4 && tiles <= 1024;
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

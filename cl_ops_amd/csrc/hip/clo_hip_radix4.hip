@@ -170,180 +170,6 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 }
 
 // ---------------------------------------------------------------------------
-// The same pass as a STREAMING kernel: as many work-groups as the chip holds, each
-// drawing tiles by ticket, with the NEXT tile's keys and counters requested
-// before the current tile is scattered — the key registers are free once the
-// second split has written the stage, so the ~2 500 ticks a tile waits for its
-// loads (a tenth of its life) run under the scatter of the tile before.
-// Tickets come from one counter per XCD over that XCD's contiguous range of
-// tiles (the mapping of the kernel above): tiles in flight behind one L2 stay
-// neighbours however the groups drift. (Round 1's persistent variant walked its
-// range with a fixed stride per group: the groups drifted apart, the neighbours
-// were gone, 3.74 ms.) Tiles are independent, so any hand-out order is correct;
-// the ticket for the next tile is drawn before the splits and read after them.
-// ---------------------------------------------------------------------------
-constexpr int RP_TICKET_STRIDE = 16;   // words between the XCD pools' counters (one 64-byte line each)
-constexpr unsigned RP_NONE = 0xffffffffu;
-
-template <typename E, int LB, int HB>
-__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)
-void clo_radix4_pair_stream_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
-	unsigned shift, unsigned mask_lo, unsigned mask_hi,
-	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
-	clo_keyx kx_in, clo_keyx kx_out, unsigned* __restrict__ tickets, unsigned tiles) {
-
-	constexpr int THREADS = pair_shape<E>::THREADS;
-	constexpr int ITEMS = pair_shape<E>::ITEMS;
-	constexpr int TILE = THREADS * ITEMS;
-	constexpr int WAVES = THREADS / 64;
-	constexpr int R2 = 1 << (LB + HB);
-	constexpr int HMAX = pc_words<(LB > HB ? LB : HB)>::H;
-	static_assert(R2 <= 256 && R2 <= THREADS, "one thread per combined digit, scanned by the first four waves");
-
-	__shared__ __attribute__((aligned(16))) E s_stage[TILE];
-	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
-	__shared__ unsigned s_wtot[WAVES][HMAX];
-	__shared__ unsigned s_wbase[WAVES][HMAX];
-	__shared__ unsigned s_delta[R2];
-	__shared__ unsigned s_w4[4];
-	__shared__ unsigned s_next;
-
-	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-	const unsigned per_xcd = (tiles + 7u) / 8u;
-	const unsigned mask2 = (mask_hi << LB) | mask_lo;
-	const unsigned n32 = n > 0xffffffffull ? 0xffffffffu : (unsigned) n;
-	const unsigned tbase = tid * ITEMS;
-	const unsigned xcc = clo_xcc_id();
-
-	// ticket k of pool p is tile p * per_xcd + k; an exhausted pool sends its groups to the next one
-	auto tile_of = [&](unsigned pool, unsigned k) -> unsigned {
-		const unsigned t = pool * per_xcd + k;
-		return (k < per_xcd && t < tiles) ? t : RP_NONE;
-	};
-	auto steal = [&]() -> unsigned {   // (thread 0, rarely: the own pool has run dry)
-		for (unsigned t = 1; t < 8u; ++t) {
-			const unsigned pool = (xcc + t) & 7u;
-			const unsigned cand = tile_of(pool, atomicAdd(&tickets[pool * RP_TICKET_STRIDE], 1u));
-			if (cand != RP_NONE) return cand;
-		}
-		return RP_NONE;
-	};
-
-	if (tid == 0) {
-		unsigned t = tile_of(xcc, atomicAdd(&tickets[xcc * RP_TICKET_STRIDE], 1u));
-		if (t == RP_NONE) t = steal();
-		s_next = t;
-	}
-	clo_lds_barrier();
-	unsigned tile = s_next;
-	if (tile == RP_NONE) return;
-
-	unsigned h2 = 0, goff = 0;
-	E key[ITEMS];
-	auto request = [&](unsigned t) {   // counters first, then the keys
-		const size_t b = (size_t) t * TILE;
-		if (tid < (unsigned) R2) {
-			h2 = thist[(size_t) t * R2 + tid];
-			goff = toff[(size_t) t * R2 + tid];
-		}
-		if (b + TILE <= n) {
-			load_blocked<E, ITEMS>(in + b + tbase, key, aligned != 0);
-		} else {
-			#pragma unroll
-			for (int i = 0; i < ITEMS; ++i) key[i] = (b + tbase + i < n) ? in[b + tbase + i] : (E) 0;
-		}
-	};
-	request(tile);
-
-	for (;;) {
-		const size_t base = (size_t) tile * TILE;
-		const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-		const bool full = count == (unsigned) TILE;
-		// the next ticket: asked for now, looked at after the first split
-		unsigned k_next = 0;
-		if (tid == 0) k_next = atomicAdd(&tickets[xcc * RP_TICKET_STRIDE], 1u);
-
-		if (kx_in.kind) {
-			#pragma unroll
-			for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
-		}
-		const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
-		if (lane == 63 && wave < 4) s_w4[wave] = incl2;
-
-		pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
-
-		if (tid < (unsigned) R2) {
-			unsigned dstart2 = incl2 - h2;
-			#pragma unroll
-			for (unsigned w = 0; w < 4; ++w) if (w < wave) dstart2 += s_w4[w];
-			s_delta[tid] = goff - dstart2;
-		}
-		if (tid == 0) {
-			unsigned t = tile_of(xcc, k_next);
-			if (t == RP_NONE) t = steal();
-			s_next = t;
-		}
-		if (full) {
-			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
-			typedef E vec16 __attribute__((ext_vector_type(PER)));
-			#pragma unroll
-			for (int k = 0; k < ITEMS / PER; ++k) {
-				const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
-				#pragma unroll
-				for (int q = 0; q < PER; ++q) key[k * PER + q] = t[q];
-			}
-		} else {
-			#pragma unroll
-			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
-		}
-		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase);
-
-		// the stage holds the tile in order and the key registers are free: ask for the next tile
-		const unsigned nxt = s_next;
-		if (nxt != RP_NONE) request(nxt);
-
-		constexpr int VEC = sizeof(E) >= 8 ? 1 : 4;
-		typedef E vecE __attribute__((ext_vector_type(VEC)));
-		typedef E vecE_u __attribute__((ext_vector_type(VEC), aligned(sizeof(E))));
-		#pragma unroll
-		for (int j = 0; j < ITEMS / VEC; ++j) {
-			const unsigned p = (j * THREADS + tid) * VEC;
-			if (full) {
-				const vecE v = *reinterpret_cast<const vecE*>(&s_stage[p]);
-				const unsigned d0 = (unsigned) (v[0] >> shift) & mask2, dl = (unsigned) (v[VEC - 1] >> shift) & mask2;
-				const unsigned gi0 = p + s_delta[d0];
-				if (d0 == dl && gi0 <= n32 - VEC) {
-					vecE vo = v;
-					if (kx_out.kind) {
-						#pragma unroll
-						for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(v[k], kx_out);
-					}
-					*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
-				} else {
-					#pragma unroll
-					for (int k = 0; k < VEC; ++k) {
-						const unsigned gi = p + k + s_delta[(unsigned) (v[k] >> shift) & mask2];
-						if (gi < n32) out[gi] = clo_keyx_inv<E>(v[k], kx_out);
-					}
-				}
-			} else {
-				#pragma unroll
-				for (int k = 0; k < VEC; ++k) {
-					if (p + k < count) {
-						const E e = s_stage[p + k];
-						const unsigned gi = p + k + s_delta[(unsigned) (e >> shift) & mask2];
-						if (gi < n32) out[gi] = clo_keyx_inv<E>(e, kx_out);
-					}
-				}
-			}
-		}
-		if (nxt == RP_NONE) return;
-		tile = nxt;
-		clo_lds_barrier();   // (the stage and the deltas have been read by everyone before the next tile touches them)
-	}
-}
-
-// ---------------------------------------------------------------------------
 // Arrays of at most one tile: every digit inside ONE work-group, one launch for
 // the whole sort (upstream's harness sweeps sizes from 2^4 up; a multi-kernel
 // sort costs a dozen dependent launches however small the array). One local
@@ -400,8 +226,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 // Per pass: histogram of the combined digit -> counter scan -> pass kernel.
 // A requested digit width b <= 4 pairs two digits (LB = HB = b); a wider digit
 // is one pass, split in two halves.
-struct rp_layout { size_t thist, toff, partial, tickets, total, tiles; };
-constexpr int RP_MAX_PASSES = 64;   // ticket counters for up to 64 passes (1-bit digits on 64-bit keys: 32 pair passes)
+struct rp_layout { size_t thist, toff, partial, total, tiles; };
 
 rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {
 	rp_layout L;
@@ -413,8 +238,7 @@ rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {
 	L.thist = CLO_WS_HEADER_BYTES;
 	L.toff = L.thist + per;
 	L.partial = L.toff + per;
-	L.tickets = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
-	L.total = L.tickets + (size_t) RP_MAX_PASSES * 8 * RP_TICKET_STRIDE * sizeof(unsigned);
+	L.total = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
 	return L;
 }
 
@@ -430,15 +254,6 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const clo_keyx kx_none = { 0, 0, 0 };
 
 	hipError_t e;   // (no kernel of the sort polls another work-group: the header's status word stays unused)
-
-	// the streaming form of the pass kernel (tickets, next tile requested early): CLO_RADIX_STREAM=1/0, default by size
-	const char* sx = getenv("CLO_RADIX_STREAM");
-	const bool stream_kernel = passes <= RP_MAX_PASSES && (sx ? atoi(sx) != 0 : false) && tiles > 768u;
-	unsigned* tickets = (unsigned*) ((char*) ws + L.tickets);
-	if (stream_kernel) {
-		e = hipMemsetAsync(tickets, 0, (size_t) passes * 8 * RP_TICKET_STRIDE * sizeof(unsigned), s);
-		if (e != hipSuccess) return (int) e;
-	}
 
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
 	const E* cur_in = src;
@@ -464,15 +279,9 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		}
 		{
 			clo_timing_scope timing("radix_pass", s);
-			if (stream_kernel && hi_bits > 0)
-				hipLaunchKernelGGL((clo_radix4_pair_stream_kernel<E, LB, HB>), dim3(768), dim3(pair_shape<E>::THREADS), 0, s,
-					cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
-					(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none,
-					tickets + (size_t) p * 8 * RP_TICKET_STRIDE, tiles);
-			else
-				hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E>::THREADS), 0, s,
-					cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
-					(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
+			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E>::THREADS), 0, s,
+				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
+				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
 		}
 		cur_in = cur_out;
 	}

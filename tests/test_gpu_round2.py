@@ -111,15 +111,15 @@ def test_profiling_queue_gets_one_event_per_kernel(gpu):
     import cl_ops_amd as clo
     ctx, _ = gpu
     qp = clo.Queue(ctx, profiling=True)
-    n = 1 << 20
-    a = O.bench_rand(0, "uint", n)
+    n = 1 << 24
+    a = np.random.default_rng(0).integers(0, 1 << 32, n, dtype=np.uint32)
     src = clo.Buffer(ctx, n * 4)
     s = clo.Sorter("satradix", ctx, "uint")
-    # 2^18 elements: chain-free passes (histogram, counter scan, scatter per digit pair);
+    # 2^24 elements: chain-free passes (histogram, counter scan, scatter per digit pair);
     # 2^20: single-sweep passes (one up-front histogram, then scatters that hand the
-    # counts from tile to tile: no counter-scan kernel)
-    for m, names in ((1 << 18, {"satradix_histogram", "clo_scan_blelloch_wgscan", "satradix_scatter"}),
-                     (n, {"satradix_histogram", "satradix_scatter"})):
+    # counts from tile to tile: no counter-scan kernel); 2^12: one launch sorts it all
+    for m, names in ((n, {"satradix_histogram", "clo_scan_blelloch_wgscan", "satradix_scatter"}),
+                     (1 << 20, {"satradix_histogram", "satradix_scatter"}), (1 << 12, {"satradix_localsort"})):
         src.write(qp, a[:m])
         clo.Profiler(qp).duration_ns()          # (drop the copy's event)
         s.with_device_data(qp, src, None, m)
@@ -133,6 +133,7 @@ def test_profiling_queue_gets_one_event_per_kernel(gpu):
     s.close()
     prof = clo.Profiler(qp)
 
+    n = 1 << 20
     sc = clo.Scanner("blelloch", ctx, "uint", "uint")
     dst = clo.Buffer(ctx, n * 4)
     sc.with_device_data(qp, src, dst, n)
