@@ -17,8 +17,7 @@ struct clo_shard_sort {
 	clo_devbuf send, workspace, counts;   /* partitioned shard; partition workspace; G + G*G uint64 */
 	CCLBuffer* recv;                      /* what arrived (owned; grown on demand) */
 	size_t recv_cap;
-	uint64_t* counts_host;                /* G*G, pinned when possible */
-	int counts_host_pinned;
+	uint64_t* counts_host;                /* G*G (pageable: 512 bytes at G = 8, and the call waits for them anyway) */
 	void* ev[5];                          /* device time stamps of the phases */
 	double phase_ms[4];
 	int have_phase;
@@ -125,7 +124,6 @@ void clo_shard_sort_destroy(CloShardSort* ss) {
 	clo_devbuf_release(&ss->send);
 	clo_devbuf_release(&ss->workspace);
 	clo_devbuf_release(&ss->counts);
-	if (ss->counts_host_pinned) clo_hip_host_unregister(ss->counts_host);
 	free(ss->counts_host);
 	for (int i = 0; i < 5; ++i) clo_hip_event_destroy(ss->ev[i]);
 	ccl_context_unref(ss->ctx);
@@ -188,7 +186,6 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 	if (!ss->counts_host) {
 		ss->counts_host = (uint64_t*) calloc((size_t) G * G, sizeof(uint64_t));
 		if (!ss->counts_host) return NULL;
-		ss->counts_host_pinned = clo_hip_host_register(ss->counts_host, (size_t) G * G * sizeof(uint64_t)) == 0;
 	}
 	uint64_t* my_counts = (uint64_t*) ss->counts.ptr;
 	uint64_t* all_counts = my_counts + G;

@@ -123,13 +123,16 @@ void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_sh
 	}
 	// The work-group that finishes last turns the totals into digit starts (an
 	// exclusive scan over the 256 digits of every pass): no kernel of its own.
+	// (The adds are performed at the memory side and counted in vmcnt until they
+	// are: waiting for them orders them before the arrival; the totals are read
+	// back with agent-scope loads. A release fence here writes the XCD's L2 back once
+	// per group: measured 0.4 ms on the 2^28-key sort.)
 	__shared__ unsigned s_last, s_w[4];
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this group's adds before its arrival
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 	if (tid == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u;
 	__syncthreads();
 	if (!s_last) return;
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	const unsigned lane = tid & 63u, wave = tid >> 6;
 	for (int p = 0; p < NP; ++p) {
 		unsigned v = 0, incl = 0;

@@ -343,6 +343,8 @@ def test_c_shard_sort_world_one_over_rccl(gpu):
 
 def _c_shard_worker(rank, world, port, n, out_dir):
     import ctypes as C
+    import faulthandler
+    faulthandler.enable()
     import torch
     import torch.distributed as dist
     import cl_ops_amd as clo
