@@ -63,6 +63,34 @@ int clo_parse_options(const char* options, clo_option_cb cb, void* user, const c
 	return ok;
 }
 
+/* ---- stream guard (clo_internal.h) ---- */
+
+int clo_stream_guard_enter(clo_stream_guard* g, void* stream) {
+	if (g->recorded && g->stream != stream) {
+		const int st = clo_hip_stream_wait_event(stream, g->evt);
+		if (st != 0) return st;
+	}
+	return 0;
+}
+
+int clo_stream_guard_leave(clo_stream_guard* g, void* stream) {
+	if (!g->evt) {
+		const int st = clo_hip_event_create(&g->evt);
+		if (st != 0) return st;
+	}
+	const int st = clo_hip_event_record(g->evt, stream);
+	if (st != 0) return st;
+	g->stream = stream;
+	g->recorded = 1;
+	return 0;
+}
+
+void clo_stream_guard_release(clo_stream_guard* g) {
+	if (g->evt) clo_hip_event_destroy(g->evt);
+	g->evt = NULL;
+	g->recorded = 0;
+}
+
 /* ---- per-kernel events (clo_internal.h) ---- */
 
 static void kernel_events_observer(void* user, const char* label, int phase, void* stream) {

@@ -19,7 +19,7 @@ typedef struct {
 	void* ws_ready;            /* the allocation clo_hip_scan_workspace_init has prepared (NULL: none) */
 	size_t ws_ready_bytes;
 	clo_status_cell* status;   /* the workspace's status word, watched by the queues this scanner has used */
-	void* last_stream;
+	clo_stream_guard guard;    /* the workspace is used by one stream at a time */
 } clo_scan_blelloch_data;
 
 /* The one kernel of this scanner does the jobs of upstream's three; its event
@@ -34,9 +34,7 @@ static int blelloch_workspace(CloScan* scanner, CCLQueue* cq_exec, size_t numel,
 	void* stream = ccl_queue_get_stream(cq_exec);
 	const int es = (int) clo_scan_get_element_size(scanner);
 	const int ss = (int) clo_scan_get_sum_size(scanner);
-	if (data->last_stream && data->last_stream != stream)
-		if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return 0;
-	data->last_stream = stream;
+	if (clo_hip_failed(clo_stream_guard_enter(&data->guard, stream), err, "hipStreamWaitEvent")) return 0;
 	const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
 	if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return 0;
 	const int tripped = clo_status_cell_take_tripped(data->status);
@@ -82,6 +80,7 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 			numel, es, clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 			data->workspace.ptr, data->workspace.bytes, stream);
 		if (clo_hip_failed(st, err, "clo_hip_scan_exclusive")) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
+		if (clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	}
 
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
@@ -102,6 +101,7 @@ static cl_bool clo_scan_blelloch_scan_chunk(CloScan* scanner, CCLQueue* cq_exec,
 		clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 		(const uint64_t*) carry_in_dev, (uint64_t*) carry_out_dev, data->workspace.ptr, data->workspace.bytes, stream);
 	if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_carry")) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
+	if (clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
 	return CL_TRUE;
 }
@@ -141,6 +141,7 @@ static void clo_scan_blelloch_finalize(CloScan* scan) {
 		clo_status_cell_set_word(data->status, NULL);   /* queues still watching must not read freed memory */
 		clo_status_cell_unref(data->status);
 		clo_devbuf_release(&data->workspace);
+		clo_stream_guard_release(&data->guard);
 		free(data);
 	}
 	clo_scan_set_data(scan, NULL);

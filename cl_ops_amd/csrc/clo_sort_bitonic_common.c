@@ -10,6 +10,7 @@ void clo_bitonic_state_release(clo_bitonic_state* state) {
 	if (!state) return;
 	clo_graph_cache_release(&state->graph);
 	clo_devbuf_release(&state->padded);
+	clo_stream_guard_release(&state->guard);
 }
 
 typedef struct {
@@ -106,9 +107,7 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 					"bitonic sorts of a non-power-of-two numel need the key to be the whole element");
 				BITONIC_FAIL();
 			}
-			if (state->last_stream && state->last_stream != stream)
-				if (clo_hip_failed(clo_hip_stream_synchronize(state->last_stream), err, "hipStreamSynchronize")) BITONIC_FAIL();
-			state->last_stream = stream;
+			if (clo_hip_failed(clo_stream_guard_enter(&state->guard, stream), err, "hipStreamWaitEvent")) BITONIC_FAIL();
 			if (clo_hip_failed(clo_devbuf_reserve(&state->padded, padded * (size_t) ks->elem_size), err, "hipMalloc(bitonic pad)")) BITONIC_FAIL();
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(state->padded.ptr, work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
 			work = state->padded.ptr;
@@ -122,8 +121,10 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		if (clo_hip_failed(st, err, tiled ? "clo_hip_bitonic_tiled" : "clo_hip_bitonic_simple")) BITONIC_FAIL();
 		state->launches = launches;
 		clo_debug("%s: numel=%zu padded=%zu launches=%d", evt_name, numel, padded, launches);
-		if (use_pad)
+		if (use_pad) {
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
+			if (clo_hip_failed(clo_stream_guard_leave(&state->guard, stream), err, "hipEventRecord")) BITONIC_FAIL();
+		}
 	}
 #undef BITONIC_FAIL
 

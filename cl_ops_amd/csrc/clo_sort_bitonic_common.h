@@ -7,7 +7,7 @@
 
 typedef struct {
 	clo_devbuf padded;   /* used only when numel is not a power of two */
-	void* last_stream;
+	clo_stream_guard guard;   /* the padded copy is used by one stream at a time */
 	/* The launch sequence of a sort depends only on (buffer, numel, stream):
 	 * when a call repeats the previous one's, it is captured into a graph and
 	 * replayed from then on (sbitonic: 136 launches for 2^16 elements). */

@@ -41,7 +41,7 @@ typedef struct {
 	clo_status_cell* status;  /* the workspace's status word, for the sorts whose kernels poll (clo_hip_radix_polls) */
 	void* ws_ready;           /* the allocation whose header (status word) has been cleared */
 	size_t ws_ready_bytes;
-	void* last_stream;
+	clo_stream_guard guard;   /* the cached buffers are used by one stream at a time */
 } clo_sort_satradix_data;
 
 static const char* clo_sort_satradix_knames[] = {
@@ -102,9 +102,7 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 	if (numel > 0) {
 		/* The cached buffers belong to one stream at a time. Reserved before the
 		 * command's start event so that (re)allocation is not timed as device work. */
-		if (data->last_stream && data->last_stream != stream)
-			if (clo_hip_failed(clo_hip_stream_synchronize(data->last_stream), err, "hipStreamSynchronize")) return NULL;
-		data->last_stream = stream;
+		if (clo_hip_failed(clo_stream_guard_enter(&data->guard, stream), err, "hipStreamWaitEvent")) return NULL;
 		const int jit = clo_sort_get_jit(sorter) != NULL;   /* then (key, index) pairs of 8 bytes are what gets sorted */
 		const size_t ws_bytes = clo_hip_radix_workspace_bytes(numel, jit ? 8 : ks->elem_size, jit ? 32 : ks->key_bits, bits_in_digit);
 		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, jit ? numel * 8 : bytes), err, "hipMalloc(satradix aux)")) return NULL;
@@ -160,6 +158,10 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		}
 	}
 
+	if (numel > 0 && clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) {
+		if (per_kernel) clo_kernel_events_remove(&ke, NULL); else ccl_queue_abort_command(cq_exec, evt);
+		return NULL;
+	}
 	if (per_kernel) return clo_kernel_events_remove(&ke, err);
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	return evt;
@@ -216,6 +218,7 @@ static void satradix_free(clo_sort_satradix_data* data) {
 	clo_devbuf_release(&data->tmp);
 	clo_devbuf_release(&data->workspace);
 	clo_devbuf_release(&data->pairs);
+	clo_stream_guard_release(&data->guard);
 	free(data);
 }
 

@@ -38,6 +38,7 @@
 // bounded (status word, as the scan).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "clo_hip.h"
@@ -518,8 +519,11 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	int early = 8;   // (CLO_R1_EARLY: A/B measurements)
 	if (const char* m = getenv("CLO_R1_EARLY")) early = atoi(m);
 
+	const bool dbg = getenv("CLO_DEBUG") != nullptr;
+	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: n=%zu tiles=%u passes=%d ws=%p bytes=%zu stream=%p\n", n, tiles, passes, ws, L.total, (void*) s);
 	// everything the passes publish or count in starts from zero
 	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
+	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: memset -> %d\n", (int) e);
 	if (e != hipSuccess) return (int) e;
 	{
 		clo_timing_scope timing("radix_ghist", s);
@@ -530,9 +534,11 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			default: return CLO_HIP_EUNSUPPORTED;
 		}
 	}
+	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: ghist launched -> %d\n", (int) hipPeekAtLastError());
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
 	const E* cur_in = src;
 	for (int p = 0; p < passes; ++p) {
+		if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: pass %d\n", p);
 		E* cur_out;
 		if (inplace_odd) cur_out = (p % 2 == 0) ? tmp : dst;
 		else cur_out = ((passes - 1 - p) % 2 == 0) ? dst : tmp;
