@@ -15,6 +15,7 @@
 #include <string.h>
 
 typedef struct {
+	clo_devbuf fp_workspace;   /* tile sums of the floating-point scans */
 	clo_devbuf workspace;
 	void* ws_ready;            /* the allocation clo_hip_scan_workspace_init has prepared (NULL: none) */
 	size_t ws_ready_bytes;
@@ -68,6 +69,25 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 	if (numel * (size_t) es > ccl_buffer_get_size(data_in) || numel * (size_t) ss > ccl_buffer_get_size(data_out)) {
 		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "numel (%zu) exceeds the size of the device buffers", numel);
 		return NULL;
+	}
+
+	if (clo_type_is_float(clo_scan_get_sum_type(scanner))) {
+		/* float / double sums: reduce, scan the tile sums, apply (clo_hip_fscan.hip) */
+		const size_t wsb = clo_hip_scan_fp_workspace_bytes(numel, ss);
+		if (numel > 0) {
+			if (clo_hip_failed(clo_stream_guard_enter(&data->guard, stream), err, "hipStreamWaitEvent")) return NULL;
+			if (clo_hip_failed(clo_devbuf_reserve(&data->fp_workspace, wsb), err, "hipMalloc(scan workspace)")) return NULL;
+		}
+		CCLEvent* fevt = ccl_queue_begin_command(cq_exec, CLO_SCAN_BLELLOCH_EVENT, err);
+		if (!fevt) return NULL;
+		if (numel > 0) {
+			const int st = clo_hip_scan_exclusive_fp(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out), numel,
+				(int) clo_scan_get_elem_type(scanner), ss, data->fp_workspace.ptr, data->fp_workspace.bytes, stream);
+			if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_fp")) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
+			if (clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
+		}
+		if (!ccl_queue_end_command(cq_exec, fevt, err)) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
+		return fevt;
 	}
 
 	if (numel > 0 && !blelloch_workspace(scanner, cq_exec, numel, err)) return NULL;
@@ -141,6 +161,7 @@ static void clo_scan_blelloch_finalize(CloScan* scan) {
 		clo_status_cell_set_word(data->status, NULL);   /* queues still watching must not read freed memory */
 		clo_status_cell_unref(data->status);
 		clo_devbuf_release(&data->workspace);
+		clo_devbuf_release(&data->fp_workspace);
 		clo_stream_guard_release(&data->guard);
 		free(data);
 	}

@@ -1,0 +1,158 @@
+// clo_hip_fscan.hip — exclusive prefix sums in FLOATING POINT (sum type float or
+// double; elements of any CloType, converted to the sum type on load as upstream's
+// kernels do: scan/clo_scan_blelloch.cl:79-80 with CLO_SCAN_SUM_TYPE float/double).
+//
+// Not the single-pass kernel of clo_hip_scan.hip: its look-back adds up whichever
+// predecessors have published when it polls, which is harmless in modular integer
+// arithmetic and would make a floating-point result depend on timing. Here the
+// order of every addition is fixed by the data layout alone — reduce, scan the
+// tile sums (recursively), apply — so two runs give the same bits:
+//   tile = 256 threads x 16 consecutive elements; a thread adds its 16 left to
+//   right, a wave scans its 64 thread sums (shuffle tree), the 4 wave sums are
+//   added left to right; tiles are combined by the same procedure one level up
+//   (4096 tile sums per upper tile; three levels cover any array).
+// Upstream's order is the Blelloch tree of its own work-group shape, so results
+// agree with it to rounding, not bit for bit (no two work-group sizes of upstream
+// agree bit for bit either). 3 element streams instead of 2.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "clo_hip.h"
+#include "clo_hip_internal.h"
+
+namespace {
+
+constexpr int FS_THREADS = 256;
+constexpr int FS_ITEMS = 16;
+constexpr int FS_TILE = FS_THREADS * FS_ITEMS;   // 4096
+
+template <typename TSum, typename TIn>
+__device__ __forceinline__ TSum fs_cvt(TIn x) { return (TSum) x; }
+template <> __device__ __forceinline__ float fs_cvt<float, __half>(__half x) { return __half2float(x); }
+template <> __device__ __forceinline__ double fs_cvt<double, __half>(__half x) { return (double) __half2float(x); }
+
+// thread sums -> exclusive offset of every thread inside the tile, and the tile total
+template <typename TSum>
+__device__ __forceinline__ TSum fs_block_exclusive(TSum mine, TSum* total, TSum* s_w) {
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	TSum incl = mine;
+	#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const TSum y = __shfl_up(incl, off, 64);
+		if (lane >= (unsigned) off) incl += y;
+	}
+	if (lane == 63) s_w[wave] = incl;
+	__syncthreads();
+	TSum base = 0, tot = 0;
+	#pragma unroll
+	for (unsigned w = 0; w < FS_THREADS / 64; ++w) {
+		if (w < wave) base += s_w[w];
+		tot += s_w[w];
+	}
+	*total = tot;
+	return base + (incl - mine);   // (incl - mine: the sum of the lanes before, as the tree formed it)
+}
+
+template <typename TIn, typename TSum>
+__global__ __launch_bounds__(FS_THREADS)
+void clo_fscan_reduce_kernel(const TIn* __restrict__ in, size_t n, TSum* __restrict__ sums) {
+	__shared__ TSum s_w[FS_THREADS / 64];
+	const size_t base = (size_t) blockIdx.x * FS_TILE + (size_t) threadIdx.x * FS_ITEMS;
+	TSum mine = 0;
+	#pragma unroll
+	for (int i = 0; i < FS_ITEMS; ++i) if (base + i < n) mine += fs_cvt<TSum, TIn>(in[base + i]);
+	TSum total;
+	(void) fs_block_exclusive<TSum>(mine, &total, s_w);
+	if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// out[i] = offset of the tile (tile_excl[tile], or 0) + exclusive scan inside the tile.
+// in == out is allowed when TIn == TOut (the upper levels scan their sums in place).
+template <typename TIn, typename TOut, typename TSum>
+__global__ __launch_bounds__(FS_THREADS)
+void clo_fscan_apply_kernel(const TIn* in, TOut* out, size_t n, const TSum* __restrict__ tile_excl) {
+	__shared__ TSum s_w[FS_THREADS / 64];
+	const size_t base = (size_t) blockIdx.x * FS_TILE + (size_t) threadIdx.x * FS_ITEMS;
+	TSum v[FS_ITEMS];
+	TSum mine = 0;
+	#pragma unroll
+	for (int i = 0; i < FS_ITEMS; ++i) {
+		v[i] = base + i < n ? fs_cvt<TSum, TIn>(in[base + i]) : (TSum) 0;
+		mine += v[i];
+	}
+	TSum total;
+	TSum run = fs_block_exclusive<TSum>(mine, &total, s_w) + (tile_excl ? tile_excl[blockIdx.x] : (TSum) 0);
+	#pragma unroll
+	for (int i = 0; i < FS_ITEMS; ++i) {
+		if (base + i < n) out[base + i] = (TOut) run;
+		run += v[i];
+	}
+}
+
+template <typename TIn, typename TOut, typename TSum>
+int fs_scan(const TIn* in, TOut* out, size_t n, TSum* ws, hipStream_t s) {
+	const size_t t1 = (n + FS_TILE - 1) / FS_TILE;
+	clo_timing_scope timing("scan", s);
+	if (t1 <= 1) {
+		hipLaunchKernelGGL((clo_fscan_apply_kernel<TIn, TOut, TSum>), dim3(1), dim3(FS_THREADS), 0, s, in, out, n, (const TSum*) nullptr);
+		return (int) hipGetLastError();
+	}
+	TSum* sums1 = ws;
+	hipLaunchKernelGGL((clo_fscan_reduce_kernel<TIn, TSum>), dim3((unsigned) t1), dim3(FS_THREADS), 0, s, in, n, sums1);
+	const size_t t2 = (t1 + FS_TILE - 1) / FS_TILE;
+	if (t2 <= 1) {
+		hipLaunchKernelGGL((clo_fscan_apply_kernel<TSum, TSum, TSum>), dim3(1), dim3(FS_THREADS), 0, s, sums1, sums1, t1, (const TSum*) nullptr);
+	} else {
+		TSum* sums2 = sums1 + t1;
+		hipLaunchKernelGGL((clo_fscan_reduce_kernel<TSum, TSum>), dim3((unsigned) t2), dim3(FS_THREADS), 0, s, sums1, t1, sums2);
+		const size_t t3 = (t2 + FS_TILE - 1) / FS_TILE;
+		if (t3 > 1) return CLO_HIP_EUNSUPPORTED;   // (> 2^36 elements)
+		hipLaunchKernelGGL((clo_fscan_apply_kernel<TSum, TSum, TSum>), dim3(1), dim3(FS_THREADS), 0, s, sums2, sums2, t2, (const TSum*) nullptr);
+		hipLaunchKernelGGL((clo_fscan_apply_kernel<TSum, TSum, TSum>), dim3((unsigned) t2), dim3(FS_THREADS), 0, s, sums1, sums1, t1, (const TSum*) sums2);
+	}
+	hipLaunchKernelGGL((clo_fscan_apply_kernel<TIn, TOut, TSum>), dim3((unsigned) t1), dim3(FS_THREADS), 0, s, in, out, n, (const TSum*) sums1);
+	return (int) hipGetLastError();
+}
+
+template <typename TSum>
+int fs_dispatch(const void* in, void* out, size_t n, int elem_type, void* ws, hipStream_t s) {
+	TSum* w = (TSum*) ws;
+	TSum* o = (TSum*) out;
+	switch (elem_type) {   // CloType numbers (clo_common.h)
+		case 0: return fs_scan<int8_t, TSum, TSum>((const int8_t*) in, o, n, w, s);
+		case 1: return fs_scan<uint8_t, TSum, TSum>((const uint8_t*) in, o, n, w, s);
+		case 2: return fs_scan<int16_t, TSum, TSum>((const int16_t*) in, o, n, w, s);
+		case 3: return fs_scan<uint16_t, TSum, TSum>((const uint16_t*) in, o, n, w, s);
+		case 4: return fs_scan<int32_t, TSum, TSum>((const int32_t*) in, o, n, w, s);
+		case 5: return fs_scan<uint32_t, TSum, TSum>((const uint32_t*) in, o, n, w, s);
+		case 6: return fs_scan<int64_t, TSum, TSum>((const int64_t*) in, o, n, w, s);
+		case 7: return fs_scan<uint64_t, TSum, TSum>((const uint64_t*) in, o, n, w, s);
+		case 8: return fs_scan<__half, TSum, TSum>((const __half*) in, o, n, w, s);
+		case 9: return fs_scan<float, TSum, TSum>((const float*) in, o, n, w, s);
+		case 10: return fs_scan<double, TSum, TSum>((const double*) in, o, n, w, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t clo_hip_scan_fp_workspace_bytes(size_t numel, int sum_size) {
+	const size_t t1 = (numel + FS_TILE - 1) / FS_TILE;
+	const size_t t2 = (t1 + FS_TILE - 1) / FS_TILE;
+	return (t1 + t2 + 8) * (size_t) (sum_size == 8 ? 8 : 4);
+}
+
+int clo_hip_scan_exclusive_fp(const void* data_in, void* data_out, size_t numel, int elem_type, int sum_size,
+	void* workspace, size_t workspace_bytes, void* stream) {
+	if (numel == 0) return 0;
+	if (!data_in || !data_out || !workspace) return CLO_HIP_EARGS;
+	if (sum_size != 4 && sum_size != 8) return CLO_HIP_EUNSUPPORTED;
+	if (workspace_bytes < clo_hip_scan_fp_workspace_bytes(numel, sum_size)) return CLO_HIP_EWORKSPACE;
+	hipStream_t s = (hipStream_t) stream;
+	return sum_size == 8 ? fs_dispatch<double>(data_in, data_out, numel, elem_type, workspace, s)
+	                     : fs_dispatch<float>(data_in, data_out, numel, elem_type, workspace, s);
+}
+
+}  // extern "C"

@@ -115,6 +115,15 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
 	int elem_size, int elem_signed, int sum_size,
 	const uint64_t* carry_in_dev, uint64_t* carry_out_dev,
 	void* workspace, size_t workspace_bytes, void* stream);
+/* The same scan with a FLOATING-POINT sum type (float: sum_size 4, double: 8);
+ * elem_type is a CloType number (any of the eleven), elements are converted to the
+ * sum type on load as upstream's kernels do (scan/clo_scan_blelloch.cl:79-80).
+ * Reduce / scan the tile sums / apply, every addition in an order fixed by the
+ * layout alone: deterministic, equal to upstream's result to rounding (its order
+ * is the Blelloch tree of its own work-group size). No look-back, no polling. */
+size_t clo_hip_scan_fp_workspace_bytes(size_t numel, int sum_size);
+int clo_hip_scan_exclusive_fp(const void* data_in, void* data_out, size_t numel, int elem_type, int sum_size,
+	void* workspace, size_t workspace_bytes, void* stream);
 /* Sum of the elements mod 2^64 into *total_dev (device): what a shard hands
  * to the later shards of a multi-GPU scan. */
 int clo_hip_reduce_sum(const void* data_in, size_t numel, int elem_size, int elem_signed,

@@ -213,8 +213,15 @@ def test_blelloch_rejects_options_and_bad_types(off):
     assert e.value.code == CLO_ERROR_ARGS and "Invalid options for blelloch scan." in e.value.message
     with pytest.raises(clo.CloError):
         clo.Scanner("blelloch", off, "ulong", "uint")   # sum narrower than element
-    with pytest.raises(clo.CloError):
-        clo.Scanner("blelloch", off, "float", "float")
+    # floating-point sums are accepted (float, double; any element type); not built: a half
+    # sum type, and floating-point elements summed in an integer type
+    for et, st in (("float", "float"), ("double", "double"), ("float", "double"), ("uint", "float"), ("half", "float"),
+                   ("double", "float")):
+        clo.Scanner("blelloch", off, et, st).close()
+    for et, st in (("float", "uint"), ("half", "half"), ("double", "ulong")):
+        with pytest.raises(clo.CloError) as e:
+            clo.Scanner("blelloch", off, et, st)
+        assert e.value.code == CLO_ERROR_ARGS
 
 
 @pytest.mark.parametrize("elem,key,get_key,expect", [

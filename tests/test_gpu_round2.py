@@ -428,3 +428,37 @@ def test_c_shard_sort_two_ranks_on_one_gpu(gpu, tmp_path):
     outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)]
     assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
     assert np.all(outs[0] >> np.uint64(63) == 0) and np.all(outs[1] >> np.uint64(63) == 1)
+
+
+# ----------------------------------------------------------------------------
+# floating-point scans (deterministic reduce / scan / apply: clo_hip_fscan.hip)
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("types", [("float", "float"), ("double", "double"), ("float", "double"), ("uint", "float"),
+                                   ("int", "double"), ("half", "float"), ("double", "float")])
+@pytest.mark.parametrize("n", [1, 17, 4095, 4096, 4097, (1 << 20) + 3, (1 << 24) + 4099 * 4096 + 5])
+def test_float_scan_matches_a_float64_reference(gpu, types, n):
+    """Sums in float / double: equal to the exact prefix sums to rounding (the order of the
+    additions is the kernels' own tree, not upstream's), bit-identical from run to run, and
+    exact where every partial sum is representable."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, st = types
+    edt, sdt = clo.api.CLO_TYPE_NP[et], clo.api.CLO_TYPE_NP[st]
+    rng = np.random.default_rng(n % 1000 + len(et))
+    if np.issubdtype(edt, np.floating):
+        a = (rng.random(n) - 0.25).astype(edt)
+    else:
+        a = rng.integers(-50 if np.issubdtype(edt, np.signedinteger) else 0, 128, n).astype(edt)
+    sc = clo.Scanner("blelloch", ctx, et, st)
+    got = sc.with_host_data(a, q)
+    again = sc.with_host_data(a, q)
+    sc.close()
+    assert got.dtype == sdt and np.array_equal(got, again), "not deterministic"
+    wide = a.astype(np.float64)
+    exact = np.concatenate(([0.0], np.cumsum(wide)[:-1]))
+    scale = np.concatenate(([0.0], np.cumsum(np.abs(wide))[:-1])) + 1.0
+    eps = np.finfo(sdt).eps
+    assert np.all(np.abs(got.astype(np.float64) - exact) <= 64 * eps * scale), float(np.max(np.abs(got - exact) / scale))
+    if not np.issubdtype(edt, np.floating) and n <= (1 << 17):
+        assert np.array_equal(got.astype(np.int64), exact.astype(np.int64))     # small integers: every sum exact
