@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcl_ops_hip.so")
+# CLO_HIP_LIBRARY: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("CLO_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libcl_ops_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

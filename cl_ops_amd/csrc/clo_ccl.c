@@ -61,6 +61,8 @@ struct ccl_queue {
 	size_t nevents;
 	struct clo_status_cell* cells[CCL_QUEUE_MAX_CELLS];
 	int ncells;
+	int refs;     /* the caller's + one per sorter / scanner whose last call ran here (clo_queue_hold) */
+	int closed;   /* ccl_queue_destroy has run: synchronised, stream gone; only the struct is still held */
 };
 
 struct ccl_buffer {
@@ -185,6 +187,7 @@ static CCLQueue* queue_alloc(CCLContext* ctx, void* stream, int owns, cl_ulong p
 	cq->stream = stream;
 	cq->owns_stream = owns;
 	cq->profiling = (properties & CL_QUEUE_PROFILING_ENABLE) != 0;
+	cq->refs = 1;
 	return cq;
 }
 
@@ -268,17 +271,29 @@ static int queue_check_status(CCLQueue* cq, GError** err) {
 	return ok;
 }
 
+/* Synchronises and closes the queue NOW (the stream of a queue made by
+ * ccl_queue_new is destroyed, a wrapped one is the caller's again); the struct
+ * itself lives until the last holder has let go of it. */
 void ccl_queue_destroy(CCLQueue* cq) {
 	if (!cq) return;
-	clo_hip_set_device(cq->ctx->dev.index);
-	clo_hip_stream_synchronize(cq->stream);
-	for (int i = 0; i < cq->ncells; ++i) clo_status_cell_unref(cq->cells[i]);
-	cq->ncells = 0;
-	ccl_queue_gc(cq);
-	if (cq->owns_stream) clo_hip_stream_destroy(cq->stream);
-	ccl_context_unref(cq->ctx);
-	free(cq);
+	if (!cq->closed) {
+		clo_hip_set_device(cq->ctx->dev.index);
+		clo_hip_stream_synchronize(cq->stream);
+		for (int i = 0; i < cq->ncells; ++i) clo_status_cell_unref(cq->cells[i]);
+		cq->ncells = 0;
+		ccl_queue_gc(cq);
+		if (cq->owns_stream) clo_hip_stream_destroy(cq->stream);
+		cq->stream = NULL;
+		ccl_context_unref(cq->ctx);
+		cq->ctx = NULL;
+		cq->closed = 1;
+	}
+	clo_queue_drop(cq);
 }
+
+void clo_queue_hold(CCLQueue* cq) { if (cq) ++cq->refs; }
+void clo_queue_drop(CCLQueue* cq) { if (cq && --cq->refs == 0) free(cq); }
+int clo_queue_is_closed(CCLQueue* cq) { return !cq || cq->closed; }
 
 CCLDevice* ccl_queue_get_device(CCLQueue* cq, GError** err) {
 	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }

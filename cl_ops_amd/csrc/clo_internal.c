@@ -65,30 +65,30 @@ int clo_parse_options(const char* options, clo_option_cb cb, void* user, const c
 
 /* ---- stream guard (clo_internal.h) ---- */
 
-int clo_stream_guard_enter(clo_stream_guard* g, void* stream) {
-	if (g->recorded && g->stream != stream) {
-		const int st = clo_hip_stream_wait_event(stream, g->evt);
-		if (st != 0) return st;
+int clo_stream_guard_enter(clo_stream_guard* g, CCLQueue* cq) {
+	if (g->cq == cq) return 0;
+	if (g->cq) {
+		if (!clo_queue_is_closed(g->cq) && ccl_queue_get_stream(g->cq) != ccl_queue_get_stream(cq)) {
+			if (!g->evt) {
+				const int st = clo_hip_event_create(&g->evt);
+				if (st != 0) return st;
+			}
+			int st = clo_hip_event_record(g->evt, ccl_queue_get_stream(g->cq));
+			if (st == 0) st = clo_hip_stream_wait_event(ccl_queue_get_stream(cq), g->evt);
+			if (st != 0) return st;
+		}
+		clo_queue_drop(g->cq);
 	}
-	return 0;
-}
-
-int clo_stream_guard_leave(clo_stream_guard* g, void* stream) {
-	if (!g->evt) {
-		const int st = clo_hip_event_create(&g->evt);
-		if (st != 0) return st;
-	}
-	const int st = clo_hip_event_record(g->evt, stream);
-	if (st != 0) return st;
-	g->stream = stream;
-	g->recorded = 1;
+	clo_queue_hold(cq);
+	g->cq = cq;
 	return 0;
 }
 
 void clo_stream_guard_release(clo_stream_guard* g) {
 	if (g->evt) clo_hip_event_destroy(g->evt);
 	g->evt = NULL;
-	g->recorded = 0;
+	clo_queue_drop(g->cq);
+	g->cq = NULL;
 }
 
 /* ---- per-kernel events (clo_internal.h) ---- */

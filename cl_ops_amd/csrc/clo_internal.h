@@ -40,21 +40,22 @@ typedef struct {
 int clo_devbuf_reserve(clo_devbuf* b, size_t bytes);
 void clo_devbuf_release(clo_devbuf* b);
 
-/* Buffers cached in a sorter / scanner belong to one stream at a time. When a
- * call arrives on another stream than the previous one, its work must come after
- * the previous call's — without touching the previous stream's HANDLE: the queue
- * that owned it may be gone (clo_*_with_host_data makes and destroys a queue of
- * its own when the caller passes none; round 1 kept the raw handle and called
+/* Buffers cached in a sorter / scanner belong to one queue at a time. When a
+ * call arrives on another queue than the previous one, its work must come after
+ * the previous call's. The guard remembers the QUEUE of the last call (holding
+ * its struct, clo_queue_hold), not a stream handle: the queue may have been
+ * destroyed meanwhile (clo_*_with_host_data makes and destroys a queue of its own
+ * when the caller passes none; round 1 kept the raw handle and called
  * hipStreamSynchronize on it later: undefined behaviour, observed as an abort
- * inside the HIP runtime). So every call leaves an event behind, and a call on
- * a different stream makes its stream wait for that event. */
+ * inside the HIP runtime) — a destroyed queue was synchronised when it went, so
+ * nothing is left to wait for; a live one gets an event recorded on it now, and
+ * the new queue's stream waits for that. Calls that stay on one queue pay
+ * nothing (an event per call cost 3.5 us of device time between two kernels). */
 typedef struct {
-	void* evt;       /* recorded at the end of the last call (NULL: nothing yet) */
-	void* stream;    /* the stream it was recorded on: compared, never dereferenced */
-	int recorded;
+	CCLQueue* cq;    /* the queue of the last call (held), or NULL */
+	void* evt;       /* created the first time two live queues alternate */
 } clo_stream_guard;
-int clo_stream_guard_enter(clo_stream_guard* g, void* stream);   /* before the call's first enqueue; 0 or a clo_hip status */
-int clo_stream_guard_leave(clo_stream_guard* g, void* stream);   /* after its last enqueue */
+int clo_stream_guard_enter(clo_stream_guard* g, CCLQueue* cq);   /* before the call's first enqueue; 0 or a clo_hip status */
 void clo_stream_guard_release(clo_stream_guard* g);
 
 /* A launch sequence that depends only on its arguments (buffers, size,

@@ -35,7 +35,7 @@ static int blelloch_workspace(CloScan* scanner, CCLQueue* cq_exec, size_t numel,
 	void* stream = ccl_queue_get_stream(cq_exec);
 	const int es = (int) clo_scan_get_element_size(scanner);
 	const int ss = (int) clo_scan_get_sum_size(scanner);
-	if (clo_hip_failed(clo_stream_guard_enter(&data->guard, stream), err, "hipStreamWaitEvent")) return 0;
+	if (clo_hip_failed(clo_stream_guard_enter(&data->guard, cq_exec), err, "hipStreamWaitEvent")) return 0;
 	const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
 	if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return 0;
 	const int tripped = clo_status_cell_take_tripped(data->status);
@@ -75,7 +75,7 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 		/* float / double sums: reduce, scan the tile sums, apply (clo_hip_fscan.hip) */
 		const size_t wsb = clo_hip_scan_fp_workspace_bytes(numel, ss);
 		if (numel > 0) {
-			if (clo_hip_failed(clo_stream_guard_enter(&data->guard, stream), err, "hipStreamWaitEvent")) return NULL;
+			if (clo_hip_failed(clo_stream_guard_enter(&data->guard, cq_exec), err, "hipStreamWaitEvent")) return NULL;
 			if (clo_hip_failed(clo_devbuf_reserve(&data->fp_workspace, wsb), err, "hipMalloc(scan workspace)")) return NULL;
 		}
 		CCLEvent* fevt = ccl_queue_begin_command(cq_exec, CLO_SCAN_BLELLOCH_EVENT, err);
@@ -84,7 +84,6 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 			const int st = clo_hip_scan_exclusive_fp(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out), numel,
 				(int) clo_scan_get_elem_type(scanner), ss, data->fp_workspace.ptr, data->fp_workspace.bytes, stream);
 			if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_fp")) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
-			if (clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
 		}
 		if (!ccl_queue_end_command(cq_exec, fevt, err)) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
 		return fevt;
@@ -100,7 +99,6 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 			numel, es, clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 			data->workspace.ptr, data->workspace.bytes, stream);
 		if (clo_hip_failed(st, err, "clo_hip_scan_exclusive")) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
-		if (clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	}
 
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
@@ -121,7 +119,6 @@ static cl_bool clo_scan_blelloch_scan_chunk(CloScan* scanner, CCLQueue* cq_exec,
 		clo_type_is_signed(clo_scan_get_elem_type(scanner)), ss,
 		(const uint64_t*) carry_in_dev, (uint64_t*) carry_out_dev, data->workspace.ptr, data->workspace.bytes, stream);
 	if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_carry")) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
-	if (clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return CL_FALSE; }
 	return CL_TRUE;
 }

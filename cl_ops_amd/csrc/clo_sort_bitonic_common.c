@@ -107,7 +107,7 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 					"bitonic sorts of a non-power-of-two numel need the key to be the whole element");
 				BITONIC_FAIL();
 			}
-			if (clo_hip_failed(clo_stream_guard_enter(&state->guard, stream), err, "hipStreamWaitEvent")) BITONIC_FAIL();
+			if (clo_hip_failed(clo_stream_guard_enter(&state->guard, cq_exec), err, "hipStreamWaitEvent")) BITONIC_FAIL();
 			if (clo_hip_failed(clo_devbuf_reserve(&state->padded, padded * (size_t) ks->elem_size), err, "hipMalloc(bitonic pad)")) BITONIC_FAIL();
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(state->padded.ptr, work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
 			work = state->padded.ptr;
@@ -123,7 +123,6 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		clo_debug("%s: numel=%zu padded=%zu launches=%d", evt_name, numel, padded, launches);
 		if (use_pad) {
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
-			if (clo_hip_failed(clo_stream_guard_leave(&state->guard, stream), err, "hipEventRecord")) BITONIC_FAIL();
 		}
 	}
 #undef BITONIC_FAIL

@@ -100,9 +100,9 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		data->radix, bits_in_digit, numel, ks->key_shift, ks->key_shift + ks->key_bits);
 
 	if (numel > 0) {
-		/* The cached buffers belong to one stream at a time. Reserved before the
+		/* The cached buffers belong to one queue at a time. Reserved before the
 		 * command's start event so that (re)allocation is not timed as device work. */
-		if (clo_hip_failed(clo_stream_guard_enter(&data->guard, stream), err, "hipStreamWaitEvent")) return NULL;
+		if (clo_hip_failed(clo_stream_guard_enter(&data->guard, cq_exec), err, "hipStreamWaitEvent")) return NULL;
 		const int jit = clo_sort_get_jit(sorter) != NULL;   /* then (key, index) pairs of 8 bytes are what gets sorted */
 		const size_t ws_bytes = clo_hip_radix_workspace_bytes(numel, jit ? 8 : ks->elem_size, jit ? 32 : ks->key_bits, bits_in_digit);
 		if (clo_hip_failed(clo_devbuf_reserve(&data->tmp, jit ? numel * 8 : bytes), err, "hipMalloc(satradix aux)")) return NULL;
@@ -158,10 +158,6 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		}
 	}
 
-	if (numel > 0 && clo_hip_failed(clo_stream_guard_leave(&data->guard, stream), err, "hipEventRecord")) {
-		if (per_kernel) clo_kernel_events_remove(&ke, NULL); else ccl_queue_abort_command(cq_exec, evt);
-		return NULL;
-	}
 	if (per_kernel) return clo_kernel_events_remove(&ke, err);
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	return evt;

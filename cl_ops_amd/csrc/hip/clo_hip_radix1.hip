@@ -72,7 +72,7 @@ __global__ __launch_bounds__(R1_GH_THREADS)
 void clo_radix1_ghist_kernel(const E* __restrict__ in, size_t n, unsigned key_shift, unsigned key_bits,
 	unsigned* __restrict__ ghist, unsigned* __restrict__ gbase, unsigned* __restrict__ done,
 	int aligned, clo_keyx kx, unsigned tiles_per_group) {
-	constexpr int ITEMS = pair_shape<E>::ITEMS;
+	constexpr int ITEMS = sweep_shape<E>::ITEMS;
 	constexpr int TILE = R1_GH_THREADS * ITEMS;
 	// Counters: 16-bit, two digits per dword, COPIES copies of every dword (copy = lane
 	// mod COPIES, dword-major): with 32 copies the 32 lanes an LDS instruction serves
@@ -170,12 +170,12 @@ struct r1_pass {
 // R1_EARLY: level-1 entries (the previous chunk's prefix + the nearest rows) requested
 // before the second split, so that their round trip runs under it.
 template <typename E, int LB, int HB, int R1_CHUNK_LOG, int R1_EARLY>
-__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)
+__global__ __launch_bounds__(sweep_shape<E>::THREADS, 6)
 void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi, r1_pass P, int aligned, clo_keyx kx_in, clo_keyx kx_out) {
 
-	constexpr int THREADS = pair_shape<E>::THREADS;
-	constexpr int ITEMS = pair_shape<E>::ITEMS;
+	constexpr int THREADS = sweep_shape<E>::THREADS;
+	constexpr int ITEMS = sweep_shape<E>::ITEMS;
 	constexpr int TILE = THREADS * ITEMS;
 	constexpr int WAVES = THREADS / 64;
 	constexpr int R2 = 1 << (LB + HB);
@@ -557,7 +557,7 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		P.tiles = tiles;
 		P.max_spins = max_spins;
 		clo_timing_scope timing("radix_sweep", s);
-		#define CLO_R1_SWEEP(CL, EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL, EARLY>), dim3(tiles), dim3(pair_shape<E>::THREADS), 0, s, \
+		#define CLO_R1_SWEEP(CL, EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL, EARLY>), dim3(tiles), dim3(sweep_shape<E>::THREADS), 0, s, \
 			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P, \
 			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none)
 		if (chunk_log == 3) CLO_R1_SWEEP(3, 8); else if (early == 0) CLO_R1_SWEEP(4, 0); else CLO_R1_SWEEP(4, 8);
@@ -586,14 +586,18 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
-	// The library's choice (measured): from 4 to 1024 tiles (2^15 ..
-	// 2^23 4-byte elements) the sort is launch-bound and the sweeps need 6 launches
-	// instead of 12: the same time up to 2^18, 10-40 % less from 2^19 on (and half
-	// the events on a profiling queue); above that the two are within 3 % of each other
-	// (the sweep's tile histogram and its one exposed round trip cost what the
-	// separate histogram kernel costs), and the chain-free passes keep the sort free
-	// of any wait between work-groups.
-	return tiles >= 4 && tiles <= 1024;
+	// The library's choice (measured; profiles/r02_sweep_sizes_big.txt):
+	// * 4 .. 1024 tiles (2^15 .. 2^23 4-byte elements): the sort is launch-bound and the
+	//   sweeps need 6 launches instead of 12: the same time up to 2^18, 5-40 % less from
+	//   2^19 on (and half the events on a profiling queue);
+	// * 64 .. 256 MiB: the chain-free passes, 1-13 % faster — the array sits in the
+	//   256 MiB last-level cache, where their second read of every element is cheap;
+	// * from 512 MiB: the sweeps again, 2-8 % faster (half the reads now come from HBM),
+	//   except 4-byte elements from 1 GiB (the headline size), where the two differ by
+	//   1 % and the chain-free passes keep the sort free of any wait between work-groups.
+	if (tiles >= 4 && tiles <= 1024) return 1;
+	const size_t bytes = n * (size_t) elem_size;
+	return bytes >= ((size_t) 512 << 20) && !(elem_size == 4 && bytes >= ((size_t) 1 << 30));
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

@@ -417,7 +417,7 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 
 // static LDS of the pass kernel (introspection: clo_sort_get_localmem_usage)
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
-	const size_t threads = 512;
+	const size_t threads = elem_size >= 4 ? CLO_PAIR_THREADS : 512;
 	const int half = digit_bits <= 4 ? digit_bits : (digit_bits + 1) / 2;   // the wider of the two local digits
 	const size_t hmax = half >= 4 ? 8 : (half == 3 ? 4 : (half == 2 ? 2 : 1));
 	const size_t pass_bits = digit_bits <= 4 ? 2 * digit_bits : digit_bits;

@@ -226,12 +226,23 @@ __device__ __forceinline__ unsigned clo_xcc_id() {
 	return (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
 }
 
-// Shape of a tile of the pass kernels: 512 threads x 16 consecutive elements
-// (8 for 8-byte elements) = 32 KiB of LDS stage either way.
-template <typename E> struct pair_shape {
-	static constexpr int THREADS = 512;                           // tiles of 8192 (<= 4-byte elements) / 4096 elements,
-	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;         // = the tiles of clo_hip_radixw.hip's histogram
+// Shape of a tile of the single-sweep pass kernels: 512 threads x 16 consecutive
+// elements (8 for 8-byte elements) = 32 KiB of LDS stage either way.
+template <typename E> struct sweep_shape {
+	static constexpr int THREADS = 512;
+	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
 };
+
+// Shape of a tile of the chain-free pair passes (= the tiles of
+// clo_hip_radixw.hip's histogram, which takes CLO_PAIR_TILE_ELEMS).
+#ifndef CLO_PAIR_THREADS
+#define CLO_PAIR_THREADS 512
+#endif
+template <typename E> struct pair_shape {
+	static constexpr int THREADS = sizeof(E) >= 4 ? CLO_PAIR_THREADS : 512;
+	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
+};
+#define CLO_PAIR_TILE_ELEMS(elem_size) ((size_t) ((elem_size) >= 4 ? CLO_PAIR_THREADS : 512) * ((elem_size) == 8 ? 8 : 16))
 
 }  // namespace
 

@@ -15,16 +15,21 @@
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
+#include "clo_hip_radix_rank.h"
 
 namespace {
 
-constexpr int RW_THREADS = 512;
+#ifndef CLO_RW_THREADS
+#define CLO_RW_THREADS 512
+#endif
+constexpr int RW_THREADS = CLO_RW_THREADS;
 constexpr int RW_CHUNK = 128;   // tiles per chunk of the counter scan
 
-// 32 KiB LDS stage for 4- and 8-byte elements
+// the pair kernel's tile (clo_hip_radix_rank.h), RW_THREADS threads
 template <typename E> struct rw_shape {
-	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
-	static constexpr int TILE = RW_THREADS * ITEMS;
+	static constexpr int TILE = (int) CLO_PAIR_TILE_ELEMS(sizeof(E));
+	static constexpr int ITEMS = TILE / RW_THREADS;
+	static_assert(ITEMS * RW_THREADS == TILE, "whole elements per thread");
 };
 
 // ---------------------------------------------------------------------------
@@ -242,7 +247,7 @@ void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned til
 
 // ---- the histogram / counter-scan steps for any digit width 1..8 (used by
 // the digit-pair passes of clo_hip_radix4.hip) ----
-size_t clo_radixw_tile_elems(int elem_size) { return (size_t) RW_THREADS * (elem_size == 8 ? 8 : 16); }
+size_t clo_radixw_tile_elems(int elem_size) { return CLO_PAIR_TILE_ELEMS(elem_size); }
 
 template <typename E>
 static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift, unsigned mask, unsigned* thist,

@@ -144,6 +144,12 @@ CCLEvent* ccl_queue_begin_command_after(CCLQueue* cq, const char* name, CCLEvent
 cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err);
 void ccl_queue_abort_command(CCLQueue* cq, CCLEvent* evt);
 int ccl_queue_is_profiling(CCLQueue* cq);
+/* For the library's own objects that remember the queue of their last call
+ * (clo_stream_guard): keep the queue STRUCT alive past ccl_queue_destroy, which
+ * still synchronises and closes the queue at once. */
+void clo_queue_hold(CCLQueue* cq);
+void clo_queue_drop(CCLQueue* cq);
+int clo_queue_is_closed(CCLQueue* cq);
 /* A kernel that waits for other work-groups bounds its spins and raises a
  * status word in device memory when it gives up (clo_hip.h: clo_hip_check_status).
  * The owner of that word wraps it in a cell and has every queue it enqueues on

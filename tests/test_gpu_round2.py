@@ -195,6 +195,43 @@ def test_queue_without_profiling_recycles_its_events(gpu):
         x.close()
 
 
+def test_sorter_and_scanner_move_between_queues(gpu):
+    """The cached buffers of a sorter / scanner follow the queue of the call: two
+    live queues alternating (the later call waits for the earlier one's work, no
+    host synchronisation in between), and a queue destroyed while the sorter
+    still remembers it (its struct is held, its stream is gone)."""
+    import cl_ops_amd as clo
+    ctx, _ = gpu
+    n = (1 << 22) + 3
+    rng = np.random.default_rng(11)
+    q1, q2 = clo.Queue(ctx), clo.Queue(ctx)
+    s = clo.Sorter("satradix", ctx, "uint")
+    sc = clo.Scanner("blelloch", ctx, "uint", "ulong")
+    bufs = []
+    for k in range(6):
+        q = (q1, q2)[k % 2]
+        a = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+        src, dst, sums = clo.Buffer(ctx, n * 4), clo.Buffer(ctx, n * 4), clo.Buffer(ctx, n * 8)
+        src.write(q, a)
+        s.with_device_data(q, src, dst, n)     # no finish: the next call, on the other queue, reuses the sorter's buffers
+        sc.with_device_data(q, src, sums, n)
+        bufs.append((q, a, src, dst, sums))
+    q1.finish()
+    q2.finish()
+    for q, a, src, dst, sums in bufs:
+        assert np.array_equal(dst.read(q, np.uint32, n), np.sort(a))
+        assert np.array_equal(sums.read(q, np.uint64, n), _excl(a, np.uint64))
+        for x in (src, dst, sums):
+            x.close()
+    q2.close()                                  # the sorter's last call ran on q2
+    q3 = clo.Queue(ctx)
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+    assert np.array_equal(s.with_host_data(a, q3), np.sort(a))
+    assert np.array_equal(sc.with_host_data(a, q3), _excl(a, np.uint64))
+    for x in (s, sc, q1, q3):
+        x.close()
+
+
 def test_full_size_satradix_u64_2p28_shard_of_config_5(gpu):
     """Config 5's per-GPU shard: 2^28 uint64 keys, radix 16. Size-independent
     properties on the full array (order, multiset checksums, idempotence of a

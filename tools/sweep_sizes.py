@@ -1,5 +1,5 @@
 """ms per sort, chain-free pair passes vs single-sweep passes, over sizes and element kinds
-(device-resident, back-to-back sorts). GPU box only. usage: python tools/sweep_sizes.py"""
+(device-resident, back-to-back sorts). GPU box only. usage: python tools/sweep_sizes.py [big]"""
 import os
 import sys
 
@@ -50,6 +50,12 @@ def bench(kind, log2n):
     bd.close()
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "big":   # where should the default switch back for 8-byte elements?
+    for rep in range(2):
+        for kind in ("u64", "pairs", "u32"):
+            for l in (22, 23, 24, 25, 26, 27, 28):
+                bench(kind, l)
+    sys.exit(0)
 for l in (14, 15, 16, 17, 18, 19, 20, 22, 24, 26, 28):
     bench("u32", l)
 for l in (20, 24, 28):
