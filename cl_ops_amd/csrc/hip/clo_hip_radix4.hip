@@ -49,7 +49,7 @@ namespace {
 // 2^28 8-byte elements 1.84 -> 0.86 ms per pass, 4-byte 0.79 -> 0.69 ms.
 // ---------------------------------------------------------------------------
 template <typename E, int LB, int HB>
-__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs
+__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (56 used)
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
@@ -100,16 +100,20 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
 	}
 	// tile-local start of every combined digit: exclusive scan of the tile's histogram
-	const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
-	if (lane == 63 && wave < 4) s_w4[wave] = incl2;
+	{
+		const unsigned incl2 = clo_wave_scan_inclusive<unsigned>(h2, lane);
+		if (lane == 63 && wave < 4) s_w4[wave] = incl2;
+		// (parked in LDS across the first split: three registers fewer while it runs)
+		if (tid < (unsigned) R2) s_delta[tid] = goff - (incl2 - h2);
+	}
 
 	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
 
 	if (tid < (unsigned) R2) {
-		unsigned dstart2 = incl2 - h2;
+		unsigned before = 0;   // counts of the lower combined digits in the earlier waves' share of the histogram row
 		#pragma unroll
-		for (unsigned w = 0; w < 4; ++w) if (w < wave) dstart2 += s_w4[w];
-		s_delta[tid] = goff - dstart2;
+		for (unsigned w = 0; w < 4; ++w) if (w < wave) before += s_w4[w];
+		s_delta[tid] -= before;
 	}
 	if (mask_hi != 0) {
 		if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)

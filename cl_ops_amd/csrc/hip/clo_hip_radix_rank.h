@@ -188,7 +188,7 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		unsigned run = 0, dstart16[H];
 		#pragma unroll
 		for (int j = 0; j < H; ++j) {
-			const unsigned t = (unsigned) __shfl((int) tot[j / 4], (j % 4) * 16 + 15, 64);   // packed totals of digits 2j, 2j+1
+			const unsigned t = (unsigned) __builtin_amdgcn_readlane((int) tot[j / 4], (j % 4) * 16 + 15);   // packed totals of digits 2j, 2j+1 (wave-uniform: scalar registers)
 			dstart16[j] = run | ((run + (t & 0xffffu)) << 16);
 			run += (t & 0xffffu) + (t >> 16);
 		}
@@ -203,12 +203,14 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 	}
 	mid();
 	clo_lds_barrier();
+	typedef unsigned __attribute__((may_alias)) pc_u32;           // (the rows are written as dwords and read as halves:
+	typedef unsigned short __attribute__((may_alias)) pc_u16;   //  without this the compiler may move the reads above the writes)
 	#pragma unroll
 	// the thread's 16-bit ends, thread-major with a stride of PC_END_STRIDE dwords
 	// (odd: the lanes' rows start in different banks): the lookup per element is
 	// one address (digit * 2 + row) and one ds_read_u16
-	for (int j = 0; j < H; ++j) s_end[tid * PC_END_STRIDE + j] = w[j] + s_wbase[wave][j];
-	const unsigned short* s_end16 = reinterpret_cast<const unsigned short*>(s_end) + tid * (2 * PC_END_STRIDE);
+	for (int j = 0; j < H; ++j) reinterpret_cast<pc_u32*>(s_end)[tid * PC_END_STRIDE + j] = w[j] + s_wbase[wave][j];
+	const pc_u16* s_end16 = reinterpret_cast<const pc_u16*>(s_end) + tid * (2 * PC_END_STRIDE);
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		if (full || tbase + i < count) {
