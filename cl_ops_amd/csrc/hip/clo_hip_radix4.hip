@@ -49,7 +49,7 @@ namespace {
 // 2^28 8-byte elements 1.84 -> 0.86 ms per pass, 4-byte 0.79 -> 0.69 ms.
 // ---------------------------------------------------------------------------
 template <typename E, int LB, int HB>
-__global__ __launch_bounds__(pair_shape<E>::THREADS, 6)   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (56 used)
+__global__ __launch_bounds__(pair_shape<E>::THREADS, pair_shape<E>::THREADS >= 512 ? 6 : 3)   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (56 used)
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
@@ -421,11 +421,11 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 
 // static LDS of the pass kernel (introspection: clo_sort_get_localmem_usage)
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
-	const size_t threads = elem_size >= 4 ? CLO_PAIR_THREADS : 512;
+	const size_t threads = elem_size == 8 ? CLO_PAIR_THREADS_8B : (elem_size == 4 ? CLO_PAIR_THREADS : 512);
 	const int half = digit_bits <= 4 ? digit_bits : (digit_bits + 1) / 2;   // the wider of the two local digits
 	const size_t hmax = half >= 4 ? 8 : (half == 3 ? 4 : (half == 2 ? 2 : 1));
 	const size_t pass_bits = digit_bits <= 4 ? 2 * digit_bits : digit_bits;
-	const size_t items = elem_size == 8 ? 8 : 16;
+	const size_t items = elem_size == 8 ? CLO_PAIR_ITEMS_8B : 16;
 	return threads * items * (size_t) elem_size + threads * PC_END_STRIDE * sizeof(unsigned)
 		+ (2 * (threads / 64) * hmax + ((size_t) 1 << pass_bits) + 4) * sizeof(unsigned);
 }

@@ -240,11 +240,18 @@ template <typename E> struct sweep_shape {
 #ifndef CLO_PAIR_THREADS
 #define CLO_PAIR_THREADS 512
 #endif
+#ifndef CLO_PAIR_THREADS_8B      // 8-byte elements: threads x elements per thread (8 or 16)
+#define CLO_PAIR_THREADS_8B CLO_PAIR_THREADS
+#endif
+#ifndef CLO_PAIR_ITEMS_8B
+#define CLO_PAIR_ITEMS_8B 8
+#endif
 template <typename E> struct pair_shape {
-	static constexpr int THREADS = sizeof(E) >= 4 ? CLO_PAIR_THREADS : 512;
-	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
+	static constexpr int THREADS = sizeof(E) == 8 ? CLO_PAIR_THREADS_8B : (sizeof(E) == 4 ? CLO_PAIR_THREADS : 512);
+	static constexpr int ITEMS = sizeof(E) == 8 ? CLO_PAIR_ITEMS_8B : 16;
 };
-#define CLO_PAIR_TILE_ELEMS(elem_size) ((size_t) ((elem_size) >= 4 ? CLO_PAIR_THREADS : 512) * ((elem_size) == 8 ? 8 : 16))
+#define CLO_PAIR_TILE_ELEMS(elem_size) ((elem_size) == 8 ? (size_t) CLO_PAIR_THREADS_8B * CLO_PAIR_ITEMS_8B \
+	: (size_t) ((elem_size) == 4 ? CLO_PAIR_THREADS : 512) * 16)
 
 }  // namespace
 
