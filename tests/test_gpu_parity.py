@@ -635,9 +635,12 @@ def _xor_sum(a):
     return int(np.bitwise_xor.reduce(a)), int(a.sum(dtype=np.uint64))
 
 
-def test_full_size_satradix_u32_2p28(gpu):
+@pytest.mark.parametrize("path", ["library's choice", "chain-free pair passes", "single-sweep passes"])
+def test_full_size_satradix_u32_2p28(gpu, monkeypatch, path):
     import cl_ops_amd as clo
     ctx, q = gpu
+    if path != "library's choice":   # (read by the library at every call)
+        monkeypatch.setenv("CLO_RADIX_SWEEP", "1" if path == "single-sweep passes" else "0")
     n = 1 << 28
     a = np.random.default_rng(28).integers(0, 1 << 32, n, dtype=np.uint32)
     s = clo.Sorter("satradix", ctx, "uint")
@@ -656,10 +659,13 @@ def test_full_size_satradix_u32_2p28(gpu):
     s.close()
 
 
-def test_full_size_satradix_pairs_2p28(gpu):
+@pytest.mark.parametrize("path", ["library's choice", "chain-free pair passes", "single-sweep passes"])
+def test_full_size_satradix_pairs_2p28(gpu, monkeypatch, path):
     """Config 4: 2^28 (uint key, uint value) pairs; stable == values increase inside equal-key runs."""
     import cl_ops_amd as clo
     ctx, q = gpu
+    if path != "library's choice":
+        monkeypatch.setenv("CLO_RADIX_SWEEP", "1" if path == "single-sweep passes" else "0")
     n = 1 << 28
     keys = np.random.default_rng(4).integers(0, 1 << 26, n, dtype=np.uint64)   # ~4 duplicates per key
     a = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)

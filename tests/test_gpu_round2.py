@@ -232,13 +232,17 @@ def test_sorter_and_scanner_move_between_queues(gpu):
         x.close()
 
 
-def test_full_size_satradix_u64_2p28_shard_of_config_5(gpu):
+@pytest.mark.parametrize("path", ["library's choice", "chain-free pair passes"])
+def test_full_size_satradix_u64_2p28_shard_of_config_5(gpu, monkeypatch, path):
     """Config 5's per-GPU shard: 2^28 uint64 keys, radix 16. Size-independent
     properties on the full array (order, multiset checksums, idempotence of a
-    second sort) and exact equality with numpy on slices picked by value."""
+    second sort) and exact equality with numpy on slices picked by value. The
+    library sorts this size with the single-sweep passes; the other path too."""
     import torch
     import cl_ops_amd as clo
     ctx, q = gpu
+    if path != "library's choice":
+        monkeypatch.setenv("CLO_RADIX_SWEEP", "0")
     n = 1 << 28
     g = torch.Generator(device="cuda")
     g.manual_seed(28)
