@@ -48,6 +48,7 @@
 namespace {
 
 constexpr int R1_CHUNK_LOG_DEFAULT = 4;              // 16 tiles per chunk (a template parameter of the sweep kernel)
+constexpr int R1_PEEL = 4;                           // groups of equal digits a skewed wave counts by ballot, per element
 constexpr int R1_WINDOW = 8;                         // chunks a level-2 hop inspects
 constexpr unsigned R1_VALID = 0x80000000u;            // 32-bit entries: bit 31 = written, bits 30..0 = count
 constexpr int R1_CNT_SHIFT = 40;                      // 64-bit accumulators: arrivals << 40 | sum
@@ -255,9 +256,40 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
 	}
 	if (P.stamps) t1 = __builtin_amdgcn_s_memtime();
-	#pragma unroll
-	for (int i = 0; i < ITEMS; ++i)
-		if (full || tbase + i < count) atomicAdd(&s_hist[wave * R1_ROW + ((unsigned) (key[i] >> shift) & mask2)], 1u);
+	{
+		// Keys that repeat (few distinct values, one hot bin) put many lanes of an LDS add
+		// on ONE address, which the LDS serialises lane by lane: 2^28 equal keys sorted
+		// in 6.5 ms instead of 3.0. A wave that sees a quarter of its lanes agree on the
+		// first element's digit counts by groups instead: up to R1_PEEL times per element
+		// the lanes that share the first remaining lane's digit are counted with one
+		// ballot and added by that lane alone; whoever is left adds as usual.
+		const unsigned d0 = (unsigned) (key[0] >> shift) & mask2;
+		const bool skewed = __popcll(__ballot(d0 == (unsigned) __builtin_amdgcn_readfirstlane((int) d0))) >= 16;   // wave-uniform
+		unsigned* const row = s_hist + wave * R1_ROW;
+		if (!skewed) {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i)
+				if (full || tbase + i < count) atomicAdd(&row[(unsigned) (key[i] >> shift) & mask2], 1u);
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) {
+				const unsigned d = (unsigned) (key[i] >> shift) & mask2;
+				bool mine = full || tbase + i < count;   // still to be counted
+				#pragma unroll 1
+				for (int r = 0; r < R1_PEEL; ++r) {
+					const unsigned long long rem = __ballot(mine);
+					if (rem == 0) break;
+					const int l = __ffsll((long long) rem) - 1;
+					const unsigned dl = (unsigned) __builtin_amdgcn_readlane((int) d, l);
+					const bool grp = mine && d == dl;
+					const unsigned cnt = (unsigned) __popcll(__ballot(grp));
+					if ((int) lane == l) atomicAdd(&row[dl], cnt);
+					mine = mine && !grp;
+				}
+				if (mine) atomicAdd(&row[d], 1u);
+			}
+		}
+	}
 
 	// ---- first local split; between its first two barriers (all counts are in by
 	// then) the digit threads publish the tile's row and its arrival at the chunk ----

@@ -195,6 +195,38 @@ def test_queue_without_profiling_recycles_its_events(gpu):
         x.close()
 
 
+@pytest.mark.parametrize("dist", ["all equal", "8 distinct", "90 % in one bin of every digit", "sorted", "quarter of each wave equal"])
+def test_sweep_passes_on_repeating_keys(gpu, dist):
+    """Sizes the library sorts with the single-sweep passes, keys that repeat: waves whose
+    lanes agree count their digits by groups (one ballot per group) instead of one LDS add
+    per lane; the result must not depend on which way a wave counted. Keys alone and
+    stable (key, index) pairs."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = (1 << 20) + 77
+    rng = np.random.default_rng(len(dist))
+    if dist == "all equal":
+        k = np.full(n, 0x5A5A5A5A, np.uint32)
+    elif dist == "8 distinct":
+        k = (rng.integers(0, 8, n, dtype=np.uint32) * np.uint32(0x11111111)).astype(np.uint32)
+    elif dist.startswith("90"):
+        k = np.where(rng.integers(0, 10, n) > 0, np.uint32(0x77777777), rng.integers(0, 1 << 32, n, dtype=np.uint32)).astype(np.uint32)
+    elif dist == "sorted":
+        k = np.sort(rng.integers(0, 1 << 32, n, dtype=np.uint32))
+    else:   # lanes 0..15 of every wave's first element agree, everything else is random
+        k = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+        first = np.arange(0, n, 16)            # element 0 of every thread (16 consecutive elements per thread)
+        lanes = (first // 16) % 64
+        k[first[lanes < 16]] = 0xC3C3C3C3
+    s = clo.Sorter("satradix", ctx, "uint")
+    assert np.array_equal(s.with_host_data(k, q), np.sort(k))
+    s.close()
+    pairs = (k.astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    sp = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    assert np.array_equal(sp.with_host_data(pairs, q), O.stable_sort(pairs, key_size=4, key_shift=32))
+    sp.close()
+
+
 def test_sorter_and_scanner_move_between_queues(gpu):
     """The cached buffers of a sorter / scanner follow the queue of the call: two
     live queues alternating (the later call waits for the earlier one's work, no
