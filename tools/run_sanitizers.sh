@@ -18,7 +18,7 @@ for f in "$ROOT"/cl_ops_amd/csrc/*.c; do
 done
 ASAN_LIB=$(gcc -print-file-name=libasan.so)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/cl_ops_amd/lib/libcl_ops_hip.so" \
-	"$ROOT"/cl_ops_amd/csrc/build/*.hip.o "$SAN"/*.c.o -lhiprtc -L"$(dirname "$ASAN_LIB")" -lasan -lubsan
+	"$ROOT"/cl_ops_amd/csrc/build/*.hip.o "$SAN"/*.c.o -lhiprtc -ldl -L"$(dirname "$ASAN_LIB")" -lasan -lubsan
 gcc -O1 -g -std=c11 -fPIC -fopenmp -fsanitize=address,undefined -shared -o "$ROOT/oracle/libclo_oracle.so" "$ROOT/oracle/clo_oracle.c"
 cd "$ROOT"
 LD_PRELOAD=$ASAN_LIB ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 \
