@@ -39,7 +39,8 @@ __device__ __forceinline__ unsigned dpp_add(unsigned x) {
 	return x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true);
 }
 
-constexpr int PC_END_STRIDE = 9;   // dwords per thread in the table of ends: 8 words of two digits each, padded to an odd stride
+constexpr int PC_BATCH = 4;        // lookups of ends requested together in a full tile
+constexpr int PC_END_STRIDE = 8;   // dwords per thread in the table of ends: 16 digits x 16 bits (digit-major, see pc_local_split)
 
 template <int BITS> struct pc_words { static constexpr int H = (1 << BITS) >= 2 ? (1 << BITS) / 2 : 1; };
 
@@ -104,6 +105,35 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned lon
 	}
 }
 
+// Byte K of a register: written from the low byte of x / subtracted from a — one SDWA
+// instruction each (in C the first is a shift, a mask and an or; the second an
+// extract and a subtract). K is a constant after unrolling.
+__device__ __forceinline__ void pc_put_byte(unsigned& dst, unsigned x, int K) {
+	switch (K) {
+		case 0: asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(dst) : "v"(x)); break;
+		case 1: asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(dst) : "v"(x)); break;
+		case 2: asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(dst) : "v"(x)); break;
+		default: asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(dst) : "v"(x)); break;
+	}
+}
+__device__ __forceinline__ unsigned pc_sub_byte(unsigned a, unsigned b, int K) {
+	unsigned r;
+	switch (K) {
+		case 0: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b)); break;
+		case 1: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b)); break;
+		case 2: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b)); break;
+		default: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b)); break;
+	}
+	return r;
+}
+// The digit of a key: one bit-field extract for elements of up to 4 bytes
+// (nbits = the number of bits of the digit's mask, the same for the whole launch).
+template <typename E>
+__device__ __forceinline__ unsigned pc_digit(E key, unsigned dshift, unsigned dmask, unsigned nbits) {
+	if constexpr (sizeof(E) <= 4) return __builtin_amdgcn_ubfe((unsigned) key, dshift, nbits);
+	else return (unsigned) (key >> dshift) & dmask;
+}
+
 // One stable local split of the tile by the digit (key >> dshift) & dmask;
 // on return (after a barrier) s_stage holds the tile in digit order. The
 // thread's elements are ITEMS consecutive positions of the tile.
@@ -115,46 +145,45 @@ __device__ __forceinline__ void pc2_wave_scan(unsigned long long c, unsigned lon
 struct pc_no_mid { __device__ __forceinline__ void operator()() const {} };
 struct pc_no_counted { __device__ __forceinline__ void operator()(unsigned long long, unsigned long long) const {} };
 
-template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid, typename Counted = pc_no_counted>
-__device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
-	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid = Mid(), Counted counted = Counted()) {
+// FULL: every element of the tile exists. The two loops over the thread's elements
+// then carry no per-element test: compiled with one (`full || tbase + i < count`),
+// every element sat in a basic block of its own — a compare, an exec-mask dance and
+// a scalar branch each, and the lookup of its end waited for (`s_waitcnt lgkmcnt(0)`)
+// before the next element's was even requested.
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, bool FULL, typename Mid, typename Counted>
+__device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid, Counted counted) {
 	constexpr int H = pc_words<BITS>::H;
 	constexpr int WAVES = THREADS / 64;
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	const unsigned tbase = tid * ITEMS;
-	const bool full = count == (unsigned) (THREADS * ITEMS);
 
-	// thread-private counts, LAST element first: rr = 1 + the number of LATER
-	// elements of the thread with the same digit, so that the element's position
-	// is (end of the thread's slice of that digit) - rr. More than 8 elements
-	// per thread: two counters (4-bit fields hold up to 15).
+	// Thread-private counts, LAST element first: `before` = the number of LATER
+	// elements of the thread with the same digit (<= 15), so that the element's
+	// position is (end of the thread's slice of that digit) - before - 1; kept as
+	// bytes, four to a register. More than 8 elements per thread: two counters for
+	// the wave scan (a 4-bit field holds up to 15): elements 15..8 count in c2; the
+	// running counter then starts from c2, so one shift reads an element's `before`
+	// (its last increment may carry out of a field: it is never read again), and
+	// c = run - c2 (exact: integer addition) is the count of elements 7..0 alone.
 	static_assert(ITEMS == 8 || ITEMS == 16, "one or two packed counters");
-	unsigned long long c = 0, c2 = 0;
-	// ITEMS == 8: one register per rank; ITEMS == 16: (rank - 1) packed 4 bits each (register budget)
-	unsigned rr[ITEMS == 8 ? 8 : 2];
+	unsigned long long run = 0, c2 = 0;
+	unsigned rb[ITEMS / 4];
+	const unsigned nbits = (unsigned) __builtin_popcount(dmask);
 	#pragma unroll
-	for (int k = 0; k < (ITEMS == 8 ? 8 : 2); ++k) rr[k] = 0;
+	for (int k = 0; k < ITEMS / 4; ++k) rb[k] = 0;
 	#pragma unroll
-	for (int i = ITEMS - 1; i >= 8; --i) {   // (ITEMS == 16 only)
-		if (full || tbase + i < count) {
-			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
-			rr[1] |= ((unsigned) (c2 >> sh) & 15u) << (4 * (i - 8));   // count BEFORE this element = rank - 1
-			c2 += 1ull << sh;
+	for (int i = ITEMS - 1; i >= 0; --i) {
+		if (ITEMS == 16 && i == 7) c2 = run;
+		if (FULL || tbase + i < count) {
+			const unsigned sh = pc_digit<E>(key[i], dshift, dmask, nbits) * 4u;
+			pc_put_byte(rb[i >> 2], (unsigned) (run >> sh), i & 3);   // (the byte's high half is the next field: masked below)
+			run += 1ull << sh;
 		}
 	}
+	const unsigned long long c = run - c2;
 	#pragma unroll
-	for (int i = 7; i >= 0; --i) {
-		if (full || tbase + i < count) {
-			const unsigned sh = ((unsigned) (key[i] >> dshift) & dmask) * 4u;
-			if (ITEMS == 8) {
-				c += 1ull << sh;
-				rr[i] = (unsigned) (c >> sh) & 15u;
-			} else {
-				rr[0] |= ((((unsigned) (c >> sh) & 15u) + ((unsigned) (c2 >> sh) & 15u)) & 15u) << (4 * i);   // <= 15
-				c += 1ull << sh;
-			}
-		}
-	}
+	for (int k = 0; k < ITEMS / 4; ++k) rb[k] &= 0x0f0f0f0fu;
 	counted(c, c2);
 	unsigned w[H];
 	pc2_wave_scan<BITS, (ITEMS > 8)>(c, c2, w);
@@ -203,24 +232,41 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 	}
 	mid();
 	clo_lds_barrier();
-	typedef unsigned __attribute__((may_alias)) pc_u32;           // (the rows are written as dwords and read as halves:
-	typedef unsigned short __attribute__((may_alias)) pc_u16;   //  without this the compiler may move the reads above the writes)
+	// The table of ends: 16-bit entries, DIGIT-major, one row of THREADS entries per
+	// digit; inside a row a wave's lanes l and l + 32 share a dword. The bank of an
+	// entry then depends on the lane alone (dword index = digit * THREADS / 2 + wave * 32
+	// + l % 32), so neither the 16 writes nor the lookup of an element's end ever
+	// conflict, whatever the digits are. (Thread-major rows of 9 dwords — the first
+	// layout — put lanes with different digits on one bank: with the scattered stage
+	// writes, half of the kernel's LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT.)
+	typedef unsigned short __attribute__((may_alias)) pc_u16;   // (the array is declared as dwords)
+	pc_u16* const tab = reinterpret_cast<pc_u16*>(s_end) + ((tid & ~63u) + ((tid & 31u) << 1) + ((tid >> 5) & 1u));
 	#pragma unroll
-	// the thread's 16-bit ends, thread-major with a stride of PC_END_STRIDE dwords
-	// (odd: the lanes' rows start in different banks): the lookup per element is
-	// one address (digit * 2 + row) and one ds_read_u16
-	for (int j = 0; j < H; ++j) reinterpret_cast<pc_u32*>(s_end)[tid * PC_END_STRIDE + j] = w[j] + s_wbase[wave][j];
-	const pc_u16* s_end16 = reinterpret_cast<const pc_u16*>(s_end) + tid * (2 * PC_END_STRIDE);
+	for (int j = 0; j < H; ++j) {
+		const unsigned e2 = w[j] + s_wbase[wave][j];
+		tab[(2 * j) * THREADS] = (unsigned short) e2;
+		if (2 * j + 1 < (1 << BITS)) tab[(2 * j + 1) * THREADS] = (unsigned short) (e2 >> 16);
+	}
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
-		if (full || tbase + i < count) {
-			const unsigned d = (unsigned) (key[i] >> dshift) & dmask;
-			const unsigned end = s_end16[d];
-			const unsigned back = ITEMS == 8 ? rr[i] : ((rr[i >> 3] >> (4 * (i & 7))) & 15u) + 1u;
-			s_stage[end - back] = key[i];   // (counts of these very elements: always inside the tile)
+		// (lookups in flight: PC_BATCH at a time — all ITEMS at once cost 2 * ITEMS registers)
+		if (FULL && i > 0 && i % PC_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+		if (FULL || tbase + i < count) {
+			const unsigned d = pc_digit<E>(key[i], dshift, dmask, nbits);
+			const unsigned end = tab[d * THREADS];
+			s_stage[pc_sub_byte(end, rb[i >> 2], i & 3) - 1u] = key[i];   // end - before - 1 (counts of these very elements: always inside the tile)
 		}
 	}
 	clo_lds_barrier();
+}
+
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid, typename Counted = pc_no_counted>
+__device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid = Mid(), Counted counted = Counted()) {
+	if (count == (unsigned) (THREADS * ITEMS))   // (the same for the whole work-group)
+		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, true>(key, dshift, dmask, count, s_stage, s_end, s_wtot, s_wbase, mid, counted);
+	else
+		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, false>(key, dshift, dmask, count, s_stage, s_end, s_wtot, s_wbase, mid, counted);
 }
 
 // XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Used for speed only.
