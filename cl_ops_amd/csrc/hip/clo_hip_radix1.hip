@@ -624,12 +624,14 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	//   2^19 on (and half the events on a profiling queue);
 	// * 64 .. 256 MiB: the chain-free passes, 1-13 % faster — the array sits in the
 	//   256 MiB last-level cache, where their second read of every element is cheap;
-	// * from 512 MiB: the sweeps again, 2-8 % faster (half the reads now come from HBM),
-	//   except 4-byte elements from 1 GiB (the headline size), where the two differ by
-	//   1 % and the chain-free passes keep the sort free of any wait between work-groups.
+	// * 512 MiB up to 2^28 elements: the sweeps again, 2-7 % faster (half the reads now
+	//   come from HBM);
+	// * 2^28 elements and more (the headline sizes: uint32, pairs, config 5's uint64
+	//   shard): the chain-free passes on their 16 384-element tiles, 1-5 % faster than
+	//   the sweeps, and no work-group ever waits for another.
 	if (tiles >= 4 && tiles <= 1024) return 1;
 	const size_t bytes = n * (size_t) elem_size;
-	return bytes >= ((size_t) 512 << 20) && !(elem_size == 4 && bytes >= ((size_t) 1 << 30));
+	return bytes >= ((size_t) 512 << 20) && n < ((size_t) 1 << 28);
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

@@ -48,15 +48,15 @@ namespace {
 // lines in the output, behind the same L2, where the two partial writes merge:
 // 2^28 8-byte elements 1.84 -> 0.86 ms per pass, 4-byte 0.79 -> 0.69 ms.
 // ---------------------------------------------------------------------------
-template <typename E, int LB, int HB>
-__global__ __launch_bounds__(pair_shape<E>::THREADS, pair_shape<E>::THREADS >= 512 ? 6 : 3)   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (56 used)
+template <typename E, int LB, int HB, bool BIG>
+__global__ __launch_bounds__((pair_shape<E, BIG>::THREADS), (pair_shape<E, BIG>::THREADS >= 1024 ? 8 : 6))   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (59 used); BIG: 2 x 16 waves, <= 64
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
 	clo_keyx kx_in, clo_keyx kx_out) {
 
-	constexpr int THREADS = pair_shape<E>::THREADS;
-	constexpr int ITEMS = pair_shape<E>::ITEMS;
+	constexpr int THREADS = pair_shape<E, BIG>::THREADS;
+	constexpr int ITEMS = pair_shape<E, BIG>::ITEMS;
 	constexpr int TILE = THREADS * ITEMS;
 	constexpr int WAVES = THREADS / 64;
 	constexpr int R2 = 1 << (LB + HB);
@@ -64,7 +64,8 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	static_assert(R2 <= 256 && R2 <= THREADS, "one thread per combined digit, scanned by the first four waves");
 
 	__shared__ __attribute__((aligned(16))) E s_stage[TILE];
-	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
+	constexpr bool ALIAS = pair_shape<E, BIG>::ALIAS;   // the table of ends inside the stage
+	__shared__ unsigned s_end[ALIAS ? 1 : THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][HMAX];
 	__shared__ unsigned s_wbase[WAVES][HMAX];
 	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
@@ -107,7 +108,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		if (tid < (unsigned) R2) s_delta[tid] = goff - (incl2 - h2);
 	}
 
-	pc_local_split<E, LB, THREADS, ITEMS, HMAX>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
+	pc_local_split<E, LB, THREADS, ITEMS, HMAX, pc_no_mid, pc_no_counted, ALIAS>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
 
 	if (tid < (unsigned) R2) {
 		unsigned before = 0;   // counts of the lower combined digits in the earlier waves' share of the histogram row
@@ -129,7 +130,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 			#pragma unroll
 			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) key[i] = s_stage[tbase + i];
 		}
-		pc_local_split<E, HB, THREADS, ITEMS, HMAX>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase);
+		pc_local_split<E, HB, THREADS, ITEMS, HMAX, pc_no_mid, pc_no_counted, ALIAS>(key, shift + LB, mask_hi, count, s_stage, s_end, s_wtot, s_wbase);
 	} else {
 		__syncthreads();
 	}
@@ -232,10 +233,10 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 // is one pass, split in two halves.
 struct rp_layout { size_t thist, toff, partial, total, tiles; };
 
-rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {
+rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {   // (tiles of the shape clo_radix_big_tiles picks for n)
 	rp_layout L;
 	const size_t R2 = (size_t) 1 << pass_bits;
-	const size_t tile = clo_radixw_tile_elems(elem_size);
+	const size_t tile = clo_pair_tile_elems(elem_size, clo_radix_big_tiles(n, elem_size));
 	L.tiles = (n + tile - 1) / tile;
 	if (L.tiles == 0) L.tiles = 1;
 	const size_t per = L.tiles * R2 * sizeof(unsigned);
@@ -255,6 +256,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles;
+	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
 	const clo_keyx kx_none = { 0, 0, 0 };
 
 	hipError_t e;   // (no kernel of the sort polls another work-group: the header's status word stays unused)
@@ -273,7 +275,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		{
 			clo_timing_scope timing("radix_hist", s);
 			const int st = clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
-				thist, tiles, p == 0 ? kx : kx_none, s);
+				thist, tiles, big, p == 0 ? kx : kx_none, s);
 			if (st != 0) return st;
 		}
 		{
@@ -283,9 +285,18 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		}
 		{
 			clo_timing_scope timing("radix_pass", s);
-			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E>::THREADS), 0, s,
-				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
-				(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none);
+			const int aligned = (int) ((uintptr_t) cur_in % 16 == 0);
+			const clo_keyx kin = p == 0 ? kx : kx_none, kout = p + 1 == passes ? kx : kx_none;
+			if constexpr (sizeof(E) >= 4) {
+				if (big) {
+					hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+						cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout);
+					cur_in = cur_out;
+					continue;
+				}
+			}
+			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
+				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout);
 		}
 		cur_in = cur_out;
 	}
@@ -352,15 +363,21 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES, s);   // (clo_hip_check_status may be asked about this workspace)
 	if (e != hipSuccess) return (int) e;
 	clo_timing_scope timing("msd_partition", s);
-	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tiles, kx_none, s);
+	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
+	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tiles, big, kx_none, s);
 	if (st != 0) return st;
 	if (counts)
 		hipLaunchKernelGGL((clo_radix4_counts_kernel<R, (1 << PB)>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);
 	st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, s);
 	if (st != 0) return st;
-	hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E>::THREADS), 0, s,
-		src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
-		(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none);
+	if (big)
+		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+			src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
+			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none);
+	else
+		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
+			src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
+			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none);
 	return (int) hipGetLastError();
 }
 
@@ -421,11 +438,11 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 
 // static LDS of the pass kernel (introspection: clo_sort_get_localmem_usage)
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
-	const size_t threads = elem_size == 8 ? CLO_PAIR_THREADS_8B : (elem_size == 4 ? CLO_PAIR_THREADS : 512);
+	const size_t threads = 512;   // (the shape of arrays below 256 MiB; larger ones: 1024 threads, table inside a 64 KiB stage)
 	const int half = digit_bits <= 4 ? digit_bits : (digit_bits + 1) / 2;   // the wider of the two local digits
 	const size_t hmax = half >= 4 ? 8 : (half == 3 ? 4 : (half == 2 ? 2 : 1));
 	const size_t pass_bits = digit_bits <= 4 ? 2 * digit_bits : digit_bits;
-	const size_t items = elem_size == 8 ? CLO_PAIR_ITEMS_8B : 16;
+	const size_t items = elem_size == 8 ? 8 : 16;
 	return threads * items * (size_t) elem_size + threads * PC_END_STRIDE * sizeof(unsigned)
 		+ (2 * (threads / 64) * hmax + ((size_t) 1 << pass_bits) + 4) * sizeof(unsigned);
 }

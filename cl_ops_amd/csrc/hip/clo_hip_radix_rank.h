@@ -150,7 +150,7 @@ struct pc_no_counted { __device__ __forceinline__ void operator()(unsigned long 
 // every element sat in a basic block of its own — a compare, an exec-mask dance and
 // a scalar branch each, and the lookup of its end waited for (`s_waitcnt lgkmcnt(0)`)
 // before the next element's was even requested.
-template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, bool FULL, typename Mid, typename Counted>
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, bool FULL, bool ALIAS, typename Mid, typename Counted>
 __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
 	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid, Counted counted) {
 	constexpr int H = pc_words<BITS>::H;
@@ -247,6 +247,7 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 		tab[(2 * j) * THREADS] = (unsigned short) e2;
 		if (2 * j + 1 < (1 << BITS)) tab[(2 * j + 1) * THREADS] = (unsigned short) (e2 >> 16);
 	}
+	unsigned pos[ALIAS ? ITEMS / 2 : 1];
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		// (lookups in flight: PC_BATCH at a time — all ITEMS at once cost 2 * ITEMS registers)
@@ -254,19 +255,37 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 		if (FULL || tbase + i < count) {
 			const unsigned d = pc_digit<E>(key[i], dshift, dmask, nbits);
 			const unsigned end = tab[d * THREADS];
-			s_stage[pc_sub_byte(end, rb[i >> 2], i & 3) - 1u] = key[i];   // end - before - 1 (counts of these very elements: always inside the tile)
+			if constexpr (ALIAS) {   // position kept (16 bits), stored after the barrier below
+				const unsigned p = pc_sub_byte(end, rb[i >> 2], i & 3) - 1u;
+				if (i & 1) pos[i >> 1] |= p << 16; else pos[i >> 1] = p & 0xffffu;
+			} else {
+				s_stage[pc_sub_byte(end, rb[i >> 2], i & 3) - 1u] = key[i];   // end - before - 1 (counts of these very elements: always inside the tile)
+			}
 		}
+	}
+	if constexpr (ALIAS) {
+		// the table lives in the head of the stage (thread-private, dead from here on)
+		clo_lds_barrier();
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i)
+			if (FULL || tbase + i < count) s_stage[(i & 1) ? pos[i >> 1] >> 16 : pos[i >> 1] & 0xffffu] = key[i];
 	}
 	clo_lds_barrier();
 }
 
-template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid, typename Counted = pc_no_counted>
+// ALIAS: the table of ends is built in the head of the stage itself (s_end is then
+// ignored; positions are looked up into registers, one more barrier, then the
+// stage is written) — for tiles whose stage and table do not both fit in LDS.
+// The stage must not be read by anyone between the call's first barrier and its end.
+template <typename E, int BITS, int THREADS, int ITEMS, int HMAX, typename Mid = pc_no_mid, typename Counted = pc_no_counted, bool ALIAS = false>
 __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask, unsigned count,
 	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX], Mid mid = Mid(), Counted counted = Counted()) {
+	static_assert(!ALIAS || (size_t) THREADS * PC_END_STRIDE * 4 <= (size_t) THREADS * ITEMS * sizeof(E), "the table fits in the stage");
+	unsigned* const tab = ALIAS ? reinterpret_cast<unsigned*>(s_stage) : s_end;
 	if (count == (unsigned) (THREADS * ITEMS))   // (the same for the whole work-group)
-		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, true>(key, dshift, dmask, count, s_stage, s_end, s_wtot, s_wbase, mid, counted);
+		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, true, ALIAS>(key, dshift, dmask, count, s_stage, tab, s_wtot, s_wbase, mid, counted);
 	else
-		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, false>(key, dshift, dmask, count, s_stage, s_end, s_wtot, s_wbase, mid, counted);
+		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, false, ALIAS>(key, dshift, dmask, count, s_stage, tab, s_wtot, s_wbase, mid, counted);
 }
 
 // XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Used for speed only.
@@ -281,23 +300,25 @@ template <typename E> struct sweep_shape {
 	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
 };
 
-// Shape of a tile of the chain-free pair passes (= the tiles of
-// clo_hip_radixw.hip's histogram, which takes CLO_PAIR_TILE_ELEMS).
-#ifndef CLO_PAIR_THREADS
-#define CLO_PAIR_THREADS 512
-#endif
-#ifndef CLO_PAIR_THREADS_8B      // 8-byte elements: threads x elements per thread (8 or 16)
-#define CLO_PAIR_THREADS_8B CLO_PAIR_THREADS
-#endif
-#ifndef CLO_PAIR_ITEMS_8B
-#define CLO_PAIR_ITEMS_8B 8
-#endif
-template <typename E> struct pair_shape {
-	static constexpr int THREADS = sizeof(E) == 8 ? CLO_PAIR_THREADS_8B : (sizeof(E) == 4 ? CLO_PAIR_THREADS : 512);
-	static constexpr int ITEMS = sizeof(E) == 8 ? CLO_PAIR_ITEMS_8B : 16;
+// Shape of a tile of the chain-free pair passes (= the tiles of clo_hip_radixw.hip's
+// histogram). Two shapes, chosen per sort by the array's size (clo_radix_big_tiles):
+// 512 threads x 16 elements (8 for 8-byte elements) with the table of ends next to
+// the 32 KiB stage, 3 work-groups per CU; and, for arrays of 256 MiB and more, BIG:
+// 1024 threads on twice the tile, the table inside the 64 KiB stage (ALIAS), 2
+// work-groups per CU — runs of 256 bytes per digit pair and tile instead of 128 in
+// the scatter, half the counters: pair kernel 0.475 -> 0.443 ms per pass at 2^28
+// uint32, uint64 0.887 -> 0.820.
+template <typename E, bool BIG> struct pair_shape {
+	static constexpr int THREADS = (BIG && sizeof(E) >= 4) ? 1024 : 512;
+	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
+	static constexpr int TILE = THREADS * ITEMS;
+	static constexpr bool ALIAS = BIG && sizeof(E) >= 4;
 };
-#define CLO_PAIR_TILE_ELEMS(elem_size) ((elem_size) == 8 ? (size_t) CLO_PAIR_THREADS_8B * CLO_PAIR_ITEMS_8B \
-	: (size_t) ((elem_size) == 4 ? CLO_PAIR_THREADS : 512) * 16)
+constexpr size_t CLO_BIG_TILE_BYTES = (size_t) 256 << 20;
+__host__ __device__ inline bool clo_radix_big_tiles(size_t n, int elem_size) { return elem_size >= 4 && n * (size_t) elem_size >= CLO_BIG_TILE_BYTES; }
+__host__ __device__ inline size_t clo_pair_tile_elems(int elem_size, bool big) {
+	return (size_t) ((big && elem_size >= 4) ? 1024 : 512) * (elem_size == 8 ? 8 : 16);
+}
 
 }  // namespace
 

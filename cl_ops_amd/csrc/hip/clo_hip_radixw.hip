@@ -19,29 +19,26 @@
 
 namespace {
 
-#ifndef CLO_RW_THREADS
-#define CLO_RW_THREADS 512
-#endif
-constexpr int RW_THREADS = CLO_RW_THREADS;
 constexpr int RW_CHUNK = 128;   // tiles per chunk of the counter scan
 
-// the pair kernel's tile (clo_hip_radix_rank.h), RW_THREADS threads
-template <typename E> struct rw_shape {
-	static constexpr int TILE = (int) CLO_PAIR_TILE_ELEMS(sizeof(E));
-	static constexpr int ITEMS = TILE / RW_THREADS;
-	static_assert(ITEMS * RW_THREADS == TILE, "whole elements per thread");
+// the pair kernel's tile (clo_hip_radix_rank.h), one thread per 16 elements (8 of 8 bytes)
+template <typename E, bool BIG> struct rw_shape {
+	static constexpr int TILE = pair_shape<E, BIG>::TILE;
+	static constexpr int THREADS = pair_shape<E, BIG>::THREADS;
+	static constexpr int ITEMS = TILE / THREADS;
 };
 
 // ---------------------------------------------------------------------------
 // per-tile digit histogram (upstream's satradix_histogram job)
 // ---------------------------------------------------------------------------
-template <typename E, int BITS>
-__global__ __launch_bounds__(RW_THREADS)
+template <typename E, int BITS, bool BIG>
+__global__ __launch_bounds__((rw_shape<E, BIG>::THREADS))
 void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
 	unsigned* __restrict__ thist, int aligned, clo_keyx kx) {
 	constexpr int R = 1 << BITS;
-	constexpr int ITEMS = rw_shape<E>::ITEMS;
-	constexpr int TILE = rw_shape<E>::TILE;
+	constexpr int ITEMS = rw_shape<E, BIG>::ITEMS;
+	constexpr int TILE = rw_shape<E, BIG>::TILE;
+	constexpr int RW_THREADS = rw_shape<E, BIG>::THREADS;
 	constexpr int VB = ITEMS * (int) sizeof(E) >= 16 ? 16 : ITEMS * (int) sizeof(E);   // bytes per vector load
 	constexpr int VECS = ITEMS * (int) sizeof(E) / VB;
 	constexpr int PER = VB / (int) sizeof(E);
@@ -247,14 +244,17 @@ void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned til
 
 // ---- the histogram / counter-scan steps for any digit width 1..8 (used by
 // the digit-pair passes of clo_hip_radix4.hip) ----
-size_t clo_radixw_tile_elems(int elem_size) { return CLO_PAIR_TILE_ELEMS(elem_size); }
 
 template <typename E>
 static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift, unsigned mask, unsigned* thist,
-	unsigned tiles, clo_keyx kx, hipStream_t s) {
+	unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
 	const int aligned = (int) ((uintptr_t) in % 16 == 0);
-	#define CLO_RW_TH(B) case B: hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B>), dim3(tiles), dim3(RW_THREADS), 0, s, \
-		(const E*) in, n, shift, mask, thist, aligned, kx); break
+	#define CLO_RW_TH(B) case B: \
+		if (big && sizeof(E) >= 4) hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B, (sizeof(E) >= 4)>), dim3(tiles), dim3(rw_shape<E, (sizeof(E) >= 4)>::THREADS), 0, s, \
+			(const E*) in, n, shift, mask, thist, aligned, kx); \
+		else hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B, false>), dim3(tiles), dim3(rw_shape<E, false>::THREADS), 0, s, \
+			(const E*) in, n, shift, mask, thist, aligned, kx); \
+		break
 	switch (bits) {
 		CLO_RW_TH(1); CLO_RW_TH(2); CLO_RW_TH(3); CLO_RW_TH(4); CLO_RW_TH(5); CLO_RW_TH(6); CLO_RW_TH(7); CLO_RW_TH(8);
 		default: return CLO_HIP_EUNSUPPORTED;
@@ -263,13 +263,14 @@ static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift
 	return (int) hipGetLastError();
 }
 
+// `big`: the tiles are those of clo_radix_big_tiles(n, elem_size) (clo_hip_radix_rank.h)
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
-	unsigned* thist, unsigned tiles, clo_keyx kx, hipStream_t s) {
+	unsigned* thist, unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
 	switch (elem_size) {
-		case 1: return rw_launch_tilehist<uint8_t>(in, n, bits, shift, mask, thist, tiles, kx, s);
-		case 2: return rw_launch_tilehist<uint16_t>(in, n, bits, shift, mask, thist, tiles, kx, s);
-		case 4: return rw_launch_tilehist<uint32_t>(in, n, bits, shift, mask, thist, tiles, kx, s);
-		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tiles, kx, s);
+		case 1: return rw_launch_tilehist<uint8_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
+		case 2: return rw_launch_tilehist<uint16_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
+		case 4: return rw_launch_tilehist<uint32_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
+		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }

@@ -227,6 +227,36 @@ def test_sweep_passes_on_repeating_keys(gpu, dist):
     sp.close()
 
 
+@pytest.mark.parametrize("case", ["uint radix 16", "uint radix 256", "uint radix 4", "uint radix 64", "ulong radix 16", "pairs radix 16"])
+def test_big_tiles_ragged_sizes(gpu, monkeypatch, case):
+    """Arrays of 256 MiB and more run the chain-free passes on 16 384-element tiles
+    (1024 threads, the table of ends inside the stage): sizes that end inside a tile,
+    every digit-width family, 4- and 8-byte elements, stable pairs."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    monkeypatch.setenv("CLO_RADIX_SWEEP", "0")   # (8-byte elements of 512 MiB+ would take the sweeps)
+    et, _, radix = case.split()
+    rng = np.random.default_rng(len(case))
+    if et == "uint":
+        n = (1 << 26) + 16384 + 4099
+        a = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+        s = clo.Sorter("satradix", ctx, "uint", options="radix=" + radix)
+        exp = np.sort(a)
+    elif et == "ulong":
+        n = (1 << 25) + 8192 + 77
+        a = rng.integers(0, np.iinfo(np.uint64).max, n, dtype=np.uint64, endpoint=True)
+        s = clo.Sorter("satradix", ctx, "ulong", options="radix=" + radix)
+        exp = np.sort(a)
+    else:
+        n = (1 << 25) + 8192 + 77
+        a = (rng.integers(0, 1 << 20, n, dtype=np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)   # ~32 duplicates per key
+        s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)", options="radix=" + radix)
+        exp = O.stable_sort(a, key_size=4, key_shift=32)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, exp)
+
+
 def test_sorter_and_scanner_move_between_queues(gpu):
     """The cached buffers of a sorter / scanner follow the queue of the call: two
     live queues alternating (the later call waits for the earlier one's work, no
