@@ -158,14 +158,16 @@ def min_moved_bytes(label, n, es, radix):
     (element streams + its counters), from the kernels' definitions."""
     bits = int(np.log2(radix))
     pass_bits = 2 * bits if bits <= 4 else bits
-    tile = 512 * (8 if es == 8 else 16)
+    big = es >= 4 and n * es >= (256 << 20)                  # clo_radix_big_tiles (clo_hip_radix_rank.h)
+    tile = (1024 if big else 512) * (8 if es == 8 else 16)
     counters = -(-n // tile) * (1 << pass_bits) * 4          # one row of counters per tile
+    sweep_counters = -(-n // (512 * (8 if es == 8 else 16))) * (1 << pass_bits) * 4   # (the sweeps keep 512-thread tiles)
     return {
         "radix_hist": n * es + counters,                      # read every element, write the tile histograms
         "radix_offsets": 2 * counters,                        # histograms in, offsets out (chunk sums are noise)
         "radix_pass": 2 * n * es + 2 * counters,              # read + write every element, read both counter rows
         "radix_ghist": n * es,                                # one read of the source
-        "radix_sweep": 2 * n * es + 2 * counters,             # read + write every element; publish + look back
+        "radix_sweep": 2 * n * es + 2 * sweep_counters,       # read + write every element; publish + look back
         "radix_small": 2 * n * es,
         "scan": 2 * n * es,                                   # (uint32 -> uint32 workload)
         "bitonic_presort": 2 * n * es, "bitonic_tile": 2 * n * es, "bitonic_strided": 2 * n * es,

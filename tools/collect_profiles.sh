@@ -13,11 +13,11 @@ for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic sbitonic; do
 	python3 "$ROOT/bench.py" --workload $w --steps 30 --warmup 3 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
 	echo "bench $w done"
 done
-# the other path at each size: single-sweep passes forced on for the headline (the library's choice there:
-# chain-free pair passes), pair passes forced for 8-byte elements (the library's choice: sweeps)
-CLO_RADIX_SWEEP=1 python3 "$ROOT/bench.py" --workload satradix_u32 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_satradix_u32_sweep.json" 2> "$OUT/bench_satradix_u32_sweep.err" || exit 1
-CLO_RADIX_SWEEP=0 python3 "$ROOT/bench.py" --workload satradix_u64 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_satradix_u64_pair.json" 2> "$OUT/bench_satradix_u64_pair.err" || exit 1
-CLO_RADIX_SWEEP=0 python3 "$ROOT/bench.py" --workload satradix_pairs --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_satradix_pairs_pair.json" 2> "$OUT/bench_satradix_pairs_pair.err" || exit 1
+# the other path at the headline sizes (the library's choice there: chain-free pair passes): single-sweep passes forced on
+for w in satradix_u32 satradix_u64 satradix_pairs; do
+	CLO_RADIX_SWEEP=1 python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${w}_sweep.json" 2> "$OUT/bench_${w}_sweep.err" || exit 1
+done
+[ "$2" = "benchonly" ] && { echo "bench lines done"; exit 0; }
 echo "bench sweep done"
 export CLO_RADIX_SWEEP=1
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_satradix_u32_sweep" --output-format csv -- \
