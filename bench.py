@@ -153,19 +153,27 @@ FAMILIES = {
 }
 
 
-def min_moved_bytes(label, n, es, radix):
+def min_moved_bytes(label, n, es, radix, key_bits=None):
     """What one launch of the family must move through HBM at the very least
-    (element streams + its counters), from the kernels' definitions."""
+    (element streams + its counters), averaged over the launches of a sort, from the
+    kernels' definitions."""
     bits = int(np.log2(radix))
     pass_bits = 2 * bits if bits <= 4 else bits
+    key_bits = key_bits or 8 * es
+    passes = -(-key_bits // pass_bits)
     big = es >= 4 and n * es >= (256 << 20)                  # clo_radix_big_tiles (clo_hip_radix_rank.h)
     tile = (1024 if big else 512) * (8 if es == 8 else 16)
     counters = -(-n // tile) * (1 << pass_bits) * 4          # one row of counters per tile
     sweep_counters = -(-n // (512 * (8 if es == 8 else 16))) * (1 << pass_bits) * 4   # (the sweeps keep 512-thread tiles)
+    # big tiles: every pass but the last also writes one digit byte per element, and
+    # every histogram but the first reads those bytes instead of the elements
+    dig = big and passes > 1
+    hist_in = (n * es + (passes - 1) * n) / passes if dig else n * es
+    pass_extra = (passes - 1) * n / passes if dig else 0
     return {
-        "radix_hist": n * es + counters,                      # read every element, write the tile histograms
+        "radix_hist": hist_in + counters,                     # read every element (or its digit byte), write the tile histograms
         "radix_offsets": 2 * counters,                        # histograms in, offsets out (chunk sums are noise)
-        "radix_pass": 2 * n * es + 2 * counters,              # read + write every element, read both counter rows
+        "radix_pass": 2 * n * es + 2 * counters + pass_extra,  # read + write every element, read both counter rows
         "radix_ghist": n * es,                                # one read of the source
         "radix_sweep": 2 * n * es + 2 * sweep_counters,       # read + write every element; publish + look back
         "radix_small": 2 * n * es,
@@ -508,7 +516,7 @@ def main_single(args):
         if not cnt:
             continue
         avg_ms = tot_ms / cnt
-        floor_b = min_moved_bytes(label, n, es, args.radix)
+        floor_b = min_moved_bytes(label, n, es, args.radix, 32 if workload == "satradix_pairs" else None)
         pmc_b = (traffic.get(label) or {}).get("hbm_bytes_per_launch")
         moved = max(floor_b, pmc_b or 0)
         kernels.append({"name": label, "launches_per_step": round(cnt / args.steps, 3), "avg_launch_ms": round(avg_ms, 5),

@@ -619,19 +619,14 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
 	// The library's choice (measured; profiles/r02_sweep_sizes_big.txt):
-	// * 4 .. 1024 tiles (2^15 .. 2^23 4-byte elements): the sort is launch-bound and the
-	//   sweeps need 6 launches instead of 12: the same time up to 2^18, 5-40 % less from
-	//   2^19 on (and half the events on a profiling queue);
-	// * 64 .. 256 MiB: the chain-free passes, 1-13 % faster — the array sits in the
-	//   256 MiB last-level cache, where their second read of every element is cheap;
-	// * 512 MiB up to 2^28 elements: the sweeps again, 2-7 % faster (half the reads now
-	//   come from HBM);
-	// * 2^28 elements and more (the headline sizes: uint32, pairs, config 5's uint64
-	//   shard): the chain-free passes on their 16 384-element tiles, 1-5 % faster than
-	//   the sweeps, and no work-group ever waits for another.
-	if (tiles >= 4 && tiles <= 1024) return 1;
-	const size_t bytes = n * (size_t) elem_size;
-	return bytes >= ((size_t) 512 << 20) && n < ((size_t) 1 << 28);
+	// 4 .. 1024 tiles (2^15 .. 2^23 4-byte elements): the sort is launch-bound and the
+	// sweeps need 6 launches instead of 12: the same time up to 2^18, 5-40 % less from
+	// 2^19 on (and half the events on a profiling queue). Above that the chain-free
+	// passes are ahead: by 5-15 % at 64 .. 128 MiB (the array sits in the 256 MiB
+	// last-level cache, where their second read of every element is cheap), by 4-24 %
+	// from 256 MiB (16 384-element tiles, and a histogram that reads one byte per
+	// element) — and no work-group ever waits for another there.
+	return tiles >= 4 && tiles <= 1024;
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

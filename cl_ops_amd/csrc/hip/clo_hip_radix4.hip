@@ -48,12 +48,15 @@ namespace {
 // lines in the output, behind the same L2, where the two partial writes merge:
 // 2^28 8-byte elements 1.84 -> 0.86 ms per pass, 4-byte 0.79 -> 0.69 ms.
 // ---------------------------------------------------------------------------
-template <typename E, int LB, int HB, bool BIG>
+// DIG: every element's NEXT combined digit (8 bits at next_shift) also goes out, one
+// byte per element in output order: the next pass's histogram then reads n bytes
+// instead of n elements (clo_radixw_launch_tilehist_bytes).
+template <typename E, int LB, int HB, bool BIG, bool DIG = false>
 __global__ __launch_bounds__((pair_shape<E, BIG>::THREADS), (pair_shape<E, BIG>::THREADS >= 1024 ? 8 : 6))   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (59 used); BIG: 2 x 16 waves, <= 64
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
-	clo_keyx kx_in, clo_keyx kx_out) {
+	clo_keyx kx_in, clo_keyx kx_out, unsigned char* __restrict__ dig_out = nullptr, unsigned next_shift = 0) {
 
 	constexpr int THREADS = pair_shape<E, BIG>::THREADS;
 	constexpr int ITEMS = pair_shape<E, BIG>::ITEMS;
@@ -154,11 +157,23 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 					for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(v[k], kx_out);
 				}
 				*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
+				if constexpr (DIG) {
+					if constexpr (VEC == 4) {
+						typedef unsigned u32_u __attribute__((aligned(1)));
+						*reinterpret_cast<u32_u*>(dig_out + gi0) = ((unsigned) (v[0] >> next_shift) & 255u) | (((unsigned) (v[1] >> next_shift) & 255u) << 8)
+							| (((unsigned) (v[2] >> next_shift) & 255u) << 16) | ((unsigned) (v[3] >> next_shift) << 24);
+					} else {
+						dig_out[gi0] = (unsigned char) (v[0] >> next_shift);
+					}
+				}
 			} else {
 				#pragma unroll
 				for (int k = 0; k < VEC; ++k) {
 					const unsigned gi = p + k + s_delta[(unsigned) (v[k] >> shift) & mask2];
-					if (gi < n32) out[gi] = clo_keyx_inv<E>(v[k], kx_out);
+					if (gi < n32) {
+						out[gi] = clo_keyx_inv<E>(v[k], kx_out);
+						if constexpr (DIG) dig_out[gi] = (unsigned char) (v[k] >> next_shift);
+					}
 				}
 			}
 		} else {
@@ -167,7 +182,10 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 				if (p + k < count) {
 					const E e = s_stage[p + k];
 					const unsigned gi = p + k + s_delta[(unsigned) (e >> shift) & mask2];
-					if (gi < n32) out[gi] = clo_keyx_inv<E>(e, kx_out);
+					if (gi < n32) {
+						out[gi] = clo_keyx_inv<E>(e, kx_out);
+						if constexpr (DIG) dig_out[gi] = (unsigned char) (e >> next_shift);
+					}
 				}
 			}
 		}
@@ -231,9 +249,11 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 // Per pass: histogram of the combined digit -> counter scan -> pass kernel.
 // A requested digit width b <= 4 pairs two digits (LB = HB = b); a wider digit
 // is one pass, split in two halves.
-struct rp_layout { size_t thist, toff, partial, total, tiles; };
+struct rp_layout { size_t thist, toff, partial, dig, total, tiles; };   // dig: 0 = no digit stream
 
-rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {   // (tiles of the shape clo_radix_big_tiles picks for n)
+// (tiles of the shape clo_radix_big_tiles picks for n; `digits`: room for the digit stream
+// of a multi-pass sort on big tiles: n bytes)
+rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits, bool digits = true) {
 	rp_layout L;
 	const size_t R2 = (size_t) 1 << pass_bits;
 	const size_t tile = clo_pair_tile_elems(elem_size, clo_radix_big_tiles(n, elem_size));
@@ -244,6 +264,11 @@ rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits) {   // (tiles o
 	L.toff = L.thist + per;
 	L.partial = L.toff + per;
 	L.total = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
+	L.dig = 0;
+	if (digits && clo_radix_big_tiles(n, elem_size)) {
+		L.dig = L.total;
+		L.total += (n + 255) & ~(size_t) 255;
+	}
 	return L;
 }
 
@@ -257,6 +282,8 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles;
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
+	static const bool no_dig = getenv("CLO_RADIX_NO_DIGITS") != nullptr;   // (A/B runs)
+	unsigned char* dig = (L.dig != 0 && passes > 1 && !no_dig) ? (unsigned char*) ws + L.dig : nullptr;
 	const clo_keyx kx_none = { 0, 0, 0 };
 
 	hipError_t e;   // (no kernel of the sort polls another work-group: the header's status word stays unused)
@@ -274,8 +301,11 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		const unsigned mask_lo = (1u << lo_bits) - 1u, mask_hi = (1u << hi_bits) - 1u;
 		{
 			clo_timing_scope timing("radix_hist", s);
-			const int st = clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
-				thist, tiles, big, p == 0 ? kx : kx_none, s);
+			// (from the second pass on: out of the digit bytes the pass before left behind)
+			const int st = (dig && p > 0)
+				? clo_radixw_launch_tilehist_bytes(dig, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tiles, s)
+				: clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
+					thist, tiles, big, p == 0 ? kx : kx_none, s);
 			if (st != 0) return st;
 		}
 		{
@@ -289,14 +319,19 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			const clo_keyx kin = p == 0 ? kx : kx_none, kout = p + 1 == passes ? kx : kx_none;
 			if constexpr (sizeof(E) >= 4) {
 				if (big) {
-					hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-						cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout);
+					if (dig && p + 1 < passes)
+						hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout,
+							dig, (unsigned) (key_shift + (p + 1) * PB));
+					else
+						hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout, nullptr, 0u);
 					cur_in = cur_out;
 					continue;
 				}
 			}
-			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
-				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout);
+			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
+				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout, nullptr, 0u);
 		}
 		cur_in = cur_out;
 	}
@@ -354,7 +389,7 @@ template <typename E, int BITS>
 int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned long long* counts, void* ws, hipStream_t s) {
 	constexpr unsigned R = 1u << BITS;
 	constexpr int PB = 2 * BITS;
-	const rp_layout L = rp_make_layout(n, (int) sizeof(E), PB);
+	const rp_layout L = rp_make_layout(n, (int) sizeof(E), PB, false);
 	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
 	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
@@ -371,13 +406,13 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, s);
 	if (st != 0) return st;
 	if (big)
-		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
 			src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
-			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none);
+			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	else
-		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
+		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
 			src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
-			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none);
+			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	return (int) hipGetLastError();
 }
 
@@ -417,7 +452,7 @@ size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int digit_bits, int k
 }
 
 size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits) {
-	return rp_make_layout(n, elem_size, 2 * bits).total;
+	return rp_make_layout(n, elem_size, 2 * bits, false).total;
 }
 
 int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,

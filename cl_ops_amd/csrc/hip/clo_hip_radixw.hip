@@ -91,6 +91,56 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	}
 }
 
+// The same histogram out of the digit bytes the pass before wrote (one byte per
+// element, in the order of the elements; clo_radix4_pair_kernel<..., DIG>): a quarter
+// (uint32) or an eighth (8-byte elements) of the bytes to read. BIG tiles only.
+template <int BITS, int ITEMS>   // ITEMS bytes per thread: 16 (4-byte elements) or 8
+__global__ __launch_bounds__(1024)
+void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist) {
+	constexpr int R = 1 << BITS;
+	constexpr int THREADS = 1024;
+	constexpr int TILE = THREADS * ITEMS;
+	constexpr int COPIES = 32;
+	__shared__ __attribute__((aligned(16))) unsigned s_cnt[R * COPIES];
+	const unsigned tid = threadIdx.x, lane = tid & 63u;
+	const size_t base = (size_t) blockIdx.x * TILE;
+	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	{
+		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+		const vec4u z = { 0u, 0u, 0u, 0u };
+		for (unsigned i = tid; i < (unsigned) (R * COPIES / 4); i += THREADS) reinterpret_cast<vec4u*>(s_cnt)[i] = z;
+	}
+	__syncthreads();
+	const unsigned tbase = tid * ITEMS;
+	const unsigned cp = lane & (COPIES - 1);
+	if (count == (unsigned) TILE) {
+		typedef unsigned vecw __attribute__((ext_vector_type(ITEMS / 4)));   // (the stream starts 256-byte aligned, a tile is a multiple of 16 bytes)
+		const vecw v = *reinterpret_cast<const vecw*>(dig + base + tbase);
+		#pragma unroll
+		for (int k = 0; k < ITEMS / 4; ++k) {
+			#pragma unroll
+			for (int b = 0; b < 4; ++b)
+				atomicAdd(&s_cnt[((((unsigned) v[k] >> (8 * b)) & mask) << 5) + cp], 1u);
+		}
+	} else {
+		#pragma unroll
+		for (int i = 0; i < ITEMS; ++i)
+			if (tbase + i < count) atomicAdd(&s_cnt[(((unsigned) dig[base + tbase + i] & mask) << 5) + cp], 1u);
+	}
+	__syncthreads();
+	for (unsigned d = tid; d < (unsigned) R; d += THREADS) {
+		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+		const vec4u* row = reinterpret_cast<const vec4u*>(&s_cnt[d * COPIES]);
+		unsigned h = 0;
+		#pragma unroll
+		for (int k = 0; k < COPIES / 4; ++k) {
+			const vec4u x = row[(k + d) & (COPIES / 4 - 1)];
+			h += x[0] + x[1] + x[2] + x[3];
+		}
+		thist[(size_t) blockIdx.x * R + d] = h;
+	}
+}
+
 // ---------------------------------------------------------------------------
 // counts[tile][digit] -> offsets[tile][digit] in digit-major order:
 //   off[t][d] = sum_{d'<d} total[d'] + sum_{t'<t} cnt[t'][d]
@@ -273,6 +323,22 @@ int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits
 		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
+}
+
+// Histograms of big tiles (clo_radix_big_tiles) out of the digit stream.
+int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
+	unsigned* thist, unsigned tiles, hipStream_t s) {
+	#define CLO_RW_THB(B) case B: \
+		if (elem_size == 8) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, 8>), dim3(tiles), dim3(1024), 0, s, dig, n, mask, thist); \
+		else hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, 16>), dim3(tiles), dim3(1024), 0, s, dig, n, mask, thist); \
+		break
+	if (elem_size != 4 && elem_size != 8) return CLO_HIP_EUNSUPPORTED;
+	switch (bits) {
+		CLO_RW_THB(1); CLO_RW_THB(2); CLO_RW_THB(3); CLO_RW_THB(4); CLO_RW_THB(5); CLO_RW_THB(6); CLO_RW_THB(7); CLO_RW_THB(8);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+	#undef CLO_RW_THB
+	return (int) hipGetLastError();
 }
 
 int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff, hipStream_t s) {
