@@ -257,6 +257,23 @@ def test_big_tiles_ragged_sizes(gpu, monkeypatch, case):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("case", [("uint", "uint", "(x) * 2654435761u", lambda a: a * np.uint32(2654435761)),
+                                  ("ulong", "ulong", "(x) * 0x9E3779B97F4A7C15ul", lambda a: a * np.uint64(0x9E3779B97F4A7C15))])
+def test_jit_get_key_on_big_tiles(gpu, case):
+    """A run-time compiled get_key at a size where the (key, index) pairs it sorts fill 256
+    MiB and more: 16 384-element tiles, digit stream; 8-byte keys take two rounds."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, kt, expr, fn = case
+    dt = clo.api.CLO_TYPE_NP[et]
+    n = (1 << 25) + 12345
+    a = np.random.default_rng(25).integers(0, np.iinfo(dt).max, n, dtype=np.uint64).astype(dt)
+    s = clo.Sorter("satradix", ctx, et, key_type=kt, get_key=expr)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, a[np.argsort(fn(a), kind="stable")])
+
+
 def test_sorter_and_scanner_move_between_queues(gpu):
     """The cached buffers of a sorter / scanner follow the queue of the call: two
     live queues alternating (the later call waits for the earlier one's work, no
