@@ -161,7 +161,7 @@ def min_moved_bytes(label, n, es, radix, key_bits=None):
     pass_bits = 2 * bits if bits <= 4 else bits
     key_bits = key_bits or 8 * es
     passes = -(-key_bits // pass_bits)
-    big = es >= 4 and n * es >= (256 << 20)                  # clo_radix_big_tiles (clo_hip_radix_rank.h)
+    big = es >= 4 and n * es >= ((64 if es == 8 else 256) << 20)   # clo_radix_big_tiles (clo_hip_radix_rank.h)
     tile = (1024 if big else 512) * (8 if es == 8 else 16)
     counters = -(-n // tile) * (1 << pass_bits) * 4          # one row of counters per tile
     sweep_counters = -(-n // (512 * (8 if es == 8 else 16))) * (1 << pass_bits) * 4   # (the sweeps keep 512-thread tiles)
