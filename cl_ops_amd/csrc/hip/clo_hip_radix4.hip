@@ -282,7 +282,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
 	const unsigned tiles = (unsigned) L.tiles;
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
-	static const bool no_dig = getenv("CLO_RADIX_NO_DIGITS") != nullptr;   // (A/B runs)
+	const bool no_dig = getenv("CLO_RADIX_NO_DIGITS") != nullptr;   // (A/B runs and tests: read at every call)
 	unsigned char* dig = (L.dig != 0 && passes > 1 && !no_dig) ? (unsigned char*) ws + L.dig : nullptr;
 	const clo_keyx kx_none = { 0, 0, 0 };
 

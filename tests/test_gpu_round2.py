@@ -227,14 +227,19 @@ def test_sweep_passes_on_repeating_keys(gpu, dist):
     sp.close()
 
 
-@pytest.mark.parametrize("case", ["uint radix 16", "uint radix 256", "uint radix 4", "uint radix 64", "ulong radix 16", "pairs radix 16"])
+@pytest.mark.parametrize("case", ["uint radix 16", "uint radix 256", "uint radix 4", "uint radix 64", "ulong radix 16", "pairs radix 16",
+                                  "uint radix 16 no-digit-stream", "ulong radix 16 no-digit-stream"])
 def test_big_tiles_ragged_sizes(gpu, monkeypatch, case):
-    """Arrays of 256 MiB and more run the chain-free passes on 16 384-element tiles
-    (1024 threads, the table of ends inside the stage): sizes that end inside a tile,
-    every digit-width family, 4- and 8-byte elements, stable pairs."""
+    """Arrays of 256 MiB and more (64 MiB of 8-byte elements) run the chain-free passes
+    on 16 384-element tiles (1024 threads, the table of ends inside the stage), every
+    pass but the last also writing the digit stream the next histogram reads: sizes
+    that end inside a tile, every digit-width family, 4- and 8-byte elements, stable
+    pairs."""
     import cl_ops_amd as clo
     ctx, q = gpu
-    monkeypatch.setenv("CLO_RADIX_SWEEP", "0")   # (8-byte elements of 512 MiB+ would take the sweeps)
+    if case.endswith("no-digit-stream"):          # histograms over the elements in every pass
+        monkeypatch.setenv("CLO_RADIX_NO_DIGITS", "1")
+        case = case.rsplit(" ", 1)[0]
     et, _, radix = case.split()
     rng = np.random.default_rng(len(case))
     if et == "uint":
