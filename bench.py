@@ -167,7 +167,7 @@ def min_moved_bytes(label, n, es, radix, key_bits=None):
     sweep_counters = -(-n // (512 * (8 if es == 8 else 16))) * (1 << pass_bits) * 4   # (the sweeps keep 512-thread tiles)
     # big tiles: every pass but the last also writes one digit byte per element, and
     # every histogram but the first reads those bytes instead of the elements
-    dig = big and passes > 1
+    dig = big and passes > 1 and bits in (4, 8)               # clo_radix_digit_stream; radix 16 / 256 only
     hist_in = (n * es + (passes - 1) * n) / passes if dig else n * es
     pass_extra = (passes - 1) * n / passes if dig else 0
     return {

@@ -85,7 +85,7 @@ size_t clo_radixw_lds_bytes(int digit_bits);
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
 	unsigned* thist, unsigned tiles, bool big, clo_keyx kx, hipStream_t s);
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
-	unsigned* thist, unsigned tiles, hipStream_t s);
+	unsigned* thist, unsigned tiles, bool big, hipStream_t s);
 int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff, hipStream_t s);
 
 typedef unsigned long long clo_u64;

@@ -252,7 +252,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 struct rp_layout { size_t thist, toff, partial, dig, total, tiles; };   // dig: 0 = no digit stream
 
 // (tiles of the shape clo_radix_big_tiles picks for n; `digits`: room for the digit stream
-// of a multi-pass sort on big tiles: n bytes)
+// of a multi-pass sort, n bytes, where clo_radix_digit_stream says so)
 rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits, bool digits = true) {
 	rp_layout L;
 	const size_t R2 = (size_t) 1 << pass_bits;
@@ -265,7 +265,7 @@ rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits, bool digits = t
 	L.partial = L.toff + per;
 	L.total = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
 	L.dig = 0;
-	if (digits && clo_radix_big_tiles(n, elem_size)) {
+	if (digits && clo_radix_digit_stream(n, elem_size)) {
 		L.dig = L.total;
 		L.total += (n + 255) & ~(size_t) 255;
 	}
@@ -283,7 +283,10 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const unsigned tiles = (unsigned) L.tiles;
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
 	const bool no_dig = getenv("CLO_RADIX_NO_DIGITS") != nullptr;   // (A/B runs and tests: read at every call)
-	unsigned char* dig = (L.dig != 0 && passes > 1 && !no_dig) ? (unsigned char*) ws + L.dig : nullptr;
+	// (the stream exists for the schedules of radix 16 and 256 only, LB = HB = 4: every other digit width
+	// would be another set of kernels to compile for sorts nobody times)
+	constexpr bool DIG_OK = LB == 4 && HB == 4 && sizeof(E) >= 4;
+	unsigned char* dig = (DIG_OK && L.dig != 0 && passes > 1 && !no_dig) ? (unsigned char*) ws + L.dig : nullptr;
 	const clo_keyx kx_none = { 0, 0, 0 };
 
 	hipError_t e;   // (no kernel of the sort polls another work-group: the header's status word stays unused)
@@ -303,7 +306,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			clo_timing_scope timing("radix_hist", s);
 			// (from the second pass on: out of the digit bytes the pass before left behind)
 			const int st = (dig && p > 0)
-				? clo_radixw_launch_tilehist_bytes(dig, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tiles, s)
+				? clo_radixw_launch_tilehist_bytes(dig, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tiles, big, s)
 				: clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
 					thist, tiles, big, p == 0 ? kx : kx_none, s);
 			if (st != 0) return st;
@@ -319,11 +322,16 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			const clo_keyx kin = p == 0 ? kx : kx_none, kout = p + 1 == passes ? kx : kx_none;
 			if constexpr (sizeof(E) >= 4) {
 				if (big) {
-					if (dig && p + 1 < passes)
-						hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout,
-							dig, (unsigned) (key_shift + (p + 1) * PB));
-					else
+					bool done = false;
+					if constexpr (DIG_OK) {
+						if (dig && p + 1 < passes) {
+							hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+								cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout,
+								dig, (unsigned) (key_shift + (p + 1) * PB));
+							done = true;
+						}
+					}
+					if (!done)
 						hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
 							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout, nullptr, 0u);
 					cur_in = cur_out;

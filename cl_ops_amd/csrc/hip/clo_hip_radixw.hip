@@ -93,12 +93,11 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 
 // The same histogram out of the digit bytes the pass before wrote (one byte per
 // element, in the order of the elements; clo_radix4_pair_kernel<..., DIG>): a quarter
-// (uint32) or an eighth (8-byte elements) of the bytes to read. BIG tiles only.
-template <int BITS, int ITEMS>   // ITEMS bytes per thread: 16 (4-byte elements) or 8
-__global__ __launch_bounds__(1024)
+// (uint32) or an eighth (8-byte elements) of the bytes to read.
+template <int BITS, int ITEMS, int THREADS>   // ITEMS bytes per thread: 16 (4-byte elements) or 8; THREADS of the tile's shape
+__global__ __launch_bounds__(THREADS)
 void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist) {
 	constexpr int R = 1 << BITS;
-	constexpr int THREADS = 1024;
 	constexpr int TILE = THREADS * ITEMS;
 	constexpr int COPIES = 32;
 	__shared__ __attribute__((aligned(16))) unsigned s_cnt[R * COPIES];
@@ -325,12 +324,13 @@ int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits
 	}
 }
 
-// Histograms of big tiles (clo_radix_big_tiles) out of the digit stream.
+// Histograms out of the digit stream (tiles of the shape `big` names).
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
-	unsigned* thist, unsigned tiles, hipStream_t s) {
+	unsigned* thist, unsigned tiles, bool big, hipStream_t s) {
+	#define CLO_RW_THB1(B, I, T) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T>), dim3(tiles), dim3(T), 0, s, dig, n, mask, thist)
 	#define CLO_RW_THB(B) case B: \
-		if (elem_size == 8) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, 8>), dim3(tiles), dim3(1024), 0, s, dig, n, mask, thist); \
-		else hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, 16>), dim3(tiles), dim3(1024), 0, s, dig, n, mask, thist); \
+		if (!big) return CLO_HIP_EUNSUPPORTED;   /* (the stream goes with the big tiles) */ \
+		if (elem_size == 8) CLO_RW_THB1(B, 8, 1024); else CLO_RW_THB1(B, 16, 1024); \
 		break
 	if (elem_size != 4 && elem_size != 8) return CLO_HIP_EUNSUPPORTED;
 	switch (bits) {
@@ -338,6 +338,7 @@ int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int ele
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 	#undef CLO_RW_THB
+	#undef CLO_RW_THB1
 	return (int) hipGetLastError();
 }
 
