@@ -8,8 +8,8 @@ not been built — there is no CPU or PyTorch fallback path.
 """
 from . import _hip  # noqa: F401  (raises ImportError if the .so is missing)
 from .api import (CloError, Context, Queue, Buffer, Sorter, Scanner, Profiler, HipEventTimer,  # noqa: F401
-                  ShardTransport, ShardSort, CLO_TYPES, clo_type)
+                  ShardTransport, ShardSort, CLO_TYPES, clo_type, wait_for_events)
 
 __all__ = ["CloError", "Context", "Queue", "Buffer", "Sorter", "Scanner", "Profiler", "HipEventTimer",
            "ShardTransport", "ShardSort",
-           "CLO_TYPES", "clo_type"]
+           "CLO_TYPES", "clo_type", "wait_for_events"]

@@ -64,6 +64,7 @@ _sig("clo_hip_stream_wait_event", ci, vp, vp)
 _sig("clo_hip_error_string", C.c_char_p, ci)
 _sig("clo_hip_scan_workspace_bytes", sz, sz, ci, ci)
 _sig("clo_hip_scan_workspace_init", ci, vp, sz, vp)
+_sig("clo_hip_scan_workspace_forget", ci, vp)
 _sig("clo_hip_scan_workspace_set_epoch", ci, vp, C.c_uint, vp)
 _sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_scan_exclusive_carry", ci, vp, vp, sz, ci, ci, ci, vp, vp, vp, sz, vp)
@@ -96,6 +97,9 @@ _sig("clo_hip_radix_jit_sort", ci, vp, vp, vp, vp, vp, sz, ci, vp, sz, vp)
 _sig("clo_hip_timing_enable", ci, ci)
 _sig("clo_hip_timing_reset", ci)
 _sig("clo_hip_timing_read", ci, C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float))
+
+
+CLO_HIP_EARGS, CLO_HIP_EUNSUPPORTED, CLO_HIP_EWORKSPACE, CLO_HIP_ETIMEOUT = -1, -2, -3, -4   # include/clo_hip.h
 
 
 class HipError(RuntimeError):

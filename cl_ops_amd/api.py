@@ -83,6 +83,9 @@ _sig("ccl_buffer_enqueue_write", vp, vp, vp, _u32, sz, sz, vp, vp, _E)
 _sig("ccl_buffer_enqueue_read", vp, vp, vp, _u32, sz, sz, vp, vp, _E)
 _sig("ccl_buffer_enqueue_copy", vp, vp, vp, vp, sz, sz, sz, vp, _E)
 _sig("ccl_event_get_name", C.c_char_p, vp)
+_sig("ccl_event_wait", _u32, C.POINTER(vp), _E)
+_sig("ccl_event_wait_list_clear", None, C.POINTER(vp))
+lib.ccl_event_wait_list_add.restype = None      # variadic: (CCLEventWaitList*, CCLEvent*, ..., NULL)
 _sig("ccl_prof_new", vp)
 _sig("ccl_prof_destroy", None, vp)
 _sig("ccl_prof_add_queue", None, vp, C.c_char_p, vp)
@@ -224,6 +227,30 @@ class Context:
             self.h = None
 
 
+def _make_ewl(events):
+    """A CCLEventWaitList (an opaque pointer, NULL when empty) holding `events`."""
+    ewl = vp(None)
+    if events is None:
+        return ewl
+    if not isinstance(events, (list, tuple)):
+        events = [events]
+    for e in events:
+        if e:
+            lib.ccl_event_wait_list_add(C.byref(ewl), vp(e), vp(None))
+    return ewl
+
+
+def wait_for_events(events):
+    """ccl_event_wait: host-side wait for every event of the list; raises CloError if a command
+    behind one of them failed (a look-back give-up is reported here too)."""
+    ewl = _make_ewl(events)
+    if not ewl:
+        return
+    err = _Err()
+    lib.ccl_event_wait(C.byref(ewl), err.ref)
+    err.raise_if_set()
+
+
 class Queue:
     """CCLQueue = one HIP stream (own, or adopted from e.g. torch)."""
 
@@ -278,10 +305,15 @@ class Buffer:
         lib.ccl_buffer_enqueue_write(self.h, queue.h, 1, offset, a.nbytes, a.ctypes.data_as(vp), None, err.ref)
         err.raise_if_set()
 
-    def read(self, queue, dtype, count, offset=0):
+    def read(self, queue, dtype, count, offset=0, wait_for=None):
+        """Blocking read; `wait_for`: an event (or a list of events) of any queue the copy has to come after."""
         out = np.empty(count, dtype=dtype)
         err = _Err()
-        lib.ccl_buffer_enqueue_read(self.h, queue.h, 1, offset, out.nbytes, out.ctypes.data_as(vp), None, err.ref)
+        ewl = _make_ewl(wait_for)
+        lib.ccl_buffer_enqueue_read(self.h, queue.h, 1, offset, out.nbytes, out.ctypes.data_as(vp),
+                                    C.byref(ewl) if ewl else None, err.ref)
+        if ewl:
+            lib.ccl_event_wait_list_clear(C.byref(ewl))
         err.raise_if_set()
         return out
 

@@ -47,8 +47,13 @@ struct clo_status_cell {
 };
 
 #define CCL_QUEUE_MAX_CELLS 8
-/* Events a queue WITHOUT profiling keeps alive (the most recent ones; a queue
- * with profiling keeps all of them until ccl_prof_calc / ccl_queue_gc). */
+/* Events a queue WITHOUT profiling keeps distinct (the most recent ones; a queue
+ * with profiling keeps all of them until ccl_prof_calc / ccl_queue_gc). Older
+ * ones are RETIRED, not freed: the struct and its hip event go to a spare list
+ * and serve a later command of the same queue. A CCLEvent* the caller still
+ * holds therefore stays valid memory until ccl_queue_gc / ccl_queue_destroy, as
+ * in cf4ocl2; waiting on such a stale handle waits for a LATER command of the
+ * same in-order queue, which implies the one it was handed out for. */
 #define CCL_QUEUE_KEEP_EVENTS 64
 
 struct ccl_queue {
@@ -58,8 +63,10 @@ struct ccl_queue {
 	int profiling;
 	struct ccl_event* events;  /* most recent first */
 	struct ccl_event* first;   /* oldest since last gc */
+	struct ccl_event* spare;   /* retired events of a queue without profiling, reused by later commands */
 	size_t nevents;
 	struct clo_status_cell* cells[CCL_QUEUE_MAX_CELLS];
+	unsigned char armed[CCL_QUEUE_MAX_CELLS];   /* a command that may raise the word has been enqueued (or waited for) since the last check */
 	int ncells;
 	int refs;     /* the caller's + one per sorter / scanner whose last call ran here (clo_queue_hold) */
 	int closed;   /* ccl_queue_destroy has run: synchronised, stream gone; only the struct is still held */
@@ -216,6 +223,13 @@ void ccl_queue_gc(CCLQueue* cq) {
 		free(e);
 		e = next;
 	}
+	for (e = cq->spare; e; ) {
+		struct ccl_event* next = e->next;
+		clo_hip_event_destroy(e->end);
+		free(e);
+		e = next;
+	}
+	cq->spare = NULL;
 	cq->events = NULL;
 	cq->first = NULL;
 	cq->nevents = 0;
@@ -236,25 +250,50 @@ void clo_status_cell_unref(clo_status_cell* c) {
 	if (c && --c->refs == 0) free(c);
 }
 
+static void queue_drop_cell(CCLQueue* cq, int i) {
+	clo_status_cell_unref(cq->cells[i]);
+	memmove(&cq->cells[i], &cq->cells[i + 1], (size_t) (cq->ncells - 1 - i) * sizeof(cq->cells[0]));
+	memmove(&cq->armed[i], &cq->armed[i + 1], (size_t) (cq->ncells - 1 - i) * sizeof(cq->armed[0]));
+	--cq->ncells;
+}
+
+/* Called by a sorter / scanner for every command that polls other work-groups:
+ * the queue checks the word at its next synchronisation point (and only then:
+ * the check is a small blocking read, so a queue whose watched commands have all
+ * been checked pays nothing more). */
 void ccl_queue_watch_status(CCLQueue* cq, clo_status_cell* cell) {
 	if (!cq || !cell) return;
-	for (int i = 0; i < cq->ncells; ++i) if (cq->cells[i] == cell) return;
-	if (cq->ncells == CCL_QUEUE_MAX_CELLS) {   /* drop the oldest watch */
-		clo_status_cell_unref(cq->cells[0]);
-		memmove(&cq->cells[0], &cq->cells[1], (CCL_QUEUE_MAX_CELLS - 1) * sizeof(cq->cells[0]));
-		--cq->ncells;
-	}
+	for (int i = 0; i < cq->ncells; ++i) if (cq->cells[i] == cell) { cq->armed[i] = 1; return; }
+	for (int i = 0; i < cq->ncells; ++i)   /* owners that are gone */
+		if (!cq->cells[i]->dev_word) { queue_drop_cell(cq, i); --i; }
+	if (cq->ncells == CCL_QUEUE_MAX_CELLS) queue_drop_cell(cq, 0);   /* drop the oldest watch */
 	++cell->refs;
+	cq->armed[cq->ncells] = 1;
 	cq->cells[cq->ncells++] = cell;
 }
 
-/* After the queue's stream has been synchronised: did any watched kernel give
- * up a bounded spin? Returns 0 (and sets err) if so. */
-static int queue_check_status(CCLQueue* cq, GError** err) {
+/* `cq` is made to wait for a command of another queue: whatever that queue
+ * watches (and has not checked yet) can invalidate what `cq` produces from now
+ * on, and the caller may well synchronise with `cq` alone — upstream's own
+ * harness reads the sorted array back on a separate transfer queue
+ * (benchmarks/clo_sort_bench.c:160-162,196). The watch travels with the wait. */
+static void queue_inherit_watches(CCLQueue* cq, CCLQueue* from) {
+	if (!cq || !from || cq == from) return;
+	for (int i = 0; i < from->ncells; ++i)
+		if (from->armed[i] && from->cells[i]->dev_word) ccl_queue_watch_status(cq, from->cells[i]);
+}
+
+/* After the queue's stream (final) or one of its events has been synchronised:
+ * did any watched kernel give up a bounded spin? Returns 0 (and sets err) if so.
+ * Only a FINAL check disarms a watch: behind a single event later commands of
+ * the queue may still be running. */
+static int queue_check_status(CCLQueue* cq, int final, GError** err) {
 	int ok = 1;
 	for (int i = 0; i < cq->ncells; ++i) {
 		clo_status_cell* c = cq->cells[i];
-		if (!c->dev_word) continue;
+		if (!c->dev_word) { queue_drop_cell(cq, i); --i; continue; }   /* the owner is gone */
+		if (!cq->armed[i]) continue;
+		if (final) cq->armed[i] = 0;
 		const int st = clo_hip_check_status(c->dev_word, cq->stream);
 		if (st == CLO_HIP_ETIMEOUT) {
 			c->tripped = 1;
@@ -308,7 +347,7 @@ CCLContext* ccl_queue_get_context(CCLQueue* cq, GError** err) {
 cl_bool ccl_queue_finish(CCLQueue* cq, GError** err) {
 	if (!cq) return CL_FALSE;
 	if (hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize")) return CL_FALSE;
-	return queue_check_status(cq, err) ? CL_TRUE : CL_FALSE;
+	return queue_check_status(cq, 1, err) ? CL_TRUE : CL_FALSE;
 }
 
 void* ccl_queue_get_stream(CCLQueue* cq) { return cq ? cq->stream : NULL; }
@@ -331,10 +370,19 @@ CCLEvent* ccl_queue_begin_command(CCLQueue* cq, const char* name, GError** err) 
 CCLEvent* ccl_queue_begin_command_after(CCLQueue* cq, const char* name, CCLEvent* after, GError** err) {
 	if (!cq) { clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "NULL queue"); return NULL; }
 	if (!use_device(cq->ctx, err)) return NULL;
-	struct ccl_event* e = (struct ccl_event*) calloc(1, sizeof(*e));
-	if (!e) return NULL;
+	struct ccl_event* e = NULL;
+	if (!cq->profiling && cq->spare) {   /* a retired event: struct and hip event are reused */
+		e = cq->spare;
+		cq->spare = e->next;
+		void* end = e->end;
+		memset(e, 0, sizeof(*e));
+		e->end = end;
+	} else {
+		e = (struct ccl_event*) calloc(1, sizeof(*e));
+		if (!e) return NULL;
+		if (hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) { free(e); return NULL; }
+	}
 	ccl_event_set_name(e, name);
-	if (hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) { free(e); return NULL; }
 	if (cq->profiling && after != NULL && after->cq == cq && after->end != NULL) {
 		e->start = after->end;
 		e->start_borrowed = 1;
@@ -352,17 +400,16 @@ CCLEvent* ccl_queue_begin_command_after(CCLQueue* cq, const char* name, CCLEvent
 	cq->events = e;
 	if (!cq->first) cq->first = e;
 	if (++cq->nevents > 2 * CCL_QUEUE_KEEP_EVENTS && !cq->profiling) {
-		/* Nobody profiles this queue: only the most recent events stay (a loop
-		 * of sorts would otherwise grow the list without bound). An in-order
-		 * queue has finished or will finish the older commands first; destroying
-		 * a pending hipEvent is legal. */
+		/* Nobody profiles this queue: only the most recent events stay distinct (a
+		 * loop of sorts would otherwise grow the list without bound); the older
+		 * ones are retired to the spare list (see CCL_QUEUE_KEEP_EVENTS). */
 		struct ccl_event* keep = cq->events;
 		for (size_t i = 1; i < CCL_QUEUE_KEEP_EVENTS && keep->next; ++i) keep = keep->next;
 		struct ccl_event* old = keep->next;
 		keep->next = NULL;
 		cq->first = keep;
 		cq->nevents = CCL_QUEUE_KEEP_EVENTS;
-		while (old) { struct ccl_event* next = old->next; event_free(old); old = next; }
+		while (old) { struct ccl_event* next = old->next; old->next = cq->spare; cq->spare = old; old = next; }
 	}
 	return e;
 }
@@ -387,9 +434,11 @@ cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err) {
 cl_bool ccl_queue_wait_for(CCLQueue* cq, CCLEventWaitList* ewl, GError** err) {
 	if (!cq) return CL_FALSE;
 	if (!ewl || !*ewl) return CL_TRUE;
-	for (size_t i = 0; i < (*ewl)->n; ++i)
+	for (size_t i = 0; i < (*ewl)->n; ++i) {
 		if (hip_failed(clo_hip_stream_wait_event(cq->stream, (*ewl)->evts[i]->end), err, "hipStreamWaitEvent"))
 			return CL_FALSE;
+		queue_inherit_watches(cq, (*ewl)->evts[i]->cq);
+	}
 	return CL_TRUE;
 }
 
@@ -445,8 +494,10 @@ static CCLEvent* enqueue_copy(CCLQueue* cq, const char* name, copy_fn fn, void* 
 		 * is done, so nothing is lost by waiting for its dependencies here — and a
 		 * wait pending in the copy's stream pushes the runtime onto a slower copy
 		 * path (measured: reading back 256 MiB took 12.9 ms instead of 4.6 ms). */
-		for (size_t i = 0; i < (*ewl)->n; ++i)
+		for (size_t i = 0; i < (*ewl)->n; ++i) {
 			if (hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) return NULL;
+			queue_inherit_watches(cq, (*ewl)->evts[i]->cq);
+		}
 	} else if (!ccl_queue_wait_for(cq, ewl, err)) return NULL;
 	if (ewl) ccl_event_wait_list_clear(ewl);
 	CCLEvent* e = ccl_queue_begin_command(cq, name, err);
@@ -540,7 +591,7 @@ cl_bool ccl_event_wait(CCLEventWaitList* ewl, GError** err) {
 		 * watches the status word (only queues that ran such commands pay this) */
 		for (size_t i = 0; i < (*ewl)->n && ok; ++i) {
 			CCLQueue* cq = (*ewl)->evts[i]->cq;
-			if (cq && cq->ncells > 0 && !queue_check_status(cq, err)) ok = CL_FALSE;
+			if (cq && cq->ncells > 0 && !queue_check_status(cq, 0, err)) ok = CL_FALSE;
 		}
 		ccl_event_wait_list_clear(ewl);
 	}
@@ -626,7 +677,7 @@ cl_bool ccl_prof_calc(CCLProf* prof, GError** err) {
 		}
 		if (!cq->events) continue;
 		if (hip_failed(clo_hip_stream_synchronize(cq->stream), err, "hipStreamSynchronize")) return CL_FALSE;
-		if (!queue_check_status(cq, err)) return CL_FALSE;
+		if (!queue_check_status(cq, 1, err)) return CL_FALSE;
 		/* Sum of the commands' own durations: on an in-order queue that is the
 		 * time the device spent on them, idle gaps between commands (a chunked
 		 * pipeline waiting for its next copy) excluded — cf4ocl2's aggregate

@@ -99,6 +99,20 @@ typedef struct {
 const clo_scan_impl_ext* clo_scan_impl_ext_find(const char* name);
 extern const clo_scan_impl_ext clo_scan_blelloch_ext;
 
+/* The same for sort implementations (CloSortImplDef keeps upstream's layout,
+ * clo_sort_abstract.in.h:43-110).
+ *  check_status: after the sort's result has been waited for, fails with
+ *    CLO_ERROR_LIBRARY if a kernel of this sorter gave up a bounded spin (the
+ *    single-sweep radix passes poll other work-groups). clo_sort_with_host_data
+ *    calls it whatever queues the caller passed. */
+struct clo_sort;
+typedef struct {
+	const char* name;
+	cl_bool (*check_status)(struct clo_sort* sorter, CCLQueue* cq, GError** err);
+} clo_sort_impl_ext;
+const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name);
+extern const clo_sort_impl_ext clo_sort_satradix_ext;
+
 /* Per-kernel events on a profiling queue. Upstream enqueues every kernel itself
  * and names its event (clo_sort_satradix.c:282,295,312; clo_scan_blelloch.c:158,
  * 183,193; clo_sort_sbitonic.c:115), and CCLProf consumers see those names. Here

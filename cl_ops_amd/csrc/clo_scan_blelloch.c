@@ -156,6 +156,7 @@ static void clo_scan_blelloch_finalize(CloScan* scan) {
 	clo_scan_blelloch_data* data = (clo_scan_blelloch_data*) clo_scan_get_data(scan);
 	if (data) {
 		clo_status_cell_set_word(data->status, NULL);   /* queues still watching must not read freed memory */
+		if (data->workspace.ptr) clo_hip_scan_workspace_forget(data->workspace.ptr);
 		clo_status_cell_unref(data->status);
 		clo_devbuf_release(&data->workspace);
 		clo_devbuf_release(&data->fp_workspace);

@@ -217,6 +217,13 @@ static void sort_warmup(CloSort* sorter, const char* type, size_t elem_size) {
 	}
 }
 
+const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name) {
+	static const clo_sort_impl_ext* const table[] = { &clo_sort_satradix_ext, NULL };
+	for (unsigned i = 0; name != NULL && table[i] != NULL; ++i)
+		if (strcmp(table[i]->name, name) == 0) return table[i];
+	return NULL;
+}
+
 CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
 	const char* compiler_opts, GError** err) {
@@ -401,6 +408,14 @@ cl_bool clo_sort_with_host_data(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq
 	ccl_event_set_name(evt, "clo_sort_read");
 	ccl_event_wait(ccl_ewl(&ewl, evt, NULL), &err_internal);
 	if (err_internal) goto error_handler;
+	/* A sorter whose kernels poll other work-groups may have given up a bounded
+	 * spin: asked here explicitly, whatever queues the caller passed (with a
+	 * separate cq_comm — upstream's own harness, benchmarks/clo_sort_bench.c:160-162 —
+	 * the wait above has synchronised with the transfer queue only). */
+	{
+		const clo_sort_impl_ext* ext = clo_sort_impl_ext_find(sorter->impl_def.name);
+		if (ext && ext->check_status && !ext->check_status(sorter, cq_exec, &err_internal)) goto error_handler;
+	}
 
 	status = CL_TRUE;
 	goto finish;

@@ -158,10 +158,41 @@ static CCLEvent* clo_sort_satradix_sort_with_device_data(CloSort* sorter, CCLQue
 		}
 	}
 
-	if (per_kernel) return clo_kernel_events_remove(&ke, err);
+	if (per_kernel) {
+		GError* e2 = NULL;
+		CCLEvent* last = clo_kernel_events_remove(&ke, &e2);
+		if (e2) { clo_gerror_propagate(err, e2); return NULL; }
+		if (last) return last;
+		evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);   /* (no launch was observed) */
+		if (!evt) return NULL;
+	}
 	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	return evt;
 }
+
+/* After the sort's result has been waited for: did one of its kernels give up a
+ * bounded look-back spin (single-sweep passes)? clo_internal.h: clo_sort_impl_ext. */
+static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GError** err) {
+	clo_sort_satradix_data* data = (clo_sort_satradix_data*) clo_sort_get_data(sorter);
+	if (!data || !data->workspace.ptr || data->ws_ready != data->workspace.ptr) return CL_TRUE;
+	if (clo_status_cell_take_tripped(data->status)) {   /* a queue's own check found it first (and has cleared the word) */
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY,
+			"satradix: a work-group gave up waiting for its predecessors' counts (bounded look-back spin); the output is not valid");
+		return CL_FALSE;
+	}
+	const int st = clo_hip_check_status(data->workspace.ptr, ccl_queue_get_stream(cq));
+	if (st == 0) return CL_TRUE;
+	if (st == CLO_HIP_ETIMEOUT) {
+		data->ws_ready = NULL;   /* the header is cleared again before the next sort */
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY,
+			"satradix: a work-group gave up waiting for its predecessors' counts (bounded look-back spin); the output is not valid");
+		return CL_FALSE;
+	}
+	clo_hip_failed(st, err, "clo_hip_check_status");
+	return CL_FALSE;
+}
+
+const clo_sort_impl_ext clo_sort_satradix_ext = { "satradix", clo_sort_satradix_check_status };
 
 typedef struct {
 	clo_sort_satradix_data* data;

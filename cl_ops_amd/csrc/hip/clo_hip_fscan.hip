@@ -13,7 +13,8 @@
 //   (4096 tile sums per upper tile; three levels cover any array).
 // Upstream's order is the Blelloch tree of its own work-group shape, so results
 // agree with it to rounding, not bit for bit (no two work-group sizes of upstream
-// agree bit for bit either). 3 element streams instead of 2.
+// agree bit for bit either); like upstream's down-sweep, no step subtracts. 3 element
+// streams instead of 2.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -50,7 +51,13 @@ __device__ __forceinline__ TSum fs_block_exclusive(TSum mine, TSum* total, TSum*
 		tot += s_w[w];
 	}
 	*total = tot;
-	return base + (incl - mine);   // (incl - mine: the sum of the lanes before, as the tree formed it)
+	// The lanes before this one: the inclusive value of the lane below, never `incl - mine` —
+	// in floating point (a + b) - b is not a: a thread sum much larger than the prefix in
+	// front of it would swallow that prefix (thread sums 16, 1e9: the second thread's
+	// offset must be 16, upstream's down-sweep never subtracts either).
+	TSum excl = __shfl_up(incl, 1, 64);
+	if (lane == 0) excl = 0;
+	return base + excl;
 }
 
 template <typename TIn, typename TSum>

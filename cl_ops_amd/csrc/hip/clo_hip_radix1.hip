@@ -30,12 +30,26 @@
 //            before its own.
 // One hop of level 2 covers 16 * 8 = 128 tiles. Tile numbers are tickets (HIP
 // promises no dispatch order: a tile may only wait for tiles already handed
-// out), drawn from one counter per XCD: chunk j of pool x is global chunk
-// 8*j + x, so the 16 tiles of a chunk run behind one L2, where the boundary
-// lines of neighbouring runs merge (clo_hip_radix4.hip has the measurements),
-// and the eight pools advance side by side. Which XCD a work-group is on is
-// read from the hardware (XCC_ID) and used for speed only. Every poll loop is
-// bounded (status word, as the scan).
+// out). Two ways of drawing them (r1_pass::pools):
+//   1 pool   ONE counter, tickets = tile numbers: whatever the device looks like,
+//            every tile a work-group can be waiting for has been handed out. The
+//            library's default (it takes this path for 4 .. 1024 tiles).
+//   8 pools  one counter per XCD, chunk j of pool x = global chunk 8*j + x, the
+//            XCD read from the hardware (XCC_ID): the 16 tiles of a chunk run
+//            behind one L2, where the boundary lines of neighbouring runs merge
+//            (clo_hip_radix4.hip has the measurements). A tile of pool x waits for
+//            the chunk before its own, which belongs to pool x - 1: forward
+//            progress then DEPENDS on all eight pools being drawn from side by
+//            side, i.e. on work-groups being resident on all eight XCDs. With
+//            every work-group reporting one XCC_ID (a partitioned device, CU
+//            masking) and more tiles in a pool than resident work-groups, the
+//            resident ones would hold pool-x tiles that wait for chunks of pools
+//            nobody draws from, until the bounded spins give up. Used only where
+//            that cannot happen by construction: a device with all 256 CUs (8
+//            XCDs, >= 768 resident work-groups), more than 1024 tiles, i.e. the
+//            forced sweeps of the A/B runs (CLO_RADIX_SWEEP=1) — and a work-group
+//            whose own pool is used up helps the others.
+// Every poll loop is bounded (status word, as the scan).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -166,6 +180,7 @@ struct r1_pass {
 	unsigned* status;        // workspace status word
 	clo_u64* stamps;         // optional: 8 s_memtime stamps per tile (diagnostic builds of the probe tools)
 	unsigned tiles, max_spins;
+	unsigned pools;          // 1 or R1_POOLS ticket counters (see the head of this file)
 };
 
 // R1_EARLY: level-1 entries (the previous chunk's prefix + the nearest rows) requested
@@ -216,16 +231,16 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	#pragma unroll
 	for (int k = 0; k < WAVES * R1_ROW / THREADS; ++k) s_hist[k * THREADS + tid] = 0;
 
-	// ---- ticket: the next tile of this XCD's pool (another pool's once it is used up) ----
+	// ---- ticket: the next tile (of this XCD's pool; another pool's once it is used up) ----
 	if (tid == 0) {
 		const unsigned nchunks = (P.tiles + R1_CHUNK - 1u) >> R1_CHUNK_LOG;
 		const unsigned x = clo_xcc_id();
 		unsigned tile = 0xffffffffu;
-		for (unsigned t = 0; t < (unsigned) R1_POOLS; ++t) {
-			const unsigned pool = (x + t) & (R1_POOLS - 1);
-			// (tiles of pool `pool`: chunks pool, pool + 8, ...; only the very last chunk may be partial)
+		for (unsigned t = 0; t < P.pools; ++t) {
+			const unsigned pool = (x + t) & (P.pools - 1u);
+			// (tiles of pool `pool`: chunks pool, pool + pools, ...; only the very last chunk may be partial)
 			const unsigned k = atomicAdd(&P.ticket[pool * R1_TICKET_STRIDE], 1u);
-			const unsigned c = (k >> R1_CHUNK_LOG) * R1_POOLS + pool;
+			const unsigned c = (k >> R1_CHUNK_LOG) * P.pools + pool;
 			const unsigned cand = (c << R1_CHUNK_LOG) + (k & (R1_CHUNK - 1u));
 			if (c < nchunks && cand < P.tiles) { tile = cand; break; }
 		}
@@ -522,6 +537,13 @@ r1_layout r1_make_layout(size_t n, int elem_size, int key_bits) {
 	return L;
 }
 
+int r1_device_cus() {   // compute units of the current device (256 = all eight XCDs of an MI355X)
+	int dev = 0, cus = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	return cus;
+}
+
 clo_u64* g_r1_stamps = nullptr;   // diagnostic (clo_hip_radix_debug_stamps)
 size_t g_r1_stamps_tiles = 0;
 
@@ -550,6 +572,10 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const int chunk_log = r1_chunk_log();
 	int early = 8;   // (CLO_R1_EARLY: A/B measurements)
 	if (const char* m = getenv("CLO_R1_EARLY")) early = atoi(m);
+
+	// ticket pools: one counter unless the eight pools are safe (head of this file); CLO_R1_POOLS: A/B runs
+	unsigned pools = (tiles > 1024u && r1_device_cus() >= 256) ? (unsigned) R1_POOLS : 1u;
+	if (const char* m = getenv("CLO_R1_POOLS")) pools = atoi(m) == R1_POOLS ? (unsigned) R1_POOLS : 1u;
 
 	const bool dbg = getenv("CLO_DEBUG") != nullptr;
 	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: n=%zu tiles=%u passes=%d ws=%p bytes=%zu stream=%p\n", n, tiles, passes, ws, L.total, (void*) s);
@@ -588,6 +614,7 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		P.stamps = (g_r1_stamps && g_r1_stamps_tiles >= L.tiles && p == passes - 1) ? g_r1_stamps : nullptr;
 		P.tiles = tiles;
 		P.max_spins = max_spins;
+		P.pools = pools;
 		clo_timing_scope timing("radix_sweep", s);
 		#define CLO_R1_SWEEP(CL, EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL, EARLY>), dim3(tiles), dim3(sweep_shape<E>::THREADS), 0, s, \
 			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P, \

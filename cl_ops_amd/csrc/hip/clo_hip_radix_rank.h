@@ -290,7 +290,8 @@ __device__ __forceinline__ void pc_local_split(const E (&key)[ITEMS], unsigned d
 		pc_local_split_impl<E, BITS, THREADS, ITEMS, HMAX, false, ALIAS>(key, dshift, dmask, count, s_stage, tab, s_wtot, s_wbase, mid, counted);
 }
 
-// XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. Used for speed only.
+// XCD the wave runs on (HW_REG_XCC_ID, bits 3..0), 0..7. The sweep kernel's eight ticket pools rely
+// on it for forward progress, not only for speed, and are restricted accordingly (clo_hip_radix1.hip, head).
 __device__ __forceinline__ unsigned clo_xcc_id() {
 	return (unsigned) __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
 }

@@ -21,7 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
@@ -502,6 +504,39 @@ int launch_reduce(const void* in, size_t n, uint64_t* total, hipStream_t s) {
 	return (int) hipGetLastError();
 }
 
+// Workspaces clo_hip_scan_workspace_init has prepared, with the byte count it was given
+// (host side, this process). A scan keeps its workspace consistent itself and clears
+// nothing per call, and where its accumulators live depends on the workspace's SIZE: a
+// range that was never initialised, or a call that passes another byte count than the
+// one the range was initialised with (one workspace for the largest n and
+// clo_hip_scan_workspace_bytes(n) per call — the natural usage while every call cleared
+// its workspace), would read garbage as counters and return wrong sums with no
+// status raised. Such calls are refused (CLO_HIP_EWORKSPACE) instead.
+struct scan_ws_entry { void* ptr; size_t bytes; };
+std::mutex g_scan_ws_mutex;
+std::vector<scan_ws_entry> g_scan_ws;
+constexpr size_t SCAN_WS_MAX_ENTRIES = 1024;
+
+void scan_ws_remember(void* ptr, size_t bytes) {   // bytes == 0: forget whatever starts inside [ptr, ptr + 1)
+	std::lock_guard<std::mutex> lock(g_scan_ws_mutex);
+	const char* lo = (const char*) ptr;
+	const char* hi = lo + (bytes ? bytes : 1);
+	for (size_t i = 0; i < g_scan_ws.size(); ) {   // anything that overlaps the range is gone
+		const char* a = (const char*) g_scan_ws[i].ptr;
+		if (a < hi && lo < a + g_scan_ws[i].bytes) { g_scan_ws[i] = g_scan_ws.back(); g_scan_ws.pop_back(); }
+		else ++i;
+	}
+	if (bytes == 0) return;
+	if (g_scan_ws.size() >= SCAN_WS_MAX_ENTRIES) g_scan_ws.erase(g_scan_ws.begin());
+	g_scan_ws.push_back({ ptr, bytes });
+}
+
+bool scan_ws_known(void* ptr, size_t bytes) {
+	std::lock_guard<std::mutex> lock(g_scan_ws_mutex);
+	for (const scan_ws_entry& e : g_scan_ws) if (e.ptr == ptr) return e.bytes == bytes;
+	return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -517,7 +552,16 @@ size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size) {
 
 int clo_hip_scan_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
 	if (!workspace || workspace_bytes < CLO_WS_HEADER_BYTES) return CLO_HIP_EARGS;
-	return (int) hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t) stream);
+	const hipError_t e = hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t) stream);
+	if (e != hipSuccess) return (int) e;
+	scan_ws_remember(workspace, workspace_bytes);
+	return 0;
+}
+
+int clo_hip_scan_workspace_forget(void* workspace) {
+	if (!workspace) return CLO_HIP_EARGS;
+	scan_ws_remember(workspace, 0);
+	return 0;
 }
 
 int clo_hip_scan_workspace_set_epoch(void* workspace, unsigned epoch, void* stream) {
@@ -546,6 +590,9 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
 		g_scan_max_spins = m ? (unsigned) strtoul(m, nullptr, 10) : CLO_MAX_SPINS;
 	}
 	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
+	// the place of the accumulators follows from the workspace's size, and nothing is cleared per call:
+	// this must be the range clo_hip_scan_workspace_init prepared, under the byte count it was given
+	if (!scan_ws_known(workspace, workspace_bytes)) return CLO_HIP_EWORKSPACE;
 	if (numel / scan_tile_elems(numel, sum_size) >= 0x7fffffffull) return CLO_HIP_EARGS;
 	const clo_u64* ci = (const clo_u64*) carry_in_dev;
 	clo_u64* co = (clo_u64*) carry_out_dev;

@@ -265,7 +265,8 @@ class HipScanOps:
         """dst[:n] = carry + exclusive scan of src[:n]; carry: 1-element int64 device tensor or None."""
         need = self.lib.clo_hip_scan_workspace_bytes(n, self.elem_size, self.sum_size)
         if self._ws is None or self._ws.numel() < need:
-            self._ws = self.torch.zeros(need, dtype=self.torch.uint8, device=src.device)   # (= clo_hip_scan_workspace_init)
+            self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=src.device)
+            self._hip.check(self.lib.clo_hip_scan_workspace_init(self._ws.data_ptr(), need, self.stream), "clo_hip_scan_workspace_init")
         self._hip.check(self.lib.clo_hip_scan_exclusive_carry(
             src.data_ptr(), dst.data_ptr(), n, self.elem_size, self.elem_signed, self.sum_size,
             carry.data_ptr() if carry is not None else None, None,
@@ -276,7 +277,7 @@ class HipScanOps:
         if self._ws is not None:
             st = self.lib.clo_hip_check_status(self._ws.data_ptr(), self.stream)
             if st != 0:
-                self._ws.zero_()
+                self.lib.clo_hip_scan_workspace_init(self._ws.data_ptr(), self._ws.numel(), self.stream)
             self._hip.check(st, "sharded scan")
 
 

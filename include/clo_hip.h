@@ -99,6 +99,17 @@ const char* clo_hip_error_string(int status);
  * `stream`. */
 size_t clo_hip_scan_workspace_bytes(size_t numel, int elem_size, int sum_size);
 int clo_hip_scan_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+/* RULE: every scan on a workspace passes the SAME workspace_bytes the range was
+ * initialised with (where the scan keeps its accumulators follows from that
+ * size; a workspace sized for the largest array serves every smaller one under
+ * its full byte count). The library remembers what clo_hip_scan_workspace_init
+ * prepared (pointer and byte count, host side) and answers CLO_HIP_EWORKSPACE
+ * to a scan on a range it did not prepare or under another byte count — round 1's
+ * "contents don't care, pass clo_hip_scan_workspace_bytes(n) per call" would
+ * otherwise return wrong sums silently. clo_hip_scan_workspace_forget: the
+ * caller is about to free the range (optional; initialising a range that
+ * overlaps a remembered one replaces it). */
+int clo_hip_scan_workspace_forget(void* workspace);
 /* Test hook: sets the epoch the next scan on this workspace continues from
  * (epochs run 1 .. 2^30-1, then the workspace is zeroed in-kernel and they start
  * over); lets a test cross the wrap without 2^30 calls. */

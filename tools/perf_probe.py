@@ -59,7 +59,7 @@ def probe_radix(ctx, q, logn, etype, variant, radix=16, pairs=False):
     npass, tp = k["radix_pass"]
     print("radix %s%s 2^%d radix=%d variant=%d: %.3f ms (min of %s) -> %.0f Mkeys/s; pass avg %.3f ms (%d launches) = %.2f TB/s moved, hist %.3f ms, offsets avg %.4f ms; sorted=%s"
           % (etype, "(pairs)" if pairs else "", logn, radix, variant, best, ["%.3f" % x for x in ms2], n / best / 1e3,
-             tp / max(npass, 1), npass, 2 * es * n / (tp / max(npass, 1) * 1e-3) / 1e12, k["radix_hist"][1] / max(k["radix_hist"][0], 1), k["radix_offsets"][1] / max(k["radix_offsets"][0], 1), ok), flush=True)
+             tp / max(npass, 1), npass, 2 * es * n / (max(tp, 1e-9) / max(npass, 1) * 1e-3) / 1e12, k["radix_hist"][1] / max(k["radix_hist"][0], 1), k["radix_offsets"][1] / max(k["radix_offsets"][0], 1), ok), flush=True)
     for b in (src, dst):
         b.close()
     s.close()
