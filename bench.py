@@ -14,9 +14,12 @@ N > 1: one rank per GPU over RCCL. Started either by the driver
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) or
 by this script itself: with WORLD_SIZE unset, `python bench.py --gpus N` spawns
 that very command as a child process BEFORE anything here touches a GPU and
-exits with its code. A step is the distributed sort of the whole array: MSD
-bucket partition -> count all-gather -> all-to-all(v) over xGMI -> local
-satradix (cl_ops_amd/multigpu.py). Three legs, K timed steps each
+exits with its code. A step is the distributed sort of the whole array behind the
+C API (include/clo_shard.h, clo_shard_sort_with_device_data; --exchange torch: the
+same steps driven from Python): MSD partition into ranks x slices sub-buckets ->
+count all-gather (with every rank's status: ranks fail together) -> one
+all-to-all(v) of ncclSend/ncclRecv per slice over xGMI, slice j + 1 travelling while
+slice j is sorted -> local satradix. Three legs, K timed steps each
 (--scaling both, the default):
   weak    2^28 uint32 keys per GPU       -> the line's `value` (scaling: weak)
   strong  2^28 uint32 keys in total      -> "strong": {...}  (BASELINE.json's
@@ -25,7 +28,15 @@ satradix (cl_ops_amd/multigpu.py). Three legs, K timed steps each
           config 5 is this leg at N = 8: 2^31 keys)
 value = all keys of all ranks / max-over-ranks time. "ranks_seen" proves how
 many ranks took part (world size and an all-reduce of ones); "phases_ms" splits
-a step into partition / count exchange / key exchange / local sort.
+a step into partition / count exchange / key exchange (until the first slice is
+there) / local sort (and the rest of the exchange beside it). Every leg also carries
+"exchange": bytes a rank sends over xGMI per step, the device time from the first
+all-to-all(v) to the end of the last, the rate, and that rate as a fraction of
+(N - 1) links x 153 GB/s; and "local_sort_roofline": the bytes the local sorts move
+through HBM (PMC-calibrated per key where profiles/traffic_*.json has them, else the
+minimum the kernels must move) over the local-sort phase, as a fraction of 8 TB/s.
+A rank that spends more than --watchdog seconds in one leg ends itself with exit code
+3 (a fresh exit, never a re-exec), which makes the launcher end the other ranks.
 
 Rank 0 prints ONE JSON line. Besides the contract's fields it carries
   roofline:     PHYSICAL. `kernels` lists every kernel family of a step with
@@ -81,9 +92,14 @@ def parse_args(argv=None):
                     help="N > 1: which legs to run (both = weak + strong + the uint64 leg of config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2n", type=int, default=None)
-    ap.add_argument("--exchange", default="torch", choices=["torch", "c"],
-                    help="N > 1: the exchange through torch.distributed (batched isend/irecv on RCCL) or through the "
-                         "library's own C API over RCCL (include/clo_shard.h)")
+    ap.add_argument("--exchange", default="c", choices=["torch", "c"],
+                    help="N > 1: the sort through the library's own C API over RCCL (include/clo_shard.h: "
+                         "clo_shard_sort_with_device_data -> ncclSend/ncclRecv; the default) or driven from Python "
+                         "through torch.distributed (batched isend/irecv on RCCL)")
+    ap.add_argument("--slices", type=int, default=0, choices=[0, 1, 2, 4, 8],
+                    help="N > 1, --exchange c: sub-buckets per rank that travel while earlier ones are sorted (0 = the library's default)")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="N > 1: seconds a rank may spend in one leg before it ends itself with exit code 3 (a stuck collective)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / exchange-plan test on CPU (gloo); not a measurement")
     return ap.parse_args(argv)
 
@@ -250,7 +266,21 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # The ranks watch themselves (--watchdog per leg); this is the outer net: the launcher and its ranks run in a
+    # process group of their own and are ended as a group when the whole job overruns every leg's limit.
+    limit = 3 * args.watchdog + 600 if args.watchdog and args.watchdog > 0 else None
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        sys.stderr.write("bench.py: the %d-rank job did not end within %.0f s: ending its process group\n" % (args.gpus, limit))
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        return 3
 
 
 # ----------------------------------------------------------------------------
@@ -298,18 +328,56 @@ class _Backend:
         return float(t.item())
 
 
-def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix, exchange="torch"):
+XGMI_LINK_GBPS = 153.0   # per link and direction pair (7 links per GPU; the task's figure)
+
+
+def local_sort_bytes(m, es, radix):
+    """HBM bytes one local satradix sort of m keys moves at the least (histogram + counter scan +
+    pass kernels of every pass: min_moved_bytes per launch x launches)."""
+    if m <= 0:
+        return 0
+    bits = int(np.log2(radix))
+    passes = -(-8 * es // (2 * bits if bits <= 4 else bits))
+    return int(sum(min_moved_bytes(k, m, es, radix) for k in ("radix_hist", "radix_offsets", "radix_pass")) * passes)
+
+
+class _Watchdog:
+    """Ends THIS rank (os._exit(3): no cleanup, no re-exec) when a leg takes longer than `seconds` — a
+    collective some rank never joined would otherwise hold the whole job until the caller's own limit;
+    the launcher ends the other ranks when one of them has gone."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.t = threading.Timer(seconds, self._fire, args=(seconds, what)) if seconds and seconds > 0 else None
+        if self.t:
+            self.t.daemon = True
+            self.t.start()
+
+    @staticmethod
+    def _fire(seconds, what):
+        sys.stderr.write("bench.py: watchdog: %s still running after %.0f s — a stuck collective? ending this rank (exit 3)\n" % (what, seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def done(self):
+        if self.t:
+            self.t.cancel()
+
+
+def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix, exchange="c", slices=0, watchdog=0.0,
+                    name="leg"):
     """K timed distributed sorts of n_local keys per rank; returns the leg's record
     (on every rank; only rank 0's is printed)."""
     torch, dist = be.torch, be.dist
     from cl_ops_amd.multigpu import ShardedSorter
+    wd = _Watchdog(watchdog, "rank %d, leg %s" % (rank, name))
     es = 4 if etype == "uint" else 8
     workload = "satradix_u32" if es == 4 else "satradix_u64"
     host = make_input(workload, n_local, seed + rank)
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to(be.device)
     if exchange == "c" and not be.dry:
         from cl_ops_amd.multigpu import CShardedSorter
-        sharded = CShardedSorter(etype, local_rank, options="radix=%d" % radix)
+        sharded = CShardedSorter(etype, local_rank, options="radix=%d%s" % (radix, ",slices=%d" % slices if slices else ""))
     else:
         sharded = ShardedSorter(be.ops(etype, local_rank))
 
@@ -335,6 +403,15 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     be.fence()
     phases = {k: be.max_over_ranks(v / steps) for k, v in sorted(sharded.collect_phase_times().items())}
     sharded.phase_times = None
+    # ---- the key exchange of the last step: bytes over xGMI, device time, rate (max / min over ranks) ----
+    if hasattr(sharded, "ss"):                       # the C driver measures its own exchange (all slices)
+        x = sharded.ss.exchange()
+        x_bytes, x_s, x_slices = x["bytes_out"], x["ms"] * 1e-3, x["slices"]
+    else:                                            # the Python driver: one exchange = the key_exchange phase
+        x_bytes, x_s, x_slices = getattr(sharded, "last_exchange_bytes", 0), phases.get("key_exchange", 0.0), 1
+    x_s_max = be.max_over_ranks(x_s)
+    x_bytes_max = int(be.max_over_ranks(float(x_bytes)))
+    x_rate = x_bytes_max / x_s_max / 1e9 if x_s_max > 0 else 0.0
 
     # ---- correctness of what was timed (size-independent properties) ----
     out_t, m = last
@@ -360,7 +437,23 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     elif hasattr(sharded.ops, "close"):
         sharded.ops.close()
     del src
+    wd.done()
+    ls_bytes = local_sort_bytes(int(a[:, 2].max()), es, radix)          # the fullest rank's bucket
+    ls_s = phases.get("local_sort", 0.0)
     return {"value": round(n_local * world * steps / t_max / 1e6, 1), "unit": "Mkeys/s",
+            "exchange_stats": {
+                "bytes_out_per_gpu": x_bytes_max, "slices": x_slices, "device_ms": round(x_s_max * 1e3, 4),
+                "key_exchange_GBps": round(x_rate, 4),
+                "xgmi_peak_GBps": round((world - 1) * XGMI_LINK_GBPS, 1),
+                "xgmi_frac": round(x_rate / ((world - 1) * XGMI_LINK_GBPS), 7) if world > 1 else None,
+                "note": "bytes a rank sends to the other ranks per step (its own bucket stays on the GPU) / device time from the "
+                        "first all-to-all(v) to the end of the last; peak = (N - 1) links x %.0f GB/s" % XGMI_LINK_GBPS},
+            "local_sort_roofline": {
+                "bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "bytes": ls_bytes,
+                "achieved": round(ls_bytes / ls_s / 1e9, 3) if ls_s > 0 else None,
+                "frac": round(ls_bytes / ls_s / HBM_PEAK, 7) if ls_s > 0 else None,
+                "basis": "minimum bytes the local sort's kernels must move for the fullest rank's bucket / the local_sort "
+                         "phase (with slices that phase also waits for later slices to arrive: a lower bound)"},
             "ms_per_step": round(t_max / steps * 1e3, 4), "elements_per_gpu": n_local, "elements_total": n_local * world,
             "dtype": "u32" if es == 4 else "u64", "radix": radix, "correct": ok, "exchange": exchange,
             "ranks_seen": {"world_size": dist.get_world_size(), "allreduce_of_ones": int(ones.item())},
@@ -378,13 +471,13 @@ def main_sharded(args, world, rank, local_rank):
     n = 1 << log2n
     wbits = world.bit_length() - 1
     legs = {}
-    common = (args.steps, args.warmup, args.seed, rank, world, local_rank, args.radix, args.exchange)
+    common = (args.steps, args.warmup, args.seed, rank, world, local_rank, args.radix, args.exchange, args.slices, args.watchdog)
     if args.scaling in ("weak", "both"):
-        legs["weak"] = run_sharded_leg(be, etype, n, *common)
+        legs["weak"] = run_sharded_leg(be, etype, n, *common, name="weak")
     if args.scaling in ("strong", "both"):
-        legs["strong"] = run_sharded_leg(be, etype, max(n >> wbits, 1), *common)
+        legs["strong"] = run_sharded_leg(be, etype, max(n >> wbits, 1), *common, name="strong")
     if args.scaling == "both" and etype == "uint":       # BASELINE config 5's shape: uint64 keys, the same count per GPU
-        legs["config5_u64"] = run_sharded_leg(be, "ulong", n, *common)
+        legs["config5_u64"] = run_sharded_leg(be, "ulong", n, *common, name="config5_u64")
     head = legs.get("weak") or legs["strong"]
     ok = all(l["correct"] for l in legs.values())
     if rank == 0:
@@ -398,10 +491,12 @@ def main_sharded(args, world, rank, local_rank):
                                    % (world, int(np.log2(head["elements_per_gpu"])), "uint32" if etype == "uint" else "uint64",
                                       world, args.radix),
                        "elements_per_gpu": head["elements_per_gpu"], "radix": args.radix,
-                       "parallelism": "msd-bucket-exchange x%d (RCCL send/recv all-to-all) + local satradix" % world,
+                       "parallelism": "msd-bucket-exchange x%d (RCCL send/recv all-to-all, %d slice(s)) + local satradix"
+                                      % (world, head["exchange_stats"]["slices"]),
                        "api": "clo_shard_sort_with_device_data (C API over RCCL)" if args.exchange == "c" else
                               "cl_ops_amd.multigpu.ShardedSorter over clo_hip_msd_partition + clo_sort_with_device_data"},
             "correct": ok, "ranks_seen": head["ranks_seen"], "phases_ms": head["phases_ms"],
+            "exchange_stats": head["exchange_stats"], "roofline": head["local_sort_roofline"],
         }
         for k, v in legs.items():
             if v is not head:

@@ -88,6 +88,7 @@ _sig("clo_hip_check_status", ci, vp, vp)
 _sig("clo_hip_rccl_unique_id", ci, vp)
 _sig("clo_hip_rccl_comm_create", ci, C.POINTER(vp), vp, ci, ci)
 _sig("clo_hip_rccl_comm_destroy", ci, vp)
+_sig("clo_hip_rccl_comm_abort", ci, vp)
 _sig("clo_hip_rccl_all_gather_u64", ci, vp, vp, vp, sz, vp)
 _sig("clo_hip_rccl_all_to_all_v", ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp)
 _sig("clo_hip_set_launch_observer", ci, vp, vp)

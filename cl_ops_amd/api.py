@@ -143,7 +143,7 @@ SHARD_DESTROY = C.CFUNCTYPE(None, vp)
 
 class ShardTransportStruct(C.Structure):
     _fields_ = [("user", vp), ("rank", ci), ("world", ci), ("all_gather_u64", SHARD_AG), ("all_to_all_v", SHARD_A2A),
-                ("destroy", SHARD_DESTROY)]
+                ("destroy", SHARD_DESTROY), ("abort", SHARD_DESTROY)]
 
 
 _sig("clo_shard_rccl_unique_id", _u32, vp, _E)
@@ -154,6 +154,9 @@ _sig("clo_shard_sort_destroy", None, vp)
 _sig("clo_shard_sort_with_device_data", vp, vp, vp, vp, sz, C.POINTER(vp), C.POINTER(sz), _E)
 _sig("clo_shard_sort_get_phase_ms", None, vp, C.POINTER(C.c_double * 4))
 _sig("clo_shard_plan", None, C.POINTER(C.c_uint64), ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
+_sig("clo_shard_plan_slice", sz, C.POINTER(C.c_uint64), sz, ci, ci, ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
+     C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
+_sig("clo_shard_sort_get_exchange", None, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_double), C.POINTER(ci))
 
 
 class CloError(RuntimeError):
@@ -487,8 +490,14 @@ class ShardTransport:
         def a2a(user, s, sb, so, r, rb, ro, stream):
             return int(all_to_all_v(s, [sb[i] for i in range(world)], [so[i] for i in range(world)], r,
                                     [rb[i] for i in range(world)], [ro[i] for i in range(world)], stream) or 0)
-        st = ShardTransportStruct(None, rank, world, SHARD_AG(ag), SHARD_A2A(a2a), SHARD_DESTROY())
-        return cls(C.pointer(st), keep=(st, ag, a2a), owned=False)
+        aborted = []
+
+        def ab(user):
+            aborted.append(True)
+        st = ShardTransportStruct(None, rank, world, SHARD_AG(ag), SHARD_A2A(a2a), SHARD_DESTROY(), SHARD_DESTROY(ab))
+        t = cls(C.pointer(st), keep=(st, ag, a2a, ab), owned=False)
+        t.aborted = aborted          # non-empty once the C driver has asked for an abort
+        return t
 
     def close(self):
         if self.ptr and self._owned:
@@ -520,6 +529,13 @@ class ShardSort:
         a = (C.c_double * 4)()
         lib.clo_shard_sort_get_phase_ms(self.h, C.byref(a))
         return dict(zip(("partition", "count_exchange", "key_exchange", "local_sort"), a))
+
+    def exchange(self):
+        """The key exchange of the last call: bytes sent to / received from other ranks, device ms from the first
+        all-to-all(v) to the end of the last, number of slices used."""
+        bo, bi, ms, sl = sz(0), sz(0), C.c_double(0), ci(0)
+        lib.clo_shard_sort_get_exchange(self.h, C.byref(bo), C.byref(bi), C.byref(ms), C.byref(sl))
+        return {"bytes_out": bo.value, "bytes_in": bi.value, "ms": ms.value, "slices": sl.value}
 
     def close(self):
         if self.h:

@@ -92,7 +92,7 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 }
 
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {
-	if (bucket_bits < 1 || bucket_bits > 3) return 0;
+	if (bucket_bits < 1 || bucket_bits > 6) return 0;
 	return clo_radix4_partition_workspace_bytes(numel, elem_size, bucket_bits);
 }
 
@@ -116,7 +116,7 @@ int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_siz
 	int key_shift, int key_bits, int bucket_bits, uint64_t* counts_dev,
 	void* workspace, size_t workspace_bytes, void* stream) {
 	hipStream_t s = (hipStream_t) stream;
-	if (bucket_bits < 1 || bucket_bits > 3 || bucket_bits > key_bits) return CLO_HIP_EARGS;
+	if (bucket_bits < 1 || bucket_bits > 6 || bucket_bits > key_bits) return CLO_HIP_EARGS;
 	if (numel == 0) {
 		if (counts_dev) return (int) hipMemsetAsync(counts_dev, 0, sizeof(uint64_t) << bucket_bits, s);
 		return 0;

@@ -371,7 +371,7 @@ int rp_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, 
 }
 
 // Bucket sizes of a single-pass partition, from the per-tile histograms
-// (uint64 because the exchange plan adds them across ranks).
+// (uint64 because the exchange plan adds them across ranks). R buckets, rows of R2 counters.
 template <int R, int R2>
 __global__ __launch_bounds__(256)
 void clo_radix4_counts_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned long long* __restrict__ counts) {
@@ -391,12 +391,15 @@ void clo_radix4_counts_kernel(const unsigned* __restrict__ thist, unsigned tiles
 }
 
 // One stable pass on `BITS` bits at `shift`: the MSD bucket split of the
-// multi-GPU exchange (the pair kernel with no high digit). counts (optional)
-// receives the 1 << BITS bucket sizes.
-template <typename E, int BITS>
+// multi-GPU exchange. Up to 3 bits: the pair kernel with no high digit; 4 .. 6 bits
+// (the buckets of the ranks times the sub-buckets of a rank, include/clo_shard.h): both
+// local splits, LB + HB = BITS. counts (optional) receives the 1 << BITS bucket sizes.
+template <typename E, int BITS, int LB, int HB>
 int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned long long* counts, void* ws, hipStream_t s) {
 	constexpr unsigned R = 1u << BITS;
-	constexpr int PB = 2 * BITS;
+	constexpr int PB = LB + HB;   // width of a row of counters (BITS <= 3: LB = HB = BITS, the high half stays empty)
+	constexpr bool TWO = BITS > 3;
+	static_assert(TWO ? PB == BITS : (LB == BITS && HB == BITS), "see above");
 	const rp_layout L = rp_make_layout(n, (int) sizeof(E), PB, false);
 	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
 	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
@@ -407,6 +410,7 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	if (e != hipSuccess) return (int) e;
 	clo_timing_scope timing("msd_partition", s);
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
+	const unsigned mask_lo = TWO ? (1u << LB) - 1u : R - 1u, mask_hi = TWO ? (1u << HB) - 1u : 0u;
 	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tiles, big, kx_none, s);
 	if (st != 0) return st;
 	if (counts)
@@ -414,12 +418,12 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, s);
 	if (st != 0) return st;
 	if (big)
-		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-			src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
+		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
+			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	else
-		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, BITS, BITS, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
-			src, dst, n, shift, R - 1u, 0u, (const unsigned*) thist, (const unsigned*) toff,
+		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
+			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	return (int) hipGetLastError();
 }
@@ -460,20 +464,26 @@ size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int digit_bits, int k
 }
 
 size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits) {
-	return rp_make_layout(n, elem_size, 2 * bits, false).total;
+	return rp_make_layout(n, elem_size, bits <= 3 ? 2 * bits : bits, false).total;
 }
 
 int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
 	unsigned long long* counts, void* ws, hipStream_t s) {
-	#define CLO_R4P(E, B) return r4_partition_impl<E, B>((const E*) src, (E*) dst, n, shift, counts, ws, s)
+	#define CLO_R4P(E, B, LB, HB) return r4_partition_impl<E, B, LB, HB>((const E*) src, (E*) dst, n, shift, counts, ws, s)
 	if (elem_size == 4) {
-		if (bits == 1) CLO_R4P(uint32_t, 1);
-		if (bits == 2) CLO_R4P(uint32_t, 2);
-		if (bits == 3) CLO_R4P(uint32_t, 3);
+		if (bits == 1) CLO_R4P(uint32_t, 1, 1, 1);
+		if (bits == 2) CLO_R4P(uint32_t, 2, 2, 2);
+		if (bits == 3) CLO_R4P(uint32_t, 3, 3, 3);
+		if (bits == 4) CLO_R4P(uint32_t, 4, 2, 2);
+		if (bits == 5) CLO_R4P(uint32_t, 5, 3, 2);
+		if (bits == 6) CLO_R4P(uint32_t, 6, 3, 3);
 	} else if (elem_size == 8) {
-		if (bits == 1) CLO_R4P(uint64_t, 1);
-		if (bits == 2) CLO_R4P(uint64_t, 2);
-		if (bits == 3) CLO_R4P(uint64_t, 3);
+		if (bits == 1) CLO_R4P(uint64_t, 1, 1, 1);
+		if (bits == 2) CLO_R4P(uint64_t, 2, 2, 2);
+		if (bits == 3) CLO_R4P(uint64_t, 3, 3, 3);
+		if (bits == 4) CLO_R4P(uint64_t, 4, 2, 2);
+		if (bits == 5) CLO_R4P(uint64_t, 5, 3, 2);
+		if (bits == 6) CLO_R4P(uint64_t, 6, 3, 3);
 	}
 	#undef CLO_R4P
 	return CLO_HIP_EUNSUPPORTED;

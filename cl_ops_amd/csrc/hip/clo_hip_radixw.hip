@@ -146,55 +146,87 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 // (exactly upstream's exclusive scan of counters[num_wgs*d + wg]). A row of R
 // counters is contiguous, thread = digit: every access is coalesced. Three
 // small kernels: sums of chunks of RW_CHUNK tiles, a one-work-group scan of the
-// chunk sums, the walk over each chunk's tiles; G = 256 / R thread groups share
-// the work when R < 256.
+// chunk sums, the walk over each chunk's tiles.
+//
+// These kernels move a few MB and are bound by LATENCY: a thread that walks its
+// rows one after the other pays a round trip per row (round 2: 256 threads, one
+// thread per digit walking 128 rows, 8 loads in flight: 16-25 us for the three
+// launches, a quarter of a 2^24-key sort). Round 3: 1024 threads = G groups of R
+// threads, group g owns SUB = RW_CHUNK / G consecutive rows of the chunk and requests
+// ALL of them at once (SUB registers, fully unrolled); the groups meet in LDS. One
+// round trip per kernel instead of SUB.
 // ---------------------------------------------------------------------------
+constexpr int RW_CS_THREADS = 1024;
+template <int R> struct rw_cs {
+	static constexpr int G = (RW_CS_THREADS / R) < RW_CHUNK ? (RW_CS_THREADS / R) : RW_CHUNK;   // thread groups per chunk
+	static constexpr int SUB = RW_CHUNK / G;                                                      // rows per group
+	static_assert(G * SUB == RW_CHUNK && G * R <= RW_CS_THREADS, "the groups tile the chunk");
+};
+
 template <int R>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(RW_CS_THREADS)
 void clo_radixw_chunksum_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned* __restrict__ partial) {
-	constexpr int G = 256 / R;
-	__shared__ unsigned s_p[G][R];
+	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
+	__shared__ unsigned s_p[G * R];
 	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R;
 	const unsigned t0 = blockIdx.x * RW_CHUNK;
 	const unsigned t1 = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
-	unsigned sum = 0;
-	#pragma unroll 8
-	for (unsigned t = t0 + g; t < t1; t += G) sum += thist[(size_t) t * R + d];
-	s_p[g][d] = sum;
+	if (g < (unsigned) G) {
+		unsigned v[SUB];
+		#pragma unroll
+		for (int k = 0; k < SUB; ++k) {
+			const unsigned t = t0 + g * SUB + k;
+			v[k] = t < t1 ? thist[(size_t) t * R + d] : 0u;
+		}
+		unsigned sum = 0;
+		#pragma unroll
+		for (int k = 0; k < SUB; ++k) sum += v[k];
+		s_p[g * R + d] = sum;
+	}
 	__syncthreads();
 	if (tid < (unsigned) R) {
 		unsigned tot = 0;
-		#pragma unroll
-		for (int k = 0; k < G; ++k) tot += s_p[k][tid];
+		#pragma unroll 8
+		for (int k = 0; k < G; ++k) tot += s_p[k * R + tid];
 		partial[(size_t) blockIdx.x * R + tid] = tot;
 	}
 }
 
 // Chunk sums -> for every (chunk, digit) the offset of the chunk's first tile:
 // digit base (exclusive scan of the digit totals over the digits) + count of
-// the digit in earlier chunks. ONE work-group: thread (g, d) walks every G-th
-// chunk serially (a few hundred coalesced loads per thread), the groups are
-// combined through LDS. In place: partial[c][d] becomes that offset.
+// the digit in earlier chunks. ONE work-group: thread (g, d) owns a contiguous
+// range of chunks — all of them in registers at once when there are at most
+// RW_CS_REGS per thread (up to 128 chunks = 16 384 tiles with R = 256), else walked
+// twice —, the groups are combined through LDS. In place: partial[c][d] becomes that offset.
+constexpr int RW_CS_REGS = 32;
 template <int R>
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(RW_CS_THREADS)
 void clo_radixw_chunkscan_kernel(unsigned* __restrict__ partial, unsigned chunks) {
-	constexpr int G = 1024 / R;   // thread groups: each walks chunks / G chunks
-	__shared__ unsigned s_g[G][R], s_w[4];
+	constexpr int G = RW_CS_THREADS / R;   // thread groups: each owns chunks / G chunks
+	__shared__ unsigned s_g[G * R], s_w[4];
 	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
-	// group g owns the contiguous range of chunks [c0, c1)
 	const unsigned per = (chunks + G - 1) / G;
 	const unsigned c0 = g * per < chunks ? g * per : chunks, c1 = c0 + per < chunks ? c0 + per : chunks;
+	const bool in_regs = per <= (unsigned) RW_CS_REGS;   // (the same for every thread)
+	unsigned v[RW_CS_REGS];
 	unsigned sum = 0;
-	#pragma unroll 8
-	for (unsigned c = c0; c < c1; ++c) sum += partial[(size_t) c * R + d];
-	s_g[g][d] = sum;
+	if (in_regs) {
+		#pragma unroll
+		for (int k = 0; k < RW_CS_REGS; ++k) v[k] = c0 + k < c1 ? partial[(size_t) (c0 + k) * R + d] : 0u;
+		#pragma unroll
+		for (int k = 0; k < RW_CS_REGS; ++k) sum += v[k];
+	} else {
+		#pragma unroll 8
+		for (unsigned c = c0; c < c1; ++c) sum += partial[(size_t) c * R + d];
+	}
+	s_g[g * R + d] = sum;
 	__syncthreads();
 	unsigned before = 0, tot = 0;
-	#pragma unroll
+	#pragma unroll 4
 	for (int k = 0; k < G; ++k) {
-		const unsigned v = s_g[k][d];
-		if ((unsigned) k < g) before += v;
-		tot += v;
+		const unsigned x = s_g[k * R + d];
+		if ((unsigned) k < g) before += x;
+		tot += x;
 	}
 	// exclusive scan of the digit totals over the digits (threads 0..R-1 carry them)
 	const unsigned t = tid < (unsigned) R ? tot : 0u;
@@ -205,44 +237,58 @@ void clo_radixw_chunkscan_kernel(unsigned* __restrict__ partial, unsigned chunks
 	#pragma unroll
 	for (unsigned w = 0; w < 4; ++w) if (w < wave) dbase += s_w[w];
 	__syncthreads();
-	if (tid < (unsigned) R) s_g[0][tid] = dbase;   // (s_g[0] is free again: every thread has read it)
+	if (tid < (unsigned) R) s_g[tid] = dbase;   // (row 0 of s_g is free again: every thread has read it)
 	__syncthreads();
-	unsigned run = s_g[0][d] + before;
-	#pragma unroll 8
-	for (unsigned c = c0; c < c1; ++c) {
-		const unsigned v = partial[(size_t) c * R + d];
-		partial[(size_t) c * R + d] = run;
-		run += v;
+	unsigned run = s_g[d] + before;
+	if (in_regs) {
+		#pragma unroll
+		for (int k = 0; k < RW_CS_REGS; ++k) {
+			if (c0 + k < c1) partial[(size_t) (c0 + k) * R + d] = run;
+			run += v[k];
+		}
+	} else {
+		#pragma unroll 8
+		for (unsigned c = c0; c < c1; ++c) {
+			const unsigned x = partial[(size_t) c * R + d];
+			partial[(size_t) c * R + d] = run;
+			run += x;
+		}
 	}
 }
 
-// Offsets of the tiles of one chunk: thread (g, d) walks SUB consecutive tiles.
+// Offsets of the tiles of one chunk: thread (g, d) owns SUB consecutive tiles, all requested at once.
 template <int R>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(RW_CS_THREADS)
 void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tiles,
 	const unsigned* __restrict__ cbase, unsigned* __restrict__ toff) {
-	constexpr int G = 256 / R;
-	constexpr int SUB = RW_CHUNK / G;   // tiles per thread group
-	__shared__ unsigned s_a[G][R];
+	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
+	__shared__ unsigned s_a[G * R];
 	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R;
 	const unsigned t0 = blockIdx.x * RW_CHUNK;
 	const unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
-	const unsigned ts = t0 + g * SUB < tend ? t0 + g * SUB : tend;
-	const unsigned te = ts + SUB < tend ? ts + SUB : tend;
-	unsigned run = cbase[(size_t) blockIdx.x * R + d];
-	if (G > 1) {
+	const bool active = g < (unsigned) G;
+	unsigned v[SUB];
+	unsigned run = 0;
+	if (active) {
+		run = cbase[(size_t) blockIdx.x * R + d];
+		#pragma unroll
+		for (int k = 0; k < SUB; ++k) {
+			const unsigned t = t0 + g * SUB + k;
+			v[k] = t < tend ? thist[(size_t) t * R + d] : 0u;
+		}
 		unsigned own = 0;
-		#pragma unroll 8
-		for (unsigned t = ts; t < te; ++t) own += thist[(size_t) t * R + d];
-		s_a[g][d] = own;
-		__syncthreads();
-		for (unsigned k = 0; k < g; ++k) run += s_a[k][d];
+		#pragma unroll
+		for (int k = 0; k < SUB; ++k) own += v[k];
+		s_a[g * R + d] = own;
 	}
-	#pragma unroll 8
-	for (unsigned t = ts; t < te; ++t) {
-		const unsigned c = thist[(size_t) t * R + d];
-		toff[(size_t) t * R + d] = run;
-		run += c;
+	__syncthreads();
+	if (!active) return;
+	for (unsigned k = 0; k < g; ++k) run += s_a[k * R + d];
+	#pragma unroll
+	for (int k = 0; k < SUB; ++k) {
+		const unsigned t = t0 + g * SUB + k;
+		if (t < tend) toff[(size_t) t * R + d] = run;
+		run += v[k];
 	}
 }
 
@@ -354,9 +400,9 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 	}
 	#undef CLO_RW_OFF1
 	#define CLO_RW_OFF(B) case B: \
-		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, partial); \
-		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(1024), 0, s, partial, chunks); \
-		hipLaunchKernelGGL((clo_radixw_offsets_kernel<(1 << B)>), dim3(chunks), dim3(256), 0, s, thist, tiles, (const unsigned*) partial, toff); break
+		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, partial); \
+		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(RW_CS_THREADS), 0, s, partial, chunks); \
+		hipLaunchKernelGGL((clo_radixw_offsets_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, (const unsigned*) partial, toff); break
 	switch (bits) {
 		CLO_RW_OFF(1); CLO_RW_OFF(2); CLO_RW_OFF(3); CLO_RW_OFF(4); CLO_RW_OFF(5); CLO_RW_OFF(6); CLO_RW_OFF(7); CLO_RW_OFF(8);
 		default: return CLO_HIP_EUNSUPPORTED;

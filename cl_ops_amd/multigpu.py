@@ -190,29 +190,73 @@ class ShardedSorter:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
+    def _grow(self, total, like):
+        """The receive buffer for `total` keys (more skew than capacity_factor allows for): count-exact."""
+        self._recv = self.torch.empty(total, dtype=like.dtype, device=like.device)
+        return self._recv
+
     def sort(self, local, n=None):
         """Sorts the global array whose shards are `local[:n]` on each rank.
-        Returns (tensor, m): this rank's bucket, sorted, in tensor[:m]."""
+        Returns (tensor, m): this rank's bucket, sorted, in tensor[:m].
+
+        COLLECTIVE, and the ranks fail together (the protocol of include/clo_shard.h): a rank
+        whose own preparation fails still joins the count exchange and reports it there, so
+        that every rank raises ShardedSortError instead of one raising and the others waiting
+        inside the all-to-all for ever; growing a receive buffer, the one local step after the
+        plan, is followed by a second agreement round."""
         torch, dist = self.torch, self.dist
         n = local.numel() if n is None else n
         if self.world == 1:
             self.ops.sort_inplace(local, n)
             return local, n
 
-        send, recv = self._buffers(local, n)
         b = self.bucket_bits
+        G = self.world
+        failure = None
+        send = recv = counts = None
         self._mark(local)
-        counts = self.ops.msd_partition(local, send, n, b)                # step 1
+        try:
+            send, recv = self._buffers(local, n)
+            counts = self.ops.msd_partition(local, send, n, b)            # step 1
+        except Exception as e:                                            # noqa: BLE001 (reported through the exchange)
+            failure = e
         self._mark(local)
-        gathered = [torch.empty_like(counts) for _ in range(self.world)]
-        dist.all_gather(gathered, counts, group=self.group)               # step 2
+        # step 2: counts + [status, receive capacity]; EVERY rank joins, whatever happened above
+        row = torch.zeros(G + 2, dtype=torch.int64, device=local.device)
+        if failure is None:
+            row[:G] = counts
+            row[G + 1] = recv.numel()
+        else:
+            row[G] = 1
+        gathered = [torch.empty_like(row) for _ in range(G)]
+        dist.all_gather(gathered, row, group=self.group)
         # the host needs the sizes to slice the send / receive buffers: the one
-        # device -> host round trip of a sort (G*G counters)
-        matrix = torch.stack(gathered).cpu().numpy()
+        # device -> host round trip of a sort (G * (G + 2) words)
+        full = torch.stack(gathered).cpu().numpy()
+        bad = [int(r) for r in range(G) if full[r, G] != 0]
+        if bad:
+            if failure is not None:
+                raise ShardedSortError("rank %d failed before the exchange: %r" % (self.rank, failure)) from failure
+            raise ShardedSortError("rank(s) %s failed before the exchange: no rank sorted" % bad)
+        matrix = full[:, :G]
         sc, so, rc, ro = self.plan(matrix, self.rank)
         total = int(rc.sum())
-        if total > recv.numel():   # more skew than capacity_factor allows for: count-exact allocation
-            self._recv = recv = torch.empty(total, dtype=local.dtype, device=local.device)
+        totals = matrix.sum(axis=0)
+        if bool(np.any(totals > full[:, G + 1])):                         # somebody has to grow: decided alike everywhere
+            ok = 1
+            if total > recv.numel():
+                try:
+                    recv = self._grow(total, local)
+                except Exception as e:                                    # noqa: BLE001
+                    failure, ok = e, 0
+            flag = torch.tensor([ok], dtype=torch.int64, device=local.device)
+            flags = [torch.empty_like(flag) for _ in range(G)]
+            dist.all_gather(flags, flag, group=self.group)
+            bad = [r for r in range(G) if int(flags[r].item()) == 0]
+            if bad:
+                if failure is not None:
+                    raise ShardedSortError("rank %d could not grow its receive buffer: %r" % (self.rank, failure)) from failure
+                raise ShardedSortError("rank(s) %s could not grow their receive buffers: no rank sorted" % bad)
         self._mark(local)
 
         self.exchange(send, recv, sc, so, rc, ro)                         # step 3
@@ -220,7 +264,12 @@ class ShardedSorter:
         if total > 0:
             self.ops.sort_inplace(recv, total)                            # step 4
         self._mark(local)
+        self.last_exchange_bytes = int((sc.sum() - sc[self.rank]) * local.element_size())
         return recv, total
+
+
+class ShardedSortError(RuntimeError):
+    """A sharded sort that no rank carried out because at least one rank could not."""
 
 
 # ---------------------------------------------------------------------------

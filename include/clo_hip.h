@@ -169,7 +169,9 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
  * bucket_bits of the key field; dst gets the buckets back to back in bucket
  * order. counts_dev (device, 1<<bucket_bits uint64; may be NULL for the
  * partition) receives the bucket sizes — the partition produces them as a
- * by-product, clo_hip_msd_histogram computes them alone. */
+ * by-product, clo_hip_msd_histogram computes them alone. bucket_bits: 1..6 for
+ * the partition (up to 8 ranks x 8 sub-buckets per rank, include/clo_shard.h),
+ * 1..3 for the histogram alone. */
 int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
 	int key_shift, int key_bits, int bucket_bits,
 	uint64_t* counts_dev, void* stream);
@@ -189,6 +191,11 @@ size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits)
 int clo_hip_rccl_unique_id(void* id_out);
 int clo_hip_rccl_comm_create(void** comm, const void* id_in, int rank, int world);
 int clo_hip_rccl_comm_destroy(void* comm);
+/* ncclCommAbort: ends the communicator NOW; operations of it that are pending on any
+ * rank's streams fail instead of waiting for this rank for ever. What a rank that
+ * cannot take part in a collective its peers have already entered calls before it
+ * returns its error. The handle is gone afterwards (no clo_hip_rccl_comm_destroy). */
+int clo_hip_rccl_comm_abort(void* comm);
 int clo_hip_rccl_all_gather_u64(void* comm, const uint64_t* send_dev, uint64_t* recv_dev, size_t count, void* stream);
 int clo_hip_rccl_all_to_all_v(void* comm, int rank, int world,
 	const void* send_dev, const size_t* send_bytes, const size_t* send_offset_bytes,

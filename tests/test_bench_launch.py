@@ -30,6 +30,13 @@ def _check(d, world):
     assert set(d["phases_ms"]) == {"partition", "count_exchange", "key_exchange", "local_sort"}
     for leg in ("strong", "config5_u64"):
         assert d[leg]["correct"] is True and d[leg]["ranks_seen"]["allreduce_of_ones"] == world
+    # every leg says what it sent over the links and how the local sort stands against the HBM peak
+    for leg in (d, d["strong"], d["config5_u64"]):
+        x = leg["exchange_stats"]
+        assert x["bytes_out_per_gpu"] > 0 and x["xgmi_peak_GBps"] == round((world - 1) * 153.0, 1)
+        assert x["key_exchange_GBps"] > 0 and x["xgmi_frac"] > 0 and x["slices"] >= 1
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["bytes"] > 0 and d["roofline"]["frac"] > 0
+    assert d["strong"]["local_sort_roofline"]["bytes"] > 0
     assert d["strong"]["elements_total"] == d["config"]["elements_per_gpu"]           # the same array, split N ways
     assert d["config5_u64"]["dtype"] == "u64" and d["config5_u64"]["elements_per_gpu"] == d["config"]["elements_per_gpu"]
 
@@ -60,3 +67,14 @@ def test_reference_round_trip_yardstick():
     assert bench.reference_bitonic_round_trips(12) == 12
     assert bench.contract_bytes_per_elem("satradix_u32", 16, 28) == 96
     assert bench.contract_bytes_per_elem("sbitonic", 16, 16) == 8 * 136
+
+
+def test_watchdog_ends_a_stuck_rank_with_a_nonzero_exit():
+    """A leg that takes longer than --watchdog seconds (here: any leg, the limit is 50 ms) ends the rank with
+    exit code 3 — a plain exit of a fresh child process — and the launcher reports failure instead of hanging."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "200", "--warmup", "1", "--dry-run", "--log2n", "15",
+                        "--watchdog", "0.05"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert "watchdog" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

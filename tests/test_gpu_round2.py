@@ -481,49 +481,8 @@ def _c_shard_worker(rank, world, port, n, out_dir):
     try:
         # a transport that moves the same bytes through host memory over gloo (RCCL
         # refuses two ranks on one device); everything else is the C code under test
-        def d2h(ptr, nbytes, stream):
-            h = np.empty(nbytes, dtype=np.uint8)
-            _hip.check(lib.clo_hip_memcpy_d2h_async(h.ctypes.data, ptr, nbytes, stream))
-            _hip.check(lib.clo_hip_stream_synchronize(stream))
-            return h
-
-        def h2d(ptr, h, stream):
-            h = np.ascontiguousarray(h)
-            _hip.check(lib.clo_hip_memcpy_h2d_async(ptr, h.ctypes.data, h.nbytes, stream))
-            _hip.check(lib.clo_hip_stream_synchronize(stream))
-
-        def all_gather(send, recv, count, stream):
-            mine = torch.from_numpy(d2h(send, 8 * count, stream))
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            h2d(recv, torch.cat(parts).numpy(), stream)
-            return 0
-
-        def all_to_all_v(send, sb, so, recv, rb, ro, stream):
-            hs = d2h(send, max(sum(sb), 1), stream) if sum(sb) else np.empty(0, np.uint8)
-            hr = np.empty(max(sum(rb), 1), dtype=np.uint8)
-            hr[ro[rank]:ro[rank] + rb[rank]] = hs[so[rank]:so[rank] + sb[rank]]
-            ops, keep = [], []
-            for k in range(1, world):
-                dst, src = (rank + k) % world, (rank - k) % world
-                if sb[dst]:
-                    t = torch.from_numpy(hs[so[dst]:so[dst] + sb[dst]].copy())
-                    keep.append(t)
-                    ops.append(dist.P2POp(dist.isend, t, dst))
-                if rb[src]:
-                    t = torch.empty(rb[src], dtype=torch.uint8)
-                    keep.append((t, src))
-                    ops.append(dist.P2POp(dist.irecv, t, src))
-            for w in (dist.batch_isend_irecv(ops) if ops else []):
-                w.wait()
-            for x in keep:
-                if isinstance(x, tuple):
-                    hr[ro[x[1]]:ro[x[1]] + rb[x[1]]] = x[0].numpy()
-            if sum(rb):
-                h2d(recv, hr[:sum(rb)], stream)
-            return 0
-
-        tr = clo.ShardTransport.custom(rank, world, all_gather, all_to_all_v)
+        from shard_transport import gloo_staged_transport
+        tr = gloo_staged_transport(rank, world)
         a = np.random.default_rng(70 + rank).integers(0, np.iinfo(np.uint64).max, n + 1000 * rank, dtype=np.uint64, endpoint=True)
         if rank == 1:
             a[: a.size // 2] |= np.uint64(1) << np.uint64(63)      # uneven buckets

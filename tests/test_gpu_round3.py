@@ -187,3 +187,103 @@ def test_event_handles_stay_valid_across_many_commands(gpu):
     assert np.array_equal(dst.read(q, np.uint32, n), np.sort(a))
     for x in (s, src, dst, q):
         x.close()
+
+
+# ----------------------------------------------------------------------------
+# the sharded sort behind the C API: slices, ranks that fail together
+# ----------------------------------------------------------------------------
+
+def _shard_worker(rank, world, port, etype, n, options, fail, out_dir):
+    import faulthandler
+    faulthandler.enable()
+    import torch
+    import torch.distributed as dist
+    import cl_ops_amd as clo
+    from cl_ops_amd.multigpu import CShardedSorter
+    from shard_transport import gloo_staged_transport
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
+        bits = 8 * np.dtype(dt).itemsize
+        tr = gloo_staged_transport(rank, world)
+        a = np.random.default_rng(90 + rank).integers(0, np.iinfo(dt).max, n + 4099 * rank, dtype=dt, endpoint=True)
+        if fail and fail[1] == 2:      # everything into the failing rank's bucket: its receive buffer has to grow
+            a = (a >> dt(1)) | dt(fail[0] << (bits - 1))
+        elif rank == 1:
+            a[: a.size // 3] |= dt(1) << dt(bits - 1)              # uneven buckets
+            a[a.size // 3: a.size // 2] &= dt((1 << (bits - 3)) - 1)   # and one sub-bucket much fuller than the others
+        local = torch.from_numpy(a.view(tdt).copy()).cuda()
+        s = CShardedSorter(etype, 0, transport=tr, options=options)
+        text = ""
+        if fail:
+            os.environ["CLO_SHARD_TEST_FAIL"] = "%d:%d" % fail
+            try:
+                s.sort(local)
+                text = "NO ERROR"
+            except clo.CloError as e:
+                text = e.message
+            del os.environ["CLO_SHARD_TEST_FAIL"]
+            torch.cuda.synchronize()
+        for _ in range(2):                                          # the second call reuses every buffer
+            out, m = s.sort(local)
+            torch.cuda.synchronize()
+        x = s.ss.exchange()
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), a)
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), out.cpu().numpy().view(dt)[:m])
+        with open(os.path.join(out_dir, "info_%d.txt" % rank), "w") as f:
+            f.write("%d %d %d %d\n%s" % (x["slices"], x["bytes_out"], x["bytes_in"], int(bool(tr.aborted)), text))
+        assert np.array_equal(local.cpu().numpy().view(dt), a)
+        s.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_shard(tmp_path, etype, n, options, fail=None):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_shard_worker, args=(2, port, etype, n, options, fail, str(tmp_path)), nprocs=2, join=True)
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(2)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)]
+    infos = [(tmp_path / ("info_%d.txt" % r)).read_text().split("\n", 1) for r in range(2)]
+    bits = 8 * ins[0].dtype.itemsize
+    assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
+    assert np.all(outs[0] >> ins[0].dtype.type(bits - 1) == 0) and np.all(outs[1] >> ins[0].dtype.type(bits - 1) == 1)
+    return ins, outs, infos
+
+
+@pytest.mark.parametrize("etype,n,options,slices", [("ulong", (1 << 22) + 77, None, 4), ("uint", (1 << 22) + 5, "slices=8", 8),
+                                                    ("uint", (1 << 22) + 5, "slices=2,radix=256", 2), ("ulong", 1 << 22, "slices=1", 1),
+                                                    ("uint", 50000, None, 1)])
+def test_c_shard_sort_in_slices(gpu, tmp_path, etype, n, options, slices):
+    """Two ranks on the one GPU, the exchange staged through gloo: sub-bucket j of every rank
+    travels as its own all-to-all(v) and is sorted where it lands while the next one travels
+    (include/clo_shard.h). Small arrays fall back to one exchange whatever `slices` says."""
+    ins, outs, infos = _run_shard(tmp_path, etype, n, options)
+    es = ins[0].dtype.itemsize
+    for r in range(2):
+        used, bytes_out, bytes_in, aborted = (int(v) for v in infos[r][0].split())
+        assert used == slices and aborted == 0
+        other = 1 - r
+        top = ins[r] >> ins[r].dtype.type(8 * es - 1)
+        assert bytes_out == int(np.count_nonzero(top == other)) * es           # exactly the keys of the other rank's bucket
+        assert bytes_in == int(np.count_nonzero((ins[other] >> ins[other].dtype.type(8 * es - 1)) == r)) * es
+
+
+@pytest.mark.parametrize("fail", [(1, 1), (0, 2)])
+def test_c_shard_ranks_fail_together(gpu, tmp_path, fail):
+    """A rank that fails on its own — before the count exchange (stage 1) or while growing its
+    receive buffer after the plan (stage 2) — makes EVERY rank return an error, nobody enters the
+    key exchange, nothing is aborted, and the same objects sort correctly right afterwards."""
+    ins, outs, infos = _run_shard(tmp_path, "ulong", 300000, None, fail=fail)
+    for r in range(2):
+        aborted = int(infos[r][0].split()[3])
+        text = infos[r][1]
+        assert aborted == 0 and text != "NO ERROR", text
+        if r != fail[0]:
+            assert ("rank %d" % fail[0]) in text and "no rank sorted" in text, text

@@ -70,6 +70,109 @@ def test_sharded_sort_over_gloo(tmp_path, world, elem_type, n, skew):
             assert np.all((o >> o.dtype.type(bits - b)) == r)
 
 
+def _failing_worker(rank, world, port, stage, bad_rank, out_dir):
+    """One rank fails on its own — before the count exchange (stage 1: its partition raises)
+    or while growing its receive buffer after the plan (stage 2) — and EVERY rank must come
+    back with ShardedSortError instead of waiting inside the all-to-all; the sorter works
+    again afterwards."""
+    import torch
+    import torch.distributed as dist
+    from cl_ops_amd.multigpu import ShardedSorter, ShardedSortError
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        class Ops(NumpyLocalOps):
+            fail = False
+
+            def msd_partition(self, src, dst, n, bucket_bits):
+                if self.fail and stage == 1 and rank == bad_rank:
+                    raise MemoryError("injected: no memory for the partition on rank %d" % rank)
+                return super().msd_partition(src, dst, n, bucket_bits)
+
+        class Sorter(ShardedSorter):
+            def _grow(self, total, like):
+                if self.ops.fail and stage == 2 and rank == bad_rank:
+                    raise MemoryError("injected: cannot grow the receive buffer on rank %d" % rank)
+                return super()._grow(total, like)
+
+        n = 3000
+        rng = np.random.default_rng(5 + rank)
+        a = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+        if stage == 2:          # everything into bucket `bad_rank`: its receive buffer must grow
+            a = (a >> np.uint32(world.bit_length() - 1)) | np.uint32(bad_rank << (32 - (world.bit_length() - 1)))
+        local = torch.from_numpy(a.view(np.int32).copy())
+        ops = Ops("uint")
+        ss = Sorter(ops)
+        ops.fail = True
+        raised, text = False, ""
+        try:
+            ss.sort(local, n)
+        except ShardedSortError as e:
+            raised, text = True, str(e)
+        ops.fail = False
+        out, m = ss.sort(local, n)                      # the same object, right away
+        np.save(os.path.join(out_dir, "in_%d.npy" % rank), a)
+        np.save(os.path.join(out_dir, "out_%d.npy" % rank), out.numpy()[:m].view(np.uint32).copy())
+        with open(os.path.join(out_dir, "err_%d.txt" % rank), "w") as f:
+            f.write("%d\n%s" % (int(raised), text))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,stage,bad_rank", [(2, 1, 1), (2, 2, 0), (8, 1, 5), (8, 2, 3)])
+def test_ranks_fail_together(tmp_path, world, stage, bad_rank):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_failing_worker, args=(world, port, stage, bad_rank, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        raised, text = (tmp_path / ("err_%d.txt" % r)).read_text().split("\n", 1)
+        assert raised == "1", "rank %d did not fail with the others" % r
+        if r == bad_rank:
+            assert "injected" in text            # the failing rank tells its own story
+        else:
+            assert str(bad_rank) in text and "no rank sorted" in text
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(world)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
+
+
+def test_slice_plan_matches_a_numpy_model():
+    """clo_shard_plan_slice (pure host logic of the C driver): slice j of every rank's bucket
+    travels as one all-to-all; what rank r sends to p in slice j is what p expects from r, the
+    pieces tile the partitioned shard and the result without gaps, sub-buckets in key order."""
+    import ctypes as C
+    from cl_ops_amd.api import lib
+    rng = np.random.default_rng(3)
+    for world, slices in ((2, 4), (8, 8), (4, 2), (8, 1)):
+        row = world * slices + 2
+        m = rng.integers(0, 1000, (world, row)).astype(np.uint64)
+        m[:, 3 % (world * slices)] = 0
+        flat = np.ascontiguousarray(m.reshape(-1))
+        arr = lambda: (C.c_size_t * world)()      # noqa: E731
+        plans = {}
+        for r in range(world):
+            for j in range(slices):
+                sc, so, rc, ro = arr(), arr(), arr(), arr()
+                at, tot = C.c_size_t(0), C.c_size_t(0)
+                total = lib.clo_shard_plan_slice(flat.ctypes.data_as(C.POINTER(C.c_uint64)), row, world, slices, r, j,
+                                                 sc, so, rc, ro, C.byref(at), C.byref(tot))
+                plans[r, j] = (list(sc), list(so), list(rc), list(ro), at.value, tot.value, total)
+        for r in range(world):
+            mine = m[r, :world * slices].reshape(world, slices)
+            starts = np.concatenate(([0], np.cumsum(mine.reshape(-1))[:-1])).reshape(world, slices)
+            covered = 0
+            for j in range(slices):
+                sc, so, rc, ro, at, tot, total = plans[r, j]
+                assert sc == list(mine[:, j]) and so == list(starts[:, j])
+                assert total == int(m[:, r * slices:(r + 1) * slices].sum())
+                assert at == covered and tot == sum(rc)
+                assert ro == [at + int(sum(rc[:p])) for p in range(world)]
+                covered += tot
+                for p in range(world):
+                    assert sc[p] == plans[p, j][2][r]      # what r sends to p is what p expects from r
+            assert covered == plans[r, 0][6]
+
+
 class NumpyScanOps:
     """CPU stand-in for HipScanOps with the same contract (uint elements)."""
 
