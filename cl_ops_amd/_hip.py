@@ -84,6 +84,7 @@ _sig("clo_hip_kernel_lds_bytes", sz, C.c_char_p, ci, ci)
 _sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
 _sig("clo_hip_bitonic_jit_destroy", None, vp)
 _sig("clo_hip_bitonic_jit_sort", ci, vp, vp, sz, ci, C.POINTER(ci), vp)
+_sig("clo_hip_bitonic_jit_gselect", ci, vp, vp, vp, sz, vp)
 _sig("clo_hip_check_status", ci, vp, vp)
 _sig("clo_hip_rccl_unique_id", ci, vp)
 _sig("clo_hip_rccl_comm_create", ci, C.POINTER(vp), vp, ci, ci)

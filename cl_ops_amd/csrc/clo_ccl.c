@@ -33,8 +33,9 @@ struct ccl_event {
 	struct ccl_queue* cq;    /* the queue that owns it */
 	char name[48];
 	void* start;             /* hip events; start only when profiling */
-	void* end;
+	void* end;               /* may be NULL until somebody needs it (lazy, below) */
 	int start_borrowed;      /* start is the `end` of the command before (a chain of kernels): not ours to destroy */
+	int recorded;            /* `end` has been recorded on the queue's stream */
 };
 
 /* A device status word some kernel of this queue's commands may raise (the
@@ -380,7 +381,9 @@ CCLEvent* ccl_queue_begin_command_after(CCLQueue* cq, const char* name, CCLEvent
 	} else {
 		e = (struct ccl_event*) calloc(1, sizeof(*e));
 		if (!e) return NULL;
-		if (hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) { free(e); return NULL; }
+		/* a profiling queue stamps every command; any other queue creates and records the event of a
+		 * command only if somebody asks for it (event_ensure_recorded) */
+		if (cq->profiling && hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) { free(e); return NULL; }
 	}
 	ccl_event_set_name(e, name);
 	if (cq->profiling && after != NULL && after->cq == cq && after->end != NULL) {
@@ -426,15 +429,37 @@ void ccl_queue_abort_command(CCLQueue* cq, CCLEvent* evt) {
 	event_free(evt);
 }
 
+/* On a queue WITHOUT profiling the end of a command is not recorded when the command is enqueued:
+ * a hipEventRecord is a marker packet between two kernels (a few microseconds of pipeline bubble per
+ * command: 6 % of a 2^26-element scan), and most events are never looked at. Whoever does need the
+ * event — a wait list, a blocking copy, ccl_event_wait — has it recorded THEN, on the queue's stream:
+ * the queue is in order, so that marker completes after the command it stands for (and after whatever
+ * was enqueued behind it meanwhile: a wait that is at worst a little longer, never too short). A
+ * profiling queue records every command where it ends, as cf4ocl2's events do. */
+static int event_ensure_recorded(struct ccl_event* e, GError** err) {
+	if (e->recorded) return 1;
+	if (!e->cq || e->cq->closed) return 1;   /* the queue was synchronised when it went: nothing left to wait for */
+	if (!e->end && hip_failed(clo_hip_event_create(&e->end), err, "hipEventCreate")) return 0;
+	if (hip_failed(clo_hip_event_record(e->end, e->cq->stream), err, "hipEventRecord")) return 0;
+	e->recorded = 1;
+	return 1;
+}
+
 cl_bool ccl_queue_end_command(CCLQueue* cq, CCLEvent* evt, GError** err) {
 	if (!cq || !evt) return CL_FALSE;
-	return hip_failed(clo_hip_event_record(evt->end, cq->stream), err, "hipEventRecord") ? CL_FALSE : CL_TRUE;
+	if (!cq->profiling) { evt->recorded = 0; return CL_TRUE; }   /* lazily (above) */
+	if (hip_failed(clo_hip_event_record(evt->end, cq->stream), err, "hipEventRecord")) return CL_FALSE;
+	evt->recorded = 1;
+	return CL_TRUE;
 }
 
 cl_bool ccl_queue_wait_for(CCLQueue* cq, CCLEventWaitList* ewl, GError** err) {
 	if (!cq) return CL_FALSE;
 	if (!ewl || !*ewl) return CL_TRUE;
 	for (size_t i = 0; i < (*ewl)->n; ++i) {
+		if ((*ewl)->evts[i]->cq == cq && !cq->profiling) continue;   /* the same in-order queue: already behind it */
+		if (!event_ensure_recorded((*ewl)->evts[i], err)) return CL_FALSE;
+		if ((*ewl)->evts[i]->end == NULL) continue;                    /* (its queue is gone, and was synchronised) */
 		if (hip_failed(clo_hip_stream_wait_event(cq->stream, (*ewl)->evts[i]->end), err, "hipStreamWaitEvent"))
 			return CL_FALSE;
 		queue_inherit_watches(cq, (*ewl)->evts[i]->cq);
@@ -495,7 +520,8 @@ static CCLEvent* enqueue_copy(CCLQueue* cq, const char* name, copy_fn fn, void* 
 		 * wait pending in the copy's stream pushes the runtime onto a slower copy
 		 * path (measured: reading back 256 MiB took 12.9 ms instead of 4.6 ms). */
 		for (size_t i = 0; i < (*ewl)->n; ++i) {
-			if (hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) return NULL;
+			if (!event_ensure_recorded((*ewl)->evts[i], err)) return NULL;
+			if ((*ewl)->evts[i]->end && hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) return NULL;
 			queue_inherit_watches(cq, (*ewl)->evts[i]->cq);
 		}
 	} else if (!ccl_queue_wait_for(cq, ewl, err)) return NULL;
@@ -504,7 +530,7 @@ static CCLEvent* enqueue_copy(CCLQueue* cq, const char* name, copy_fn fn, void* 
 	if (!e) return NULL;
 	if (hip_failed(fn(dst, src, size, cq->stream), err, name)) { ccl_queue_abort_command(cq, e); return NULL; }
 	if (!ccl_queue_end_command(cq, e, err)) { ccl_queue_abort_command(cq, e); return NULL; }
-	if (blocking && hip_failed(clo_hip_event_synchronize(e->end), err, "hipEventSynchronize")) return NULL;
+	if (blocking && (!event_ensure_recorded(e, err) || (e->end && hip_failed(clo_hip_event_synchronize(e->end), err, "hipEventSynchronize")))) return NULL;
 	return e;
 }
 
@@ -585,8 +611,10 @@ void ccl_event_wait_list_clear(CCLEventWaitList* ewl) {
 cl_bool ccl_event_wait(CCLEventWaitList* ewl, GError** err) {
 	cl_bool ok = CL_TRUE;
 	if (ewl && *ewl) {
-		for (size_t i = 0; i < (*ewl)->n && ok; ++i)
-			if (hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) ok = CL_FALSE;
+		for (size_t i = 0; i < (*ewl)->n && ok; ++i) {
+			if (!event_ensure_recorded((*ewl)->evts[i], err)) ok = CL_FALSE;
+			else if ((*ewl)->evts[i]->end && hip_failed(clo_hip_event_synchronize((*ewl)->evts[i]->end), err, "hipEventSynchronize")) ok = CL_FALSE;
+		}
 		/* a command that polls other work-groups may have given up: its queue
 		 * watches the status word (only queues that ran such commands pay this) */
 		for (size_t i = 0; i < (*ewl)->n && ok; ++i) {

@@ -109,6 +109,12 @@ struct clo_sort;
 typedef struct {
 	const char* name;
 	cl_bool (*check_status)(struct clo_sort* sorter, CCLQueue* cq, GError** err);
+	/* host_pipeline: clo_sort_with_host_data with the transfers overlapped with the sort (SURVEY.md
+	 * §8f-2). Sets *handled = 0 and touches nothing when this sort is not one it pipelines (the caller
+	 * then takes upstream's blocking path, sort/clo_sort_abstract.c:348-395); otherwise *handled = 1
+	 * and the return value is the call's. */
+	cl_bool (*host_pipeline)(struct clo_sort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm, const void* data_in, void* data_out,
+		size_t numel, int* handled, GError** err);
 } clo_sort_impl_ext;
 const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name);
 extern const clo_sort_impl_ext clo_sort_satradix_ext;

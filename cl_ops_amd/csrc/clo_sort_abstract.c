@@ -261,7 +261,6 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_UNKNOWN_TYPE, "Unknown element or key type");
 			goto error_handler;
 		}
-		const int is_bitonic = strcmp(type, "sbitonic") == 0 || strcmp(type, "abitonic") == 0;
 		const int key_ok = parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)
 			&& !(ks->key_kind == 2 && ks->key_bits != 8 * ks->key_size);   /* a float key is the whole key type */
 		int cmp_ok = parse_compare(compare, &ks->descending);
@@ -273,13 +272,6 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 			ks->descending = 0;
 		}
 		if (!key_ok || !cmp_ok) {
-			if (!is_bitonic && !(is_satradix && !key_ok)) {
-				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
-					"Unsupported %s expression '%s' for %s (supported ahead of time: x, shifts, low-bit masks, "
-					"integer casts; ((a) > (b)), ((a) < (b)))", key_ok ? "compare" : "get_key",
-					key_ok ? compare : (get_key ? get_key : "(x)"), type);
-				goto error_handler;
-			}
 			/* what upstream does for every sorter: paste the macro bodies into the
 			 * kernel source and build it (clo_sort_abstract.c:144-179) */
 			char* log = NULL;
@@ -380,6 +372,21 @@ cl_bool clo_sort_with_host_data(CloSort* sorter, CCLQueue* cq_exec, CCLQueue* cq
 		cq_exec = intern_queue;
 	}
 	if (cq_comm == NULL) cq_comm = cq_exec;
+
+	/* Transfers overlapped with the sort where the implementation knows how (satradix on large
+	 * arrays: clo_sort_satradix.c); the result is the blocking path's. */
+	{
+		const clo_sort_impl_ext* ext = clo_sort_impl_ext_find(sorter->impl_def.name);
+		int handled = 0;
+		if (ext && ext->host_pipeline) {
+			status = ext->host_pipeline(sorter, cq_exec, cq_comm, data_in, data_out, numel, &handled, &err_internal);
+			if (handled) {
+				if (err_internal) goto error_handler;
+				goto finish;
+			}
+			status = CL_FALSE;
+		}
+	}
 
 	data_in_dev = ccl_buffer_new(ctx, CL_MEM_READ_ONLY, data_size, NULL, &err_internal);
 	if (err_internal) goto error_handler;

@@ -45,9 +45,13 @@ static CCLEvent* clo_sort_gselect_sort_with_device_data(CloSort* sorter, CCLQueu
 	void* src = ccl_buffer_get_device_ptr(data_in);
 	void* dst = copy_back ? data->tmp.ptr : ccl_buffer_get_device_ptr(data_out);
 	if (numel > 0) {
-		int st = clo_hip_gselect(src, dst, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size,
-			ks->key_kind, ks->descending, stream);
-		if (clo_hip_failed(st, err, "clo_hip_gselect")) return NULL;
+		/* compare / get_key outside the ahead-of-time family: the kernel compiled at clo_sort_new with
+		 * the two macro bodies pasted in, as upstream does (sort/clo_sort_gselect.cl:46-51) */
+		void* jit = clo_sort_get_jit(sorter);
+		int st = jit ? clo_hip_bitonic_jit_gselect(jit, src, dst, numel, stream)
+			: clo_hip_gselect(src, dst, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size,
+				ks->key_kind, ks->descending, stream);
+		if (clo_hip_failed(st, err, "clo_hip_gselect")) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
 	}
 	if (!ccl_queue_end_command(cq_exec, evt, err)) return NULL;
 
@@ -71,10 +75,6 @@ static CCLEvent* clo_sort_gselect_sort_with_device_data(CloSort* sorter, CCLQueu
 static const char* clo_sort_gselect_init(CloSort* sorter, const char* options, GError** err) {
 	clo_return_val_if_fail(err == NULL || *err == NULL, NULL);
 	(void) options;
-	if (clo_sort_get_jit(sorter) != NULL) {
-		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "gselect: run-time compiled compare/get_key is available for the bitonic sorters only");
-		return NULL;
-	}
 	clo_sort_gselect_data* data = (clo_sort_gselect_data*) calloc(1, sizeof(*data));
 	if (!data) return NULL;
 	clo_sort_set_data(sorter, data);

@@ -142,11 +142,34 @@ void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, 
 	__syncthreads();
 	for (unsigned i = tid; i < tile; i += 256) data[gbase + i] = s[PHYS(i)];
 }
+
+// gselect with the user's two macro bodies pasted in, as upstream pastes them
+// (sort/clo_sort_gselect.cl:38-58): position = number of elements whose key compares
+// "before" mine, ties by index. Keys are staged 2048 at a time in LDS.
+extern "C" __global__ __launch_bounds__(256)
+void jit_gselect(const E* __restrict__ in, E* __restrict__ out, unsigned long n) {
+	__shared__ K s_key[2048];
+	const unsigned long gid = (unsigned long) blockIdx.x * 256 + threadIdx.x;
+	const E mine = in[gid < n ? gid : 0];
+	const K km = (K) (CLO_SORT_KEY_GET_X(mine));
+	unsigned long pos = 0;
+	for (unsigned long base = 0; base < n; base += 2048) {
+		const unsigned cnt = n - base < 2048ul ? (unsigned) (n - base) : 2048u;
+		__syncthreads();
+		for (unsigned i = threadIdx.x; i < cnt; i += 256) { const E e = in[base + i]; s_key[i] = (K) (CLO_SORT_KEY_GET_X(e)); }
+		__syncthreads();
+		for (unsigned i = 0; i < cnt; ++i) {
+			const K ki = s_key[i];
+			if ((bool) (CLO_SORT_COMPARE_AB(km, ki)) || ((ki == km) && (base + i < gid))) ++pos;
+		}
+	}
+	if (gid < n && pos < n) out[pos] = mine;
+}
 )CLOJIT";
 
 struct jit_sorter {
 	hipModule_t module = nullptr;
-	hipFunction_t step = nullptr, tile = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipFunction_t step = nullptr, tile = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	int elem_size = 0;
 	int q = 0;
 };
@@ -224,6 +247,7 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	hipError_t e = hipModuleLoadData(&js->module, code.data());
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->step, js->module, "jit_step");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->tile, js->module, "jit_tile");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js->gselect, js->module, "jit_gselect");
 	for (int ns = 1; ns <= q && e == hipSuccess; ++ns) {
 		const std::string name = "jit_strided" + std::to_string(ns);
 		e = hipModuleGetFunction(&js->strided[ns], js->module, name.c_str());
@@ -243,6 +267,17 @@ void clo_hip_bitonic_jit_destroy(void* handle) {
 	if (!js) return;
 	if (js->module) (void) hipModuleUnload(js->module);
 	delete js;
+}
+
+// upstream's O(n^2) rank sort (sort/clo_sort_gselect.cl:38-58) with the user's compare / get_key: src -> dst
+int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t numel, void* stream) {
+	jit_sorter* js = (jit_sorter*) handle;
+	if (!js || !js->gselect) return CLO_HIP_EARGS;
+	if (numel == 0) return 0;
+	if (!src || !dst || src == dst) return CLO_HIP_EARGS;
+	unsigned long n = numel;
+	void* args[] = { &src, &dst, &n };
+	return launch(js->gselect, (unsigned) ((numel + 255) / 256), (hipStream_t) stream, args);
 }
 
 // In-place sort of data[0..numel), numel a power of two. tiled = 0: one launch

@@ -328,8 +328,12 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 
 	unsigned dstart2 = 0;
 	unsigned early[R1_EARLY > 0 ? R1_EARLY : 1];   // early[0]: prefix of the previous chunk; early[k]: row of tile - k (R1_VALID | count)
+	// (not valid yet: a pass whose high digit is empty — a key width that is 4 mod 8 — has no second
+	// split to request them from, and must fetch them in the loop below like the entries beyond
+	// R1_EARLY. Round 2 initialised them as "valid, count 0": such a pass then ignored the counts of
+	// up to 7 predecessors and the previous chunk — 28-, 20-, 12-bit keys on this path came out wrong.)
 	#pragma unroll
-	for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) early[k] = R1_VALID;
+	for (unsigned k = 0; k < (unsigned) R1_EARLY; ++k) early[k] = (k == 0 ? c > 0 : k <= q) ? 0u : R1_VALID;   // (entries this tile does not need count as zero)
 	if (dthread) {
 		dstart2 = incl2 - h2;
 		#pragma unroll

@@ -239,6 +239,9 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	void** handle, char** log);
 void clo_hip_bitonic_jit_destroy(void* handle);
 /* In place, numel a power of two. tiled: 0 = sbitonic schedule, 1 = abitonic. */
+/* gselect (upstream's O(n^2) rank sort, sort/clo_sort_gselect.cl:38-58) through the same compiled module:
+ * src -> dst (distinct), ties by index. */
+int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t numel, void* stream);
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream);
 
 /* ---- satradix specialised at run time (hiprtc) for a get_key expression

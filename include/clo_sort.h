@@ -45,7 +45,18 @@ typedef struct clo_sort_impl_def {
 	size_t (*get_localmem_usage)(CloSort* sorter, cl_uint i, size_t lws_max, size_t numel, GError** err);
 } CloSortImplDef;
 
-/* clo_sort_abstract.in.h:116-170 */
+/* clo_sort_abstract.in.h:116-170.
+ * lws_max (every call that takes it): upstream caps the OpenCL work-group size it asks
+ * cf4ocl2 to suggest (sort/clo_sort_satradix.c:184-190, clo_sort_abitonic.c:340-349). The HIP
+ * kernels' shapes are fixed at compile time — a tile IS a work-group's registers and LDS —
+ * and are chosen by array size, not by the caller: the argument is accepted, recorded in the
+ * CLO_DEBUG trace and otherwise ignored in every sorter and in the scan; results never depend
+ * on it (upstream's do not either). clo_*_get_localmem_usage reports the LDS of the shape
+ * that `numel` selects.
+ * clo_sort_with_host_data: upstream's blocking path (copy in, sort, copy out). With
+ * CLO_SORT_HOST_PIPELINE=1 in the environment satradix on unsigned keys from 2^24 elements on
+ * overlaps the sort with both copies (same result bit for bit; less wall time on arrays of a
+ * GiB and more, about twice the device time: clo_sort_satradix.c). */
 CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
 	const char* compiler_opts, GError** err);

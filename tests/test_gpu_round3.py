@@ -287,3 +287,89 @@ def test_c_shard_ranks_fail_together(gpu, tmp_path, fail):
         assert aborted == 0 and text != "NO ERROR", text
         if r != fail[0]:
             assert ("rank %d" % fail[0]) in text and "no rank sorted" in text, text
+
+
+# ----------------------------------------------------------------------------
+# clo_sort_with_host_data with the transfers overlapped
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind,n", [("uint", (1 << 24) + 12345), ("ulong", 1 << 24), ("pairs", (1 << 24) + 7), ("uint", 1 << 25)])
+@pytest.mark.parametrize("two_queues", [False, True])
+def test_sort_host_data_pipelined_equals_blocking(gpu, monkeypatch, kind, n, two_queues):
+    """With CLO_SORT_HOST_PIPELINE=1 satradix's host-data path splits every chunk by the top 4 key bits
+    as it arrives and sorts / copies out bucket by bucket; the result is upstream's blocking path's
+    (sort/clo_sort_abstract.c:348-395) bit for bit, also for key/value pairs (stable)."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    rng = np.random.default_rng(n % 97)
+    if kind == "uint":
+        a = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+        a[: n // 7] &= np.uint32(0x0fffffff)                       # uneven buckets
+        s = clo.Sorter("satradix", ctx, "uint")
+    elif kind == "ulong":
+        a = rng.integers(0, np.iinfo(np.uint64).max, n, dtype=np.uint64, endpoint=True)
+        s = clo.Sorter("satradix", ctx, "ulong")
+    else:   # few distinct keys: equal keys must keep their input order
+        a = (rng.integers(0, 1000, n, dtype=np.uint64) << np.uint64(32 + 20)) | np.arange(n, dtype=np.uint64)
+        s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+    qx = clo.Queue(ctx, profiling=True)
+    qc = clo.Queue(ctx) if two_queues else None
+    ref = s.with_host_data(a, qx, qc)
+    monkeypatch.setenv("CLO_SORT_HOST_PIPELINE", "1")
+    got = s.with_host_data(a, qx, qc)
+    assert np.array_equal(got, ref)
+    if kind != "pairs":
+        assert np.array_equal(got, np.sort(a))
+    else:
+        assert np.array_equal(got, O.stable_sort(a, key_size=4, key_shift=32))
+    again = s.with_host_data(a[: (1 << 24) + 1], qx, qc)           # the cached buffers serve a smaller array too
+    assert np.array_equal(again, np.sort(a[: (1 << 24) + 1]) if kind != "pairs" else O.stable_sort(a[: (1 << 24) + 1], key_size=4, key_shift=32))
+    for x in (s, qx, qc):
+        if x is not None:
+            x.close()
+
+
+# ----------------------------------------------------------------------------
+# gselect with compare / get_key outside the ahead-of-time family: compiled at run time
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", [("uint", "uint", "((x) ^ 0x5a5a5a5au)", None, lambda a: a ^ np.uint32(0x5a5a5a5a)),
+                                  ("ulong", "uint", "(uint) (((x) >> 32) * 2654435761u)", None,
+                                   lambda a: ((a >> np.uint64(32)) * np.uint64(2654435761)).astype(np.uint32)),
+                                  ("int", "int", "(x)", "(((a) ^ 0x55) > ((b) ^ 0x55))", lambda a: a ^ np.int32(0x55))])
+def test_gselect_with_runtime_compiled_macros(gpu, case):
+    """Upstream pastes both macro bodies into its kernel (sort/clo_sort_gselect.cl:46-51) and builds
+    it; here the same kernel text is compiled with hiprtc. Position = number of elements that
+    compare before, ties (equal keys) by index: a stable sort by the order the macros define."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, kt, get_key, compare, model = case
+    dt = clo.api.CLO_TYPE_NP[et]
+    n = 5003
+    rng = np.random.default_rng(11)
+    if et == "ulong":
+        a = (rng.integers(0, 300, n, dtype=np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)   # ties: stability shows
+    else:
+        a = rng.integers(0, 1 << 20, n).astype(dt)
+    s = clo.Sorter("gselect", ctx, et, key_type=kt, get_key=get_key, compare=compare)
+    got = s.with_host_data(a, q)
+    s.close()
+    order = np.argsort(model(a), kind="stable")
+    assert np.array_equal(got, a[order])
+
+
+@pytest.mark.parametrize("key_bits", [28, 20, 12, 4])
+@pytest.mark.parametrize("logn", [16, 20, 22])
+def test_sweep_passes_with_an_empty_high_digit(gpu, key_bits, logn):
+    """A key width that is 4 modulo 8 makes the last single-sweep pass a one-digit pass (no second
+    local split): it must still look back at ALL its predecessors (round 2's kernel took the rows it
+    would have requested from inside the second split as 'valid, zero')."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    n = (1 << logn) + 321
+    a = O.bench_rand(key_bits + logn, "uint", n)
+    mask = (1 << key_bits) - 1
+    s = clo.Sorter("satradix", ctx, "uint", get_key="((x) & 0x%x)" % mask)
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, a[np.argsort(a & np.uint32(mask), kind="stable")])
