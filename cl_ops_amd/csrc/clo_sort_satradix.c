@@ -222,14 +222,15 @@ static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GEr
  * split by the top key bits followed by stable sorts of the buckets IS a stable sort.
  * For unsigned keys (whole elements or fields) of 4- and 8-byte elements from 2^24 elements on.
  *
- * OPT-IN (CLO_SORT_HOST_PIPELINE=1 in the environment): it buys wall time with device time.
- * Measured host to host (profiles/r03_hostsort_pipeline.txt), 2^28 uint32: 116.9 ms instead of
- * 124.4, uint64: 221.7 instead of 257.6; at 2^24 .. 2^26 the sixteen small sorts and the helper
- * thread cost more than the overlap returns. And the exec queue — what upstream's harness times
+ * It buys wall time with device time. Host to host (profiles/r03_hostsort_pipeline.txt; copy in +
+ * copy out alone in brackets): 2^24 uint32 3.4 ms instead of 4.7 (2.4), 2^28 uint32 39.3 instead of
+ * 41.1 (38.1), 2^28 uint64 78.1 instead of 86.2 (76.2) — 0.7 .. 1.9 ms beside the bare copies
+ * where the blocking path has 0.9 .. 10. But the exec queue — what upstream's harness times
  * (benchmarks/clo_sort_bench.c:201-207) — does a split pass plus sixteen sorts of a sixteenth of
  * the array instead of one sort: 1.9 ms of device time instead of 0.25 at 2^24 keys, about twice
- * the time at 2^28. The default therefore stays upstream's blocking path: a caller that times the
- * exec queue sees the sort it asked for.
+ * the time at 2^28. Hence the default: pipelined, UNLESS cq_exec was created with
+ * CL_QUEUE_PROFILING_ENABLE — a caller who profiles the exec queue is timing "the sort" and gets
+ * the one sort upstream would run. CLO_SORT_HOST_PIPELINE=0 / 1 in the environment overrides.
  * --------------------------------------------------------------------------- */
 #include <pthread.h>
 
@@ -300,7 +301,12 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 	const int key_kind = (ks->key_kind == 1 && ks->key_bits < 8 * ks->key_size) ? 0 : ks->key_kind;
 	*handled = 0;
 	if (clo_sort_get_jit(sorter) != NULL || key_kind != 0 || (es != 4 && es != 8) || ks->key_bits <= SAT_PIPE_BITS) return CL_FALSE;
-	if (numel < SAT_PIPE_MIN_NUMEL || numel > 0xffffffffull || getenv("CLO_SORT_HOST_PIPELINE") == NULL) return CL_FALSE;
+	if (numel < SAT_PIPE_MIN_NUMEL || numel > 0xffffffffull) return CL_FALSE;
+	{   /* default: on, unless the caller profiles the exec queue (see above); CLO_SORT_HOST_PIPELINE=0 / 1 decides for both */
+		const char* x = getenv("CLO_SORT_HOST_PIPELINE");
+		const int want = x ? atoi(x) != 0 : !ccl_queue_is_profiling(cq_exec);
+		if (!want) return CL_FALSE;
+	}
 	*handled = 1;
 
 	const int bits_in_digit = (int) clo_tzc((int) data->radix);

@@ -53,10 +53,10 @@ typedef struct clo_sort_impl_def {
  * CLO_DEBUG trace and otherwise ignored in every sorter and in the scan; results never depend
  * on it (upstream's do not either). clo_*_get_localmem_usage reports the LDS of the shape
  * that `numel` selects.
- * clo_sort_with_host_data: upstream's blocking path (copy in, sort, copy out). With
- * CLO_SORT_HOST_PIPELINE=1 in the environment satradix on unsigned keys from 2^24 elements on
- * overlaps the sort with both copies (same result bit for bit; less wall time on arrays of a
- * GiB and more, about twice the device time: clo_sort_satradix.c). */
+ * clo_sort_with_host_data: upstream's blocking path (copy in, sort, copy out), except that
+ * satradix on unsigned keys from 2^24 elements on overlaps the sort with both copies (same
+ * result bit for bit, 5-25 % less wall time, about twice the device time: clo_sort_satradix.c)
+ * unless cq_exec is a profiling queue; CLO_SORT_HOST_PIPELINE=0 / 1 decides for all queues. */
 CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
 	const char* compiler_opts, GError** err);

@@ -314,10 +314,15 @@ def test_sort_host_data_pipelined_equals_blocking(gpu, monkeypatch, kind, n, two
         s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
     qx = clo.Queue(ctx, profiling=True)
     qc = clo.Queue(ctx) if two_queues else None
+    monkeypatch.setenv("CLO_SORT_HOST_PIPELINE", "0")
     ref = s.with_host_data(a, qx, qc)
     monkeypatch.setenv("CLO_SORT_HOST_PIPELINE", "1")
     got = s.with_host_data(a, qx, qc)
     assert np.array_equal(got, ref)
+    monkeypatch.delenv("CLO_SORT_HOST_PIPELINE")                    # the default: pipelined on a queue without profiling
+    qn = clo.Queue(ctx)
+    assert np.array_equal(s.with_host_data(a, qn, qc), ref)
+    qn.close()
     if kind != "pairs":
         assert np.array_equal(got, np.sort(a))
     else:

@@ -2,9 +2,9 @@
 # Runs ON THE GPU BOX (through gpurun): bench lines, rocprofv3 kernel stats and the two
 # PMC passes for the HBM traffic of the headline workload. Raw output goes to
 # gpurun_out/$TAG/; tools/summarize_profiles.py turns it into the files under profiles/.
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r03'   (parts: 'benchonly', 'pmc', 'probes' as 2nd argument run a part)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -28,13 +28,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 unset CLO_RADIX_SWEEP
 echo "trace + pmc sweep done"
-for w in satradix_u32 satradix_pairs scan abitonic; do
+for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic; do
 	rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" --output-format csv -- \
 		python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_$w.json" 2> "$OUT/trace_$w.log" || exit 1
 	echo "trace $w done"
 done
 # HBM traffic (headline workload first): one counter per run, kernel trace only
-for w in satradix_u32 scan abitonic; do
+for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic; do
 	for c in FETCH_SIZE WRITE_SIZE; do
 		rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_$w" --output-format csv -- \
 			python3 "$ROOT/bench.py" --workload $w --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${c}_$w.json" 2> "$OUT/pmc_${c}_$w.log" || exit 1
@@ -50,6 +50,16 @@ B="$ROOT/benchmarks/bin"
 "$B/clo_hip_scan_bench" -t uint -y uint -n 27 -r 5 > "$OUT/harness_scan.txt" 2>&1 || exit 1
 echo "harness sweeps done"
 python3 "$ROOT/tools/sweep_sizes.py" > "$OUT/sweep_sizes.txt" 2>&1 || exit 1
-python3 "$ROOT/tools/sweep_probe.py" 28 u32 > "$OUT/sweep_probe_u32.txt" 2>&1 || exit 1
-python3 "$ROOT/tools/sweep_probe.py" 28 u64 > "$OUT/sweep_probe_u64.txt" 2>&1 || exit 1
-echo "sweep probes done"
+python3 "$ROOT/tools/sweep_sizes.py" big > "$OUT/sweep_sizes_big.txt" 2>&1 || exit 1
+python3 "$ROOT/tools/size_sweep.py" > "$OUT/size_sweep.txt" 2>&1 || exit 1
+python3 "$ROOT/tools/mid_probe.py" uint 22 28 > "$OUT/mid_probe.txt" 2>&1 || exit 1
+echo "size sweeps done"
+python3 "$ROOT/tools/skew_probe.py" 28 u32 > "$OUT/skew_probe.txt" 2>&1 || exit 1
+python3 "$ROOT/tools/skew_probe.py" 28 u64 > "$OUT/skew_probe_u64.txt" 2>&1 || exit 1
+echo "skew probes done"
+python3 "$ROOT/tools/hostsort_pipe_probe.py" 24 26 28 > "$OUT/hostsort_pipeline.txt" 2>&1 || exit 1
+echo "host pipeline probe done"
+# SQ counters of the kernels that ship (one --pmc pass per counter group, kernel trace only)
+bash "$ROOT/tools/pmc_busy.sh" "$TAG/sq_u32" satradix_u32 > /dev/null 2>&1 && cp "$ROOT/gpurun_out/$TAG/sq_u32/summary.txt" "$OUT/sq_counters_satradix_u32.txt"
+bash "$ROOT/tools/pmc_busy.sh" "$TAG/sq_u64" satradix_u64 > /dev/null 2>&1 && cp "$ROOT/gpurun_out/$TAG/sq_u64/summary.txt" "$OUT/sq_counters_satradix_u64.txt"
+echo "sq counters done"

@@ -47,6 +47,7 @@ for logn in [int(x) for x in sys.argv[1:]] or [24, 26, 28]:
             ok = lib.clo_sort_with_host_data(s.h, qx.h, qc.h, a.ctypes.data_as(vp), out.ctypes.data_as(vp), n, 0, err.ref)
             err.raise_if_set()
             assert ok
+        os.environ["CLO_SORT_HOST_PIPELINE"] = "0"
         t_block = best(run)
         os.environ["CLO_SORT_HOST_PIPELINE"] = "1"
         t_pipe = best(run)

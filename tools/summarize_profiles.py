@@ -20,8 +20,8 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
     line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
     open(os.path.join(dst, "%s_%s" % (tag, os.path.basename(f))), "w").write(line + "\n")
 
-names = {"satradix_u32": "satradix_u32_2p28", "satradix_pairs": "satradix_pairs", "scan": "scan", "abitonic": "abitonic",
-         "satradix_u32_sweep": "satradix_u32_2p28_sweep"}
+names = {"satradix_u32": "satradix_u32_2p28", "satradix_pairs": "satradix_pairs", "satradix_u64": "satradix_u64", "scan": "scan",
+         "abitonic": "abitonic", "satradix_u32_sweep": "satradix_u32_2p28_sweep"}
 for w, out in names.items():
     st = glob.glob(os.path.join(src, "trace_" + w, "*", "*kernel_stats.csv"))
     if st:
@@ -127,6 +127,35 @@ for extra in ("sweep_sizes.txt", "sweep_probe_u32.txt", "sweep_probe_u64.txt"):
 print("profiles/ refreshed from", src)
 for r in rows[:6]:
     print(r)
+
+# ---- the 8-byte satradix workloads: key/value pairs (config 4) and uint64 keys (config 5's shard) ----
+for workload in ("satradix_pairs", "satradix_u64"):
+    try:
+        rows8 = traffic_rows(workload)
+    except ValueError:
+        continue
+    path8 = os.path.join(dst, "%s_%s_pmc_hbm_traffic.csv" % (tag, workload))
+    with open(path8, "w") as o:
+        o.write(HEADER % (workload, "(Same x2 as calibrated on the histogram kernel of the uint32 run.)"))
+        for r in rows8:
+            o.write("%s,%d,%.0f,%.0f,%d\n" % r)
+    pas8 = [r for r in rows8 if "pair_kernel" in r[0]]
+    if pas8:
+        d8 = max(pas8, key=lambda r: r[1])
+        json.dump({"kernel": d8[0], "hbm_bytes_per_launch": d8[4], "fetch_size_kb": d8[2], "write_size_kb": d8[3],
+                   "log2n": 28, "families": families(rows8, None),
+                   "correction": "FETCH_SIZE x2 (gfx950; calibrated on the histogram kernel of the uint32 run), WRITE_SIZE as is",
+                   "source": "profiles/" + os.path.basename(path8)},
+                  open(os.path.join(dst, "traffic_%s.json" % workload), "w"), indent=1)
+    for r in rows8[:4]:
+        print(workload, r)
+
+# ---- SQ counters of the kernels that ship (tools/pmc_busy.sh) and the other probes of the collection ----
+for extra in ("sq_counters_satradix_u32.txt", "sq_counters_satradix_u64.txt", "skew_probe.txt", "skew_probe_u64.txt",
+              "hostsort_pipeline.txt", "size_sweep.txt", "sweep_sizes_big.txt", "mid_probe.txt"):
+    f = os.path.join(src, extra)
+    if os.path.exists(f):
+        open(os.path.join(dst, "%s_%s" % (tag, extra)), "w").write("".join(l for l in open(f) if "amdgpu.ids" not in l))
 
 # ---- scan and abitonic: the dominant kernel of each ----
 for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_merge_kernel")):
