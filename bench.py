@@ -395,6 +395,10 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     be.fence()
     wall = time.perf_counter() - t0
     t_max = be.max_over_ranks(wall)
+    if hasattr(sharded, "check"):
+        sharded.check()          # (outside the timed region) did a local sort give up a look-back spin? raises if so
+    elif hasattr(sharded.ops, "check"):
+        sharded.ops.check()
 
     # ---- phases: K more steps with device events around each phase (outside the timed region) ----
     sharded.phase_times = {}

@@ -111,7 +111,22 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		if (tid < (unsigned) R2) s_delta[tid] = goff - (incl2 - h2);
 	}
 
-	pc_local_split<E, LB, THREADS, ITEMS, HMAX, pc_no_mid, pc_no_counted, ALIAS>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
+	// Keys that repeat. A tile whose elements all carry ONE combined digit (its histogram row says so: a
+	// constant byte of the key — small keys, a shared prefix, equal keys) is in order already, and splitting
+	// it is the worst case of the split: every lane writes its 16 consecutive positions of the stage, a stride
+	// of 64 bytes, 16 lanes to a bank (2^28 equal uint32 keys sorted in 3.5 ms against 2.7 for uniform ones,
+	// every pass with a constant digit +0.2 ms: profiles/r03_skew_probe.txt). Such a tile goes to the stage as
+	// it stands — 16-byte LDS stores — and straight to the scatter.
+	__shared__ unsigned s_one[4];
+	if (wave < 4) {
+		const unsigned long long hit = __ballot(tid < (unsigned) R2 && h2 == count);
+		if (lane == 0) s_one[wave] = hit != 0ull;
+	}
+	clo_lds_barrier();
+	const bool single = (s_one[0] | s_one[1] | s_one[2] | s_one[3]) != 0u;   // (the same for the whole work-group)
+
+	if (!single)
+		pc_local_split<E, LB, THREADS, ITEMS, HMAX, pc_no_mid, pc_no_counted, ALIAS>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
 
 	if (tid < (unsigned) R2) {
 		unsigned before = 0;   // counts of the lower combined digits in the earlier waves' share of the histogram row
@@ -119,7 +134,23 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		for (unsigned w = 0; w < 4; ++w) if (w < wave) before += s_w4[w];
 		s_delta[tid] -= before;
 	}
-	if (mask_hi != 0) {
+	if (single) {
+		if (full) {
+			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
+			typedef E vec16 __attribute__((ext_vector_type(PER)));
+			#pragma unroll
+			for (int k = 0; k < ITEMS / PER; ++k) {
+				vec16 t;
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) t[q] = key[k * PER + q];
+				*reinterpret_cast<vec16*>(&s_stage[tbase + k * PER]) = t;
+			}
+		} else {
+			#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) s_stage[tbase + i] = key[i];
+		}
+		__syncthreads();
+	} else if (mask_hi != 0) {
 		if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)
 			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
 			typedef E vec16 __attribute__((ext_vector_type(PER)));

@@ -292,6 +292,72 @@ void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 	}
 }
 
+// The chunk scan folded into the offsets kernel (round 3): every work-group turns the raw chunk SUMS into
+// its own chunk's starting offsets itself — the rows of all chunks (<= RW_CS_REGS per thread: up to 128
+// chunks with R = 256) are requested together with its own tiles' rows, so the launch still costs one round
+// trip, and the one-work-group chunk-scan launch between the two (5 us of launch + latency per pass, 20 us of
+// a 250 us sort at 2^24 keys) is gone. 128 work-groups x 128 KiB of chunk sums come out of L2.
+template <int R>
+__global__ __launch_bounds__(RW_CS_THREADS)
+void clo_radixw_offsets2_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned chunks,
+	const unsigned* __restrict__ csum, unsigned* __restrict__ toff) {
+	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
+	__shared__ unsigned s_a[G * R], s_c[G * R], s_b[G * R], s_base[R], s_w[4];
+	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
+	const unsigned t0 = blockIdx.x * RW_CHUNK;
+	const unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
+	const bool active = g < (unsigned) G;
+	const unsigned per = (chunks + G - 1) / G;   // chunks per thread group (<= RW_CS_REGS: the launcher checks)
+	const unsigned c0 = g * per < chunks ? g * per : chunks, c1 = c0 + per < chunks ? c0 + per : chunks;
+	unsigned v[SUB], w[RW_CS_REGS];
+	if (active) {
+		#pragma unroll
+		for (int k = 0; k < SUB; ++k) {
+			const unsigned t = t0 + g * SUB + k;
+			v[k] = t < tend ? thist[(size_t) t * R + d] : 0u;
+		}
+		#pragma unroll
+		for (int k = 0; k < RW_CS_REGS; ++k) w[k] = c0 + k < c1 ? csum[(size_t) (c0 + k) * R + d] : 0u;
+		unsigned own = 0, all = 0, before = 0;
+		#pragma unroll
+		for (int k = 0; k < SUB; ++k) own += v[k];
+		#pragma unroll
+		for (int k = 0; k < RW_CS_REGS; ++k) {
+			all += w[k];
+			if (c0 + k < blockIdx.x) before += w[k];   // (chunks in front of this work-group's own)
+		}
+		s_a[g * R + d] = own;
+		s_c[g * R + d] = all;
+		s_b[g * R + d] = before;
+	}
+	__syncthreads();
+	unsigned tot = 0, bef = 0;
+	if (tid < (unsigned) R) {
+		#pragma unroll 4
+		for (int k = 0; k < G; ++k) { tot += s_c[k * R + tid]; bef += s_b[k * R + tid]; }
+	}
+	// exclusive scan of the digit totals over the digits (threads 0..R-1 carry them)
+	const unsigned incl = clo_wave_scan_inclusive<unsigned>(tot, lane);
+	if (lane == 63 && wave < 4) s_w[wave] = incl;
+	__syncthreads();
+	if (tid < (unsigned) R) {
+		unsigned dbase = incl - tot;
+		#pragma unroll
+		for (unsigned x = 0; x < 4; ++x) if (x < wave) dbase += s_w[x];
+		s_base[tid] = dbase + bef;
+	}
+	__syncthreads();
+	if (!active) return;
+	unsigned run = s_base[d];
+	for (unsigned k = 0; k < g; ++k) run += s_a[k * R + d];
+	#pragma unroll
+	for (int k = 0; k < SUB; ++k) {
+		const unsigned t = t0 + g * SUB + k;
+		if (t < tend) toff[(size_t) t * R + d] = run;
+		run += v[k];
+	}
+}
+
 // Up to RW_CHUNK tiles (one chunk): the three steps above in one launch of one
 // work-group — arrays of 2^13 .. 2^20 elements are launch-bound.
 template <int R>
@@ -399,6 +465,21 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 		return (int) hipGetLastError();
 	}
 	#undef CLO_RW_OFF1
+	// two launches (the chunk scan folded into the offsets kernel) while a thread group holds its share of the chunk sums
+	// in registers; CLO_RADIX_OFFSETS3=1: always the three launches (A/B runs; read per call)
+	#define CLO_RW_OFF2(B) case B: \
+		if ((chunks + rw_cs<(1 << B)>::G - 1) / rw_cs<(1 << B)>::G > (unsigned) RW_CS_REGS) { two = false; break; } \
+		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, partial); \
+		hipLaunchKernelGGL((clo_radixw_offsets2_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, chunks, (const unsigned*) partial, toff); break
+	bool two = getenv("CLO_RADIX_OFFSETS3") == nullptr;
+	if (two) {
+		switch (bits) {
+			CLO_RW_OFF2(1); CLO_RW_OFF2(2); CLO_RW_OFF2(3); CLO_RW_OFF2(4); CLO_RW_OFF2(5); CLO_RW_OFF2(6); CLO_RW_OFF2(7); CLO_RW_OFF2(8);
+			default: return CLO_HIP_EUNSUPPORTED;
+		}
+		if (two) return (int) hipGetLastError();
+	}
+	#undef CLO_RW_OFF2
 	#define CLO_RW_OFF(B) case B: \
 		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, partial); \
 		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(RW_CS_THREADS), 0, s, partial, chunks); \

@@ -96,6 +96,13 @@ class HipLocalOps:
         finally:
             buf.close()
 
+    def check(self):
+        """Synchronises the streams this object has sorted on and raises CloError(CLO_ERROR_LIBRARY) if a kernel of
+        a local sort gave up a bounded look-back spin (small buckets take the single-sweep passes): a caller that only
+        ever synchronises through torch would not find out."""
+        for q in self._queues.values():
+            q.finish()
+
     def close(self):
         self.sorter.close()
         for q in self._queues.values():
@@ -445,6 +452,13 @@ class CShardedSorter:
 
     def collect_phase_times(self):
         return dict(self.phase_times or {})
+
+    def check(self):
+        """ccl_queue_finish on the queues this object has sorted on: synchronises and raises CloError(CLO_ERROR_LIBRARY)
+        if a kernel of a local sort gave up a bounded look-back spin (a caller that only synchronises through torch
+        would not find out)."""
+        for q in self._queues.values():
+            q.finish()
 
     def close(self):
         self.ss.close()
