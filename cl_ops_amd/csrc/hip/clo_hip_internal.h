@@ -82,10 +82,11 @@ int clo_bitonic_tiled_e2(void* data, size_t numel, int key_shift, int key_bits, 
 int clo_bitonic_tiled_e4(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
 int clo_bitonic_tiled_e8(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
 size_t clo_radixw_lds_bytes(int digit_bits);
+// tinfo: one word per tile, 1 = one bin holds the whole tile (read by the pass kernel)
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
-	unsigned* thist, unsigned tiles, bool big, clo_keyx kx, hipStream_t s);
+	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, clo_keyx kx, hipStream_t s);
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
-	unsigned* thist, unsigned tiles, bool big, hipStream_t s);
+	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, hipStream_t s);
 int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff, hipStream_t s);
 
 typedef unsigned long long clo_u64;

@@ -55,7 +55,7 @@ template <typename E, int LB, int HB, bool BIG, bool DIG = false>
 __global__ __launch_bounds__((pair_shape<E, BIG>::THREADS), (pair_shape<E, BIG>::THREADS >= 1024 ? 8 : 6))   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (59 used); BIG: 2 x 16 waves, <= 64
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
-	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, int aligned,
+	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, const unsigned* __restrict__ tinfo, int aligned,
 	clo_keyx kx_in, clo_keyx kx_out, unsigned char* __restrict__ dig_out = nullptr, unsigned next_shift = 0) {
 
 	constexpr int THREADS = pair_shape<E, BIG>::THREADS;
@@ -111,30 +111,17 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		if (tid < (unsigned) R2) s_delta[tid] = goff - (incl2 - h2);
 	}
 
-	// Keys that repeat. A tile whose elements all carry ONE combined digit (its histogram row says so: a
-	// constant byte of the key — small keys, a shared prefix, equal keys) is in order already, and splitting
-	// it is the worst case of the split: every lane writes its 16 consecutive positions of the stage, a stride
-	// of 64 bytes, 16 lanes to a bank (2^28 equal uint32 keys sorted in 3.5 ms against 2.7 for uniform ones,
-	// every pass with a constant digit +0.2 ms: profiles/r03_skew_probe.txt). Such a tile goes to the stage as
-	// it stands — 16-byte LDS stores — and straight to the scatter.
-	__shared__ unsigned s_one[4];
-	if (wave < 4) {
-		const unsigned long long hit = __ballot(tid < (unsigned) R2 && h2 == count);
-		if (lane == 0) s_one[wave] = hit != 0ull;
-	}
-	clo_lds_barrier();
-	const bool single = (s_one[0] | s_one[1] | s_one[2] | s_one[3]) != 0u;   // (the same for the whole work-group)
+	// Keys that repeat. A tile whose elements all carry ONE combined digit (the histogram kernel has seen
+	// it: a constant byte of the key — small keys, a shared prefix, equal keys) is in order already, and
+	// splitting it is the worst case of the split: every lane writes its 16 consecutive positions of the stage,
+	// a stride of 64 bytes, 16 lanes to a bank (2^28 equal uint32 keys sorted in 3.5 ms against 2.7 for
+	// uniform ones, every pass with a constant digit +0.2 ms; now 2.2 ms: profiles/r03_skew_probe.txt).
+	// Such a tile goes to the stage as it stands — 16-byte LDS stores — and straight to the scatter.
+	const bool single = tinfo[tile] != 0u;   // (one scalar load; the same for the whole work-group)
 
-	if (!single)
+	if (!single) {
 		pc_local_split<E, LB, THREADS, ITEMS, HMAX, pc_no_mid, pc_no_counted, ALIAS>(key, shift, mask_lo, count, s_stage, s_end, s_wtot, s_wbase);
-
-	if (tid < (unsigned) R2) {
-		unsigned before = 0;   // counts of the lower combined digits in the earlier waves' share of the histogram row
-		#pragma unroll
-		for (unsigned w = 0; w < 4; ++w) if (w < wave) before += s_w4[w];
-		s_delta[tid] -= before;
-	}
-	if (single) {
+	} else {
 		if (full) {
 			constexpr int PER = ITEMS * (int) sizeof(E) >= 16 ? 16 / (int) sizeof(E) : ITEMS;
 			typedef E vec16 __attribute__((ext_vector_type(PER)));
@@ -149,6 +136,16 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 			#pragma unroll
 			for (int i = 0; i < ITEMS; ++i) if (tbase + i < count) s_stage[tbase + i] = key[i];
 		}
+		clo_lds_barrier();   // (the wave sums of the histogram row, s_w4, are in: a split has barriers of its own)
+	}
+
+	if (tid < (unsigned) R2) {
+		unsigned before = 0;   // counts of the lower combined digits in the earlier waves' share of the histogram row
+		#pragma unroll
+		for (unsigned w = 0; w < 4; ++w) if (w < wave) before += s_w4[w];
+		s_delta[tid] -= before;
+	}
+	if (single) {
 		__syncthreads();
 	} else if (mask_hi != 0) {
 		if (full) {   // 16-byte LDS reads (scalar reads at this lane stride would conflict 8-way)
@@ -280,7 +277,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 // Per pass: histogram of the combined digit -> counter scan -> pass kernel.
 // A requested digit width b <= 4 pairs two digits (LB = HB = b); a wider digit
 // is one pass, split in two halves.
-struct rp_layout { size_t thist, toff, partial, dig, total, tiles; };   // dig: 0 = no digit stream
+struct rp_layout { size_t thist, toff, partial, tinfo, dig, total, tiles; };   // dig: 0 = no digit stream; tinfo: one word per tile
 
 // (tiles of the shape clo_radix_big_tiles picks for n; `digits`: room for the digit stream
 // of a multi-pass sort, n bytes, where clo_radix_digit_stream says so)
@@ -294,7 +291,8 @@ rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits, bool digits = t
 	L.thist = CLO_WS_HEADER_BYTES;
 	L.toff = L.thist + per;
 	L.partial = L.toff + per;
-	L.total = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
+	L.tinfo = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
+	L.total = L.tinfo + ((L.tiles * sizeof(unsigned) + 255) & ~(size_t) 255);
 	L.dig = 0;
 	if (digits && clo_radix_digit_stream(n, elem_size)) {
 		L.dig = L.total;
@@ -311,6 +309,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
 	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
+	unsigned* tinfo = (unsigned*) ((char*) ws + L.tinfo);
 	const unsigned tiles = (unsigned) L.tiles;
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
 	const bool no_dig = getenv("CLO_RADIX_NO_DIGITS") != nullptr;   // (A/B runs and tests: read at every call)
@@ -337,9 +336,9 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			clo_timing_scope timing("radix_hist", s);
 			// (from the second pass on: out of the digit bytes the pass before left behind)
 			const int st = (dig && p > 0)
-				? clo_radixw_launch_tilehist_bytes(dig, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tiles, big, s)
+				? clo_radixw_launch_tilehist_bytes(dig, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, tiles, big, s)
 				: clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
-					thist, tiles, big, p == 0 ? kx : kx_none, s);
+					thist, tinfo, tiles, big, p == 0 ? kx : kx_none, s);
 			if (st != 0) return st;
 		}
 		{
@@ -357,20 +356,20 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 					if constexpr (DIG_OK) {
 						if (dig && p + 1 < passes) {
 							hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-								cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout,
+								cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo, aligned, kin, kout,
 								dig, (unsigned) (key_shift + (p + 1) * PB));
 							done = true;
 						}
 					}
 					if (!done)
 						hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout, nullptr, 0u);
+							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo, aligned, kin, kout, nullptr, 0u);
 					cur_in = cur_out;
 					continue;
 				}
 			}
 			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
-				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, aligned, kin, kout, nullptr, 0u);
+				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo, aligned, kin, kout, nullptr, 0u);
 		}
 		cur_in = cur_out;
 	}
@@ -435,6 +434,7 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
 	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
 	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
+	unsigned* tinfo = (unsigned*) ((char*) ws + L.tinfo);
 	const unsigned tiles = (unsigned) L.tiles;
 	const clo_keyx kx_none = { 0, 0, 0 };
 	hipError_t e = hipMemsetAsync(ws, 0, CLO_WS_HEADER_BYTES, s);   // (clo_hip_check_status may be asked about this workspace)
@@ -442,7 +442,7 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	clo_timing_scope timing("msd_partition", s);
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
 	const unsigned mask_lo = TWO ? (1u << LB) - 1u : R - 1u, mask_hi = TWO ? (1u << HB) - 1u : 0u;
-	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tiles, big, kx_none, s);
+	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tinfo, tiles, big, kx_none, s);
 	if (st != 0) return st;
 	if (counts)
 		hipLaunchKernelGGL((clo_radix4_counts_kernel<R, (1 << PB)>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);
@@ -450,11 +450,11 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	if (st != 0) return st;
 	if (big)
 		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
+			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	else
 		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
-			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff,
+			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	return (int) hipGetLastError();
 }

@@ -28,13 +28,26 @@ template <typename E, bool BIG> struct rw_shape {
 	static constexpr int ITEMS = TILE / THREADS;
 };
 
+// One word per tile beside its histogram row: 1 when ONE bin holds the whole tile (every element of the
+// tile carries the same digit: small keys, a shared prefix, equal keys). The pass kernel reads it with a
+// scalar load and sends such a tile past its two local splits (clo_hip_radix4.hip: the split of a
+// single-digit tile is its worst case). Decided here because the counts are here: in the pass kernel the
+// row sits with 256 threads and asking them costs a barrier per tile (+3 % on uniform keys, measured).
+// No thread needs to know more than its own bin: a bin that holds the whole tile says 1, a bin that holds a
+// part of it says 0 (several may, all the same value), an empty bin says nothing — exactly one of the first
+// two kinds exists in every tile, so the word is always written and never needs clearing or a barrier.
+__device__ __forceinline__ void rw_tile_info(unsigned h, unsigned count, unsigned* __restrict__ tinfo) {
+	if (h == count) tinfo[blockIdx.x] = 1u;
+	else if (h != 0u) tinfo[blockIdx.x] = 0u;
+}
+
 // ---------------------------------------------------------------------------
 // per-tile digit histogram (upstream's satradix_histogram job)
 // ---------------------------------------------------------------------------
 template <typename E, int BITS, bool BIG>
 __global__ __launch_bounds__((rw_shape<E, BIG>::THREADS))
 void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
-	unsigned* __restrict__ thist, int aligned, clo_keyx kx) {
+	unsigned* __restrict__ thist, unsigned* __restrict__ tinfo, int aligned, clo_keyx kx) {
 	constexpr int R = 1 << BITS;
 	constexpr int ITEMS = rw_shape<E, BIG>::ITEMS;
 	constexpr int TILE = rw_shape<E, BIG>::TILE;
@@ -88,6 +101,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 			h += x[0] + x[1] + x[2] + x[3];
 		}
 		thist[(size_t) blockIdx.x * R + d] = h;
+		rw_tile_info(h, count, tinfo);
 	}
 }
 
@@ -96,7 +110,8 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 // (uint32) or an eighth (8-byte elements) of the bytes to read.
 template <int BITS, int ITEMS, int THREADS>   // ITEMS bytes per thread: 16 (4-byte elements) or 8; THREADS of the tile's shape
 __global__ __launch_bounds__(THREADS)
-void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist) {
+void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist,
+	unsigned* __restrict__ tinfo) {
 	constexpr int R = 1 << BITS;
 	constexpr int TILE = THREADS * ITEMS;
 	constexpr int COPIES = 32;
@@ -137,6 +152,7 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 			h += x[0] + x[1] + x[2] + x[3];
 		}
 		thist[(size_t) blockIdx.x * R + d] = h;
+		rw_tile_info(h, count, tinfo);
 	}
 }
 
@@ -154,7 +170,14 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 // launches, a quarter of a 2^24-key sort). Round 3: 1024 threads = G groups of R
 // threads, group g owns SUB = RW_CHUNK / G consecutive rows of the chunk and requests
 // ALL of them at once (SUB registers, fully unrolled); the groups meet in LDS. One
-// round trip per kernel instead of SUB.
+// round trip per kernel instead of SUB: 15 / 19 us per pass at 2^24 / 2^28 keys. What is
+// left is three launches' worth of launch + one round trip each. Tried and dropped
+// (profiles/r03_hist_chain_probe.txt): the first two steps chained onto the
+// histogram kernel (write-through rows, arrival counters, the last arrival sums: the
+// histogram kernel, bound by its loads in flight, lost 0.07 ms per pass to the arrivals);
+// the chunk scan folded into the offsets kernel, every work-group re-deriving its chunk's
+// start from all chunk sums (25.7 instead of 19.3 us at 2^28, 19.3 instead of 15.1 at 2^24:
+// 128 KiB of L2 reads per work-group cost more than the launch they replace).
 // ---------------------------------------------------------------------------
 constexpr int RW_CS_THREADS = 1024;
 template <int R> struct rw_cs {
@@ -292,72 +315,6 @@ void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 	}
 }
 
-// The chunk scan folded into the offsets kernel (round 3): every work-group turns the raw chunk SUMS into
-// its own chunk's starting offsets itself — the rows of all chunks (<= RW_CS_REGS per thread: up to 128
-// chunks with R = 256) are requested together with its own tiles' rows, so the launch still costs one round
-// trip, and the one-work-group chunk-scan launch between the two (5 us of launch + latency per pass, 20 us of
-// a 250 us sort at 2^24 keys) is gone. 128 work-groups x 128 KiB of chunk sums come out of L2.
-template <int R>
-__global__ __launch_bounds__(RW_CS_THREADS)
-void clo_radixw_offsets2_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned chunks,
-	const unsigned* __restrict__ csum, unsigned* __restrict__ toff) {
-	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
-	__shared__ unsigned s_a[G * R], s_c[G * R], s_b[G * R], s_base[R], s_w[4];
-	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
-	const unsigned t0 = blockIdx.x * RW_CHUNK;
-	const unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
-	const bool active = g < (unsigned) G;
-	const unsigned per = (chunks + G - 1) / G;   // chunks per thread group (<= RW_CS_REGS: the launcher checks)
-	const unsigned c0 = g * per < chunks ? g * per : chunks, c1 = c0 + per < chunks ? c0 + per : chunks;
-	unsigned v[SUB], w[RW_CS_REGS];
-	if (active) {
-		#pragma unroll
-		for (int k = 0; k < SUB; ++k) {
-			const unsigned t = t0 + g * SUB + k;
-			v[k] = t < tend ? thist[(size_t) t * R + d] : 0u;
-		}
-		#pragma unroll
-		for (int k = 0; k < RW_CS_REGS; ++k) w[k] = c0 + k < c1 ? csum[(size_t) (c0 + k) * R + d] : 0u;
-		unsigned own = 0, all = 0, before = 0;
-		#pragma unroll
-		for (int k = 0; k < SUB; ++k) own += v[k];
-		#pragma unroll
-		for (int k = 0; k < RW_CS_REGS; ++k) {
-			all += w[k];
-			if (c0 + k < blockIdx.x) before += w[k];   // (chunks in front of this work-group's own)
-		}
-		s_a[g * R + d] = own;
-		s_c[g * R + d] = all;
-		s_b[g * R + d] = before;
-	}
-	__syncthreads();
-	unsigned tot = 0, bef = 0;
-	if (tid < (unsigned) R) {
-		#pragma unroll 4
-		for (int k = 0; k < G; ++k) { tot += s_c[k * R + tid]; bef += s_b[k * R + tid]; }
-	}
-	// exclusive scan of the digit totals over the digits (threads 0..R-1 carry them)
-	const unsigned incl = clo_wave_scan_inclusive<unsigned>(tot, lane);
-	if (lane == 63 && wave < 4) s_w[wave] = incl;
-	__syncthreads();
-	if (tid < (unsigned) R) {
-		unsigned dbase = incl - tot;
-		#pragma unroll
-		for (unsigned x = 0; x < 4; ++x) if (x < wave) dbase += s_w[x];
-		s_base[tid] = dbase + bef;
-	}
-	__syncthreads();
-	if (!active) return;
-	unsigned run = s_base[d];
-	for (unsigned k = 0; k < g; ++k) run += s_a[k * R + d];
-	#pragma unroll
-	for (int k = 0; k < SUB; ++k) {
-		const unsigned t = t0 + g * SUB + k;
-		if (t < tend) toff[(size_t) t * R + d] = run;
-		run += v[k];
-	}
-}
-
 // Up to RW_CHUNK tiles (one chunk): the three steps above in one launch of one
 // work-group — arrays of 2^13 .. 2^20 elements are launch-bound.
 template <int R>
@@ -407,14 +364,14 @@ void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned til
 // the digit-pair passes of clo_hip_radix4.hip) ----
 
 template <typename E>
-static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift, unsigned mask, unsigned* thist,
+static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift, unsigned mask, unsigned* thist, unsigned* tinfo,
 	unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
 	const int aligned = (int) ((uintptr_t) in % 16 == 0);
 	#define CLO_RW_TH(B) case B: \
 		if (big && sizeof(E) >= 4) hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B, (sizeof(E) >= 4)>), dim3(tiles), dim3(rw_shape<E, (sizeof(E) >= 4)>::THREADS), 0, s, \
-			(const E*) in, n, shift, mask, thist, aligned, kx); \
+			(const E*) in, n, shift, mask, thist, tinfo, aligned, kx); \
 		else hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B, false>), dim3(tiles), dim3(rw_shape<E, false>::THREADS), 0, s, \
-			(const E*) in, n, shift, mask, thist, aligned, kx); \
+			(const E*) in, n, shift, mask, thist, tinfo, aligned, kx); \
 		break
 	switch (bits) {
 		CLO_RW_TH(1); CLO_RW_TH(2); CLO_RW_TH(3); CLO_RW_TH(4); CLO_RW_TH(5); CLO_RW_TH(6); CLO_RW_TH(7); CLO_RW_TH(8);
@@ -426,20 +383,20 @@ static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift
 
 // `big`: the tiles are those of clo_radix_big_tiles(n, elem_size) (clo_hip_radix_rank.h)
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
-	unsigned* thist, unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
+	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
 	switch (elem_size) {
-		case 1: return rw_launch_tilehist<uint8_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
-		case 2: return rw_launch_tilehist<uint16_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
-		case 4: return rw_launch_tilehist<uint32_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
-		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tiles, big, kx, s);
+		case 1: return rw_launch_tilehist<uint8_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
+		case 2: return rw_launch_tilehist<uint16_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
+		case 4: return rw_launch_tilehist<uint32_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
+		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }
 
 // Histograms out of the digit stream (tiles of the shape `big` names).
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
-	unsigned* thist, unsigned tiles, bool big, hipStream_t s) {
-	#define CLO_RW_THB1(B, I, T) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T>), dim3(tiles), dim3(T), 0, s, dig, n, mask, thist)
+	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, hipStream_t s) {
+	#define CLO_RW_THB1(B, I, T) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T>), dim3(tiles), dim3(T), 0, s, dig, n, mask, thist, tinfo)
 	#define CLO_RW_THB(B) case B: \
 		if (!big) return CLO_HIP_EUNSUPPORTED;   /* (the stream goes with the big tiles) */ \
 		if (elem_size == 8) CLO_RW_THB1(B, 8, 1024); else CLO_RW_THB1(B, 16, 1024); \
@@ -465,21 +422,6 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 		return (int) hipGetLastError();
 	}
 	#undef CLO_RW_OFF1
-	// two launches (the chunk scan folded into the offsets kernel) while a thread group holds its share of the chunk sums
-	// in registers; CLO_RADIX_OFFSETS3=1: always the three launches (A/B runs; read per call)
-	#define CLO_RW_OFF2(B) case B: \
-		if ((chunks + rw_cs<(1 << B)>::G - 1) / rw_cs<(1 << B)>::G > (unsigned) RW_CS_REGS) { two = false; break; } \
-		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, partial); \
-		hipLaunchKernelGGL((clo_radixw_offsets2_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, chunks, (const unsigned*) partial, toff); break
-	bool two = getenv("CLO_RADIX_OFFSETS3") == nullptr;
-	if (two) {
-		switch (bits) {
-			CLO_RW_OFF2(1); CLO_RW_OFF2(2); CLO_RW_OFF2(3); CLO_RW_OFF2(4); CLO_RW_OFF2(5); CLO_RW_OFF2(6); CLO_RW_OFF2(7); CLO_RW_OFF2(8);
-			default: return CLO_HIP_EUNSUPPORTED;
-		}
-		if (two) return (int) hipGetLastError();
-	}
-	#undef CLO_RW_OFF2
 	#define CLO_RW_OFF(B) case B: \
 		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, partial); \
 		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(RW_CS_THREADS), 0, s, partial, chunks); \
