@@ -162,11 +162,16 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
  * out are issued by a helper thread; pinning the caller's memory instead
  * costs ~10 ms per GiB, more than the overlap gains.                     */
 /* ------------------------------------------------------------------ */
-#define CLO_SCAN_PIPE_MIN_NUMEL ((size_t) 1 << 24)   /* below this one copy in, one scan, one copy out */
+#define CLO_SCAN_PIPE_MIN_NUMEL ((size_t) 1 << 25)   /* below this one copy in, one scan, one copy out */
 #define CLO_SCAN_PIPE_CHUNK_MAX ((size_t) 1 << 24)
 
-/* Chunks of the pipeline: 2 up to 2^25 elements, 4 up to 2^27, then chunks of
- * 2^24. Every chunk scan starts on an idle stream (it waits for its copy), which
+/* Chunks of the pipeline: chunks of 2^24 elements (the last one shorter), from 2^25
+ * elements on. Never smaller (round 3): a chunk below 2^24 elements is scanned by the
+ * small work-group shape (clo_hip_scan.hip) at two thirds of the rate, and with the halves
+ * and quarters of rounds 1-2 the harness's table fell from 293 GValues/s at 2^23 elements
+ * to 253 at 2^24 and 266 at 2^25 before jumping to 428 at 2^26
+ * (profiles/r03_harness_sweep_scan.txt, first collection).
+ * Every chunk scan starts on an idle stream (it waits for its copy), which
  * costs ~20 us of launch latency inside its event pair whatever its size, and the
  * reference harness prints the SUM of those event times (benchmarks/
  * clo_scan_bench.c:240-278): with the 2^22-element chunks of round 1 the printed
@@ -178,10 +183,8 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
 static size_t scan_pipe_chunk(size_t numel) {
 	const char* x = getenv("CLO_SCAN_PIPE_CHUNK_LOG2");   /* (A/B measurements only) */
 	if (x && atoi(x) >= 16 && atoi(x) <= 28) return (size_t) 1 << atoi(x);
-	const size_t parts = numel < ((size_t) 1 << 25) ? 2 : 4;
-	size_t c = (numel + parts - 1) / parts;
-	c = (c + 4095) & ~(size_t) 4095;   /* whole 16-KiB blocks: every chunk starts 16-byte aligned */
-	return c < CLO_SCAN_PIPE_CHUNK_MAX ? c : CLO_SCAN_PIPE_CHUNK_MAX;
+	(void) numel;
+	return CLO_SCAN_PIPE_CHUNK_MAX;   /* (a multiple of 16-KiB blocks: every chunk starts 16-byte aligned) */
 }
 
 static void scan_pipe_res_free(scan_pipe_res* r) {

@@ -88,7 +88,7 @@ def test_scan_in_chunks_with_device_carry_and_reduce(gpu, types):
 
 
 @pytest.mark.parametrize("types", [("uint", "uint"), ("uint", "ulong")])
-@pytest.mark.parametrize("n", [1 << 24, (1 << 24) + (1 << 23) + 12345])
+@pytest.mark.parametrize("n", [1 << 25, (1 << 25) + (1 << 23) + 12345])     # (the pipeline starts at 2^25: chunks of 2^24, a short last one)
 def test_scan_host_data_pipelined_chunks(gpu, n, types):
     """numel >= 2 chunks: clo_scan_with_host_data goes through the chunked
     copy-in / scan / copy-out pipeline (helper thread for the copies out)."""
