@@ -375,10 +375,25 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     workload = "satradix_u32" if es == 4 else "satradix_u64"
     host = make_input(workload, n_local, seed + rank)
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to(be.device)
+    sharded, fallback = None, None
     if exchange == "c" and not be.dry:
+        # The C driver over RCCL (the product path). Should it not come up on this node — it has never run on more than
+        # one RCCL rank before the first multi-GPU run — every rank falls back to the Python driver TOGETHER (an all-reduce
+        # of "I have it") and the line says so: a scaling curve on the second path beats no curve.
         from cl_ops_amd.multigpu import CShardedSorter
-        sharded = CShardedSorter(etype, local_rank, options="radix=%d%s" % (radix, ",slices=%d" % slices if slices else ""))
-    else:
+        try:
+            sharded = CShardedSorter(etype, local_rank, options="radix=%d%s" % (radix, ",slices=%d" % slices if slices else ""))
+        except Exception as e:      # noqa: BLE001
+            fallback = "%s: %s" % (type(e).__name__, e)
+        have = torch.tensor([0 if sharded is None else 1], dtype=torch.int64, device=be.device)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) == 0:
+            if sharded is not None:
+                sharded.close()
+                sharded = None
+            fallback = fallback or "another rank could not create the C driver"
+            exchange = "torch (fallback from c: %s)" % fallback[:200]
+    if sharded is None:
         sharded = ShardedSorter(be.ops(etype, local_rank))
 
     def step():

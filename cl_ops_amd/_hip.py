@@ -69,6 +69,9 @@ _sig("clo_hip_scan_workspace_set_epoch", ci, vp, C.c_uint, vp)
 _sig("clo_hip_scan_exclusive", ci, vp, vp, sz, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_scan_exclusive_carry", ci, vp, vp, sz, ci, ci, ci, vp, vp, vp, sz, vp)
 _sig("clo_hip_scan_fp_workspace_bytes", sz, sz, ci)
+_sig("clo_hip_scan_is_typed", ci, ci, ci)
+_sig("clo_hip_scan_typed_workspace_bytes", sz, sz, ci)
+_sig("clo_hip_scan_exclusive_typed", ci, vp, vp, sz, ci, ci, vp, sz, vp)
 _sig("clo_hip_scan_exclusive_fp", ci, vp, vp, sz, ci, ci, vp, sz, vp)
 _sig("clo_hip_reduce_sum", ci, vp, sz, ci, ci, vp, vp)
 _sig("clo_hip_radix_workspace_bytes", sz, sz, ci, ci, ci)

@@ -90,22 +90,11 @@ CloScan* clo_scan_new(const char* type, const char* options, CCLContext* ctx,
 			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_UNKNOWN_TYPE, "Unknown element or sum type");
 			goto error_handler;
 		}
-		/* Sums in float / double run the deterministic reduce-scan-apply kernels
-		 * (clo_hip_fscan.hip), integer sums the single-pass kernel. Not built: a
-		 * half sum type, and floating-point elements summed in an integer type
-		 * (upstream's generic kernel would truncate every element). */
-		if (sum_type == CLO_HALF) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "A half sum type is not part of the HIP build (use float)");
-			goto error_handler;
-		}
-		if (clo_type_is_float(elem_type) && !clo_type_is_float(sum_type)) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "A floating-point element type needs a floating-point sum type");
-			goto error_handler;
-		}
-		if (!clo_type_is_float(sum_type) && clo_type_sizeof(sum_type) < clo_type_sizeof(elem_type)) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "The sum type must be at least as wide as the element type");
-			goto error_handler;
-		}
+		/* Every pair of types is scanned, as upstream's generic kernel does (clo_scan_abstract.c:122-125):
+		 * integer sums at least as wide as integer elements by the single-pass kernel, everything else —
+		 * half / float / double sums, floating-point elements into integer sums (every element truncated by
+		 * the cast), sums narrower than the elements — by the deterministic reduce-scan-apply kernels
+		 * (clo_hip_fscan.hip; clo_hip_scan_is_typed decides). */
 
 		const char* token = scanner->impl_def.init(scanner, options, &err_internal);
 		if (err_internal) { clo_gerror_propagate(err, err_internal); goto error_handler; }
@@ -365,7 +354,7 @@ cl_bool clo_scan_with_host_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* c
 	}
 	if (cq_comm == NULL) cq_comm = cq_exec;
 
-	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && !clo_type_is_float(scanner->sum_type) && numel >= CLO_SCAN_PIPE_MIN_NUMEL && ccl_queue_get_stream(cq_exec) != NULL
+	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && !clo_hip_scan_is_typed((int) scanner->elem_type, (int) scanner->sum_type) && numel >= CLO_SCAN_PIPE_MIN_NUMEL && ccl_queue_get_stream(cq_exec) != NULL
 		&& getenv("CLO_SCAN_NO_PIPELINE") == NULL) {   /* (the variable: A/B measurements only) */
 		status = scan_with_host_data_pipelined(scanner, cq_exec, cq_comm, data_in, data_out, numel, &err_internal);
 		if (err_internal) goto error_handler;

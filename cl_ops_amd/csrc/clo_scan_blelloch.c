@@ -71,9 +71,10 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 		return NULL;
 	}
 
-	if (clo_type_is_float(clo_scan_get_sum_type(scanner))) {
-		/* float / double sums: reduce, scan the tile sums, apply (clo_hip_fscan.hip) */
-		const size_t wsb = clo_hip_scan_fp_workspace_bytes(numel, ss);
+	if (clo_hip_scan_is_typed((int) clo_scan_get_elem_type(scanner), (int) clo_scan_get_sum_type(scanner))) {
+		/* half / float / double sums, floating-point elements into integer sums, sums narrower than
+		 * the elements: reduce, scan the tile sums, apply (clo_hip_fscan.hip) */
+		const size_t wsb = clo_hip_scan_typed_workspace_bytes(numel, (int) clo_scan_get_sum_type(scanner));
 		if (numel > 0) {
 			if (clo_hip_failed(clo_stream_guard_enter(&data->guard, cq_exec), err, "hipStreamWaitEvent")) return NULL;
 			if (clo_hip_failed(clo_devbuf_reserve(&data->fp_workspace, wsb), err, "hipMalloc(scan workspace)")) return NULL;
@@ -81,9 +82,9 @@ static CCLEvent* clo_scan_blelloch_scan_with_device_data(CloScan* scanner, CCLQu
 		CCLEvent* fevt = ccl_queue_begin_command(cq_exec, CLO_SCAN_BLELLOCH_EVENT, err);
 		if (!fevt) return NULL;
 		if (numel > 0) {
-			const int st = clo_hip_scan_exclusive_fp(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out), numel,
-				(int) clo_scan_get_elem_type(scanner), ss, data->fp_workspace.ptr, data->fp_workspace.bytes, stream);
-			if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_fp")) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
+			const int st = clo_hip_scan_exclusive_typed(ccl_buffer_get_device_ptr(data_in), ccl_buffer_get_device_ptr(data_out), numel,
+				(int) clo_scan_get_elem_type(scanner), (int) clo_scan_get_sum_type(scanner), data->fp_workspace.ptr, data->fp_workspace.bytes, stream);
+			if (clo_hip_failed(st, err, "clo_hip_scan_exclusive_typed")) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
 		}
 		if (!ccl_queue_end_command(cq_exec, fevt, err)) { ccl_queue_abort_command(cq_exec, fevt); return NULL; }
 		return fevt;

@@ -132,6 +132,15 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
  * Reduce / scan the tile sums / apply, every addition in an order fixed by the
  * layout alone: deterministic, equal to upstream's result to rounding (its order
  * is the Blelloch tree of its own work-group size). No look-back, no polling. */
+/* Every other pair of CloTypes upstream's generic kernel accepts (scan/clo_scan_abstract.c:122-125 pastes any two
+ * type names): a half sum type, floating-point elements summed in an integer type (each element truncated by the
+ * cast `(sum type) x`, as upstream's kernel does), integer sums narrower than the elements (the cast keeps the low
+ * bits). The same deterministic reduce / scan / apply kernels, arithmetic in the sum type. clo_hip_scan_is_typed
+ * says which pairs go here (1) and which to clo_hip_scan_exclusive (0). elem_type / sum_type: CloType numbers. */
+int clo_hip_scan_is_typed(int elem_type, int sum_type);
+size_t clo_hip_scan_typed_workspace_bytes(size_t numel, int sum_type);
+int clo_hip_scan_exclusive_typed(const void* data_in, void* data_out, size_t numel, int elem_type, int sum_type,
+	void* workspace, size_t workspace_bytes, void* stream);
 size_t clo_hip_scan_fp_workspace_bytes(size_t numel, int sum_size);
 int clo_hip_scan_exclusive_fp(const void* data_in, void* data_out, size_t numel, int elem_type, int sum_size,
 	void* workspace, size_t workspace_bytes, void* stream);

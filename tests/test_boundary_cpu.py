@@ -211,17 +211,17 @@ def test_blelloch_rejects_options_and_bad_types(off):
     with pytest.raises(clo.CloError) as e:
         clo.Scanner("blelloch", off, "uint", "uint", options="x=1")
     assert e.value.code == CLO_ERROR_ARGS and "Invalid options for blelloch scan." in e.value.message
-    with pytest.raises(clo.CloError):
-        clo.Scanner("blelloch", off, "ulong", "uint")   # sum narrower than element
-    # floating-point sums are accepted (float, double; any element type); not built: a half
-    # sum type, and floating-point elements summed in an integer type
+    # every pair of types is accepted, as by upstream's generic kernel (clo_scan_abstract.c:122-125): sums narrower
+    # than the elements, half sums, floating-point elements into integer sums (round 3; refused before)
     for et, st in (("float", "float"), ("double", "double"), ("float", "double"), ("uint", "float"), ("half", "float"),
-                   ("double", "float")):
+                   ("double", "float"), ("ulong", "uint"), ("float", "uint"), ("half", "half"), ("double", "ulong"), ("int", "uchar")):
         clo.Scanner("blelloch", off, et, st).close()
-    for et, st in (("float", "uint"), ("half", "half"), ("double", "ulong")):
-        with pytest.raises(clo.CloError) as e:
-            clo.Scanner("blelloch", off, et, st)
-        assert e.value.code == CLO_ERROR_ARGS
+    with pytest.raises(clo.CloError) as e:
+        clo.Scanner("blelloch", off, "uint", 42)
+    assert e.value.code == clo.api.CLO_ERROR_UNKNOWN_TYPE
+    from cl_ops_amd._hip import lib
+    # which kernel family scans which pair (CloType numbers: uint 5, ulong 7, uchar 1, half 8, float 9)
+    assert [lib.clo_hip_scan_is_typed(a, b) for a, b in ((5, 5), (5, 7), (7, 5), (9, 5), (5, 9), (8, 8), (1, 1), (4, 1))] == [0, 0, 1, 1, 1, 1, 0, 1]
 
 
 @pytest.mark.parametrize("elem,key,get_key,expect", [

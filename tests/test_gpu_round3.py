@@ -378,3 +378,62 @@ def test_sweep_passes_with_an_empty_high_digit(gpu, key_bits, logn):
     got = s.with_host_data(a, q)
     s.close()
     assert np.array_equal(got, a[np.argsort(a & np.uint32(mask), kind="stable")])
+
+
+# ----------------------------------------------------------------------------
+# scans of every pair of types upstream's generic kernel accepts (clo_scan_abstract.c:122-125)
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("types", [("ulong", "uint"), ("uint", "uchar"), ("long", "short"), ("int", "ushort"), ("ulong", "int"),
+                                   ("float", "uint"), ("double", "long"), ("float", "int"), ("half", "uint"), ("double", "uchar"),
+                                   ("float", "ulong")])
+@pytest.mark.parametrize("n", [1, 4097, (1 << 20) + 3, (1 << 24) + 5])
+def test_scan_into_narrower_or_integer_sums(gpu, types, n):
+    """Upstream's kernel converts every element with a C cast to the sum type and adds in that type
+    (clo_scan_blelloch.cl:79-80): integer elements into a narrower sum keep their low bits, floating-point
+    elements are truncated toward zero; the sums wrap. Bit-exact against numpy's astype + cumsum."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    et, st = types
+    edt, sdt = clo.api.CLO_TYPE_NP[et], clo.api.CLO_TYPE_NP[st]
+    rng = np.random.default_rng(n % 991 + len(et) + len(st))
+    if np.issubdtype(edt, np.floating):
+        si = np.iinfo(sdt)                                                 # (a float the sum type cannot hold is undefined in C: stay inside)
+        hi = min(300.0, float(si.max))
+        lo = -min(300.0, float(-si.min)) if si.min < 0 else 0.0
+        a = (rng.random(n) * (hi - lo) * 0.999 + lo).astype(edt)
+    else:
+        info = np.iinfo(edt)
+        a = rng.integers(info.min, info.max, n, dtype=edt, endpoint=True)
+    sc = clo.Scanner("blelloch", ctx, et, st)
+    got = sc.with_host_data(a, q)
+    sc.close()
+    cast = np.trunc(a.astype(np.float64)).astype(np.int64).astype(sdt) if np.issubdtype(edt, np.floating) else a.astype(sdt)
+    wide = np.concatenate((np.zeros(1, np.uint64), np.cumsum(cast[:-1].astype(np.int64).astype(np.uint64), dtype=np.uint64)))
+    exp = wide.astype(np.dtype("u%d" % sdt.itemsize)).view(sdt)
+    assert got.dtype == sdt and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("et", ["half", "uchar", "float"])
+def test_scan_with_half_sums(gpu, et):
+    """A half sum type: every addition rounds to half precision (upstream: CLO_SCAN_SUM_TYPE half). Exact
+    while every partial sum is a small integer, within a few half-ulps of the running magnitude otherwise,
+    and the same bits from run to run."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    edt = clo.api.CLO_TYPE_NP[et]
+    rng = np.random.default_rng(17)
+    n = 40000
+    a = (rng.random(n) < 0.04).astype(edt)                   # ~1600 ones: every prefix sum below 2048 is exact in half
+    sc = clo.Scanner("blelloch", ctx, et, "half")
+    got = sc.with_host_data(a, q)
+    again = sc.with_host_data(a, q)
+    assert got.dtype == np.float16 and np.array_equal(got.view(np.uint16), again.view(np.uint16))
+    exact = np.concatenate(([0.0], np.cumsum(a.astype(np.float64))[:-1]))
+    assert exact.max() < 2048 and np.array_equal(got.astype(np.float64), exact)
+    if np.issubdtype(edt, np.floating):
+        b = (rng.random(5000) * 0.5).astype(edt)
+        got = sc.with_host_data(b, q).astype(np.float64)
+        exact = np.concatenate(([0.0], np.cumsum(b.astype(np.float64))[:-1]))
+        assert np.all(np.abs(got - exact) <= 64 * np.finfo(np.float16).eps * (exact + 1.0))
+    sc.close()
