@@ -115,6 +115,11 @@ typedef struct {
 	 * and the return value is the call's. */
 	cl_bool (*host_pipeline)(struct clo_sort* sorter, CCLQueue* cq_exec, CCLQueue* cq_comm, const void* data_in, void* data_out,
 		size_t numel, int* handled, GError** err);
+	/* reserve: grows the sorter's cached buffers for a sort of numel elements on cq_exec NOW. A caller about to
+	 * enqueue several sorts of different sizes back to back (the slices of the sharded sort) asks for every size
+	 * first: growing a buffer between two of them would free memory the earlier one is still using — hipFree
+	 * waits for the device, and the overlap the slices exist for is gone. */
+	cl_bool (*reserve)(struct clo_sort* sorter, CCLQueue* cq_exec, size_t numel, GError** err);
 } clo_sort_impl_ext;
 const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name);
 extern const clo_sort_impl_ext clo_sort_satradix_ext;

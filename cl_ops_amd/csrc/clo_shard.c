@@ -27,6 +27,7 @@ struct clo_shard_sort {
 	size_t recv_cap;
 	uint64_t* counts_host;                /* G rows (pageable: a few KiB, and the call waits for them anyway) */
 	uint64_t tail_host[SHARD_TAIL];       /* status, receive capacity: this rank's words of the gather */
+	uint64_t grow_host[SHARD_MAX_WORLD];  /* the second agreement round: every rank's "I could grow" */
 	void* comm_stream;                    /* the exchanges of a sliced sort (created at the first one) */
 	void* ev_part;                        /* cq_exec has partitioned: the exchanges may read `send` and write `recv` */
 	void* ev_arrived[SHARD_MAX_SLICES];   /* sub-bucket j is here */
@@ -411,7 +412,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 		ss->tail_host[0] = (uint64_t) gst;
 		st = clo_hip_memcpy_h2d_async(my_row, ss->tail_host, sizeof(uint64_t), stream);
 		if (st == 0) st = ss->t->all_gather_u64(ss->t->user, my_row, all_rows, 1, stream);
-		if (st == 0) st = clo_hip_memcpy_d2h_async(ss->counts_host + (size_t) SHARD_MAX_WORLD * row, all_rows, (size_t) G * sizeof(uint64_t), stream);
+		if (st == 0) st = clo_hip_memcpy_d2h_async(ss->grow_host, all_rows, (size_t) G * sizeof(uint64_t), stream);
 		if (st == 0) st = clo_hip_stream_synchronize(stream);
 		if (st != 0) {
 			clo_gerror_free(local);
@@ -420,7 +421,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 			return NULL;
 		}
 		for (int p = 0; p < G; ++p) {
-			if (ss->counts_host[(size_t) SHARD_MAX_WORLD * row + p] == 0) continue;
+			if (ss->grow_host[p] == 0) continue;
 			if (local) clo_gerror_propagate(err, local);
 			else clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "rank %d could not grow its receive buffer: no rank sorted", p);
 			return NULL;
@@ -472,6 +473,11 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 		}
 		if (st == 0) st = record(&ss->evx[1], ss->comm_stream);
 		if (st != 0) { clo_hip_failed(st, err, "all-to-all of the sub-buckets"); shard_abort(ss); return NULL; }
+		{   /* the sorter's buffers for EVERY slice size now: growing them between two slices would wait for the device */
+			const clo_sort_impl_ext* ext = clo_sort_impl_ext_find("satradix");
+			for (int j = 0; j < use && ext && ext->reserve; ++j)
+				if (!ext->reserve(ss->sorter, cq_exec, slice_n[j], err)) { shard_abort(ss); return NULL; }
+		}
 		for (int j = 0; j < use; ++j) {
 			st = clo_hip_stream_wait_event(stream, ss->ev_arrived[j]);
 			if (st == 0 && j == 0) st = record(&ss->ev[3], stream);

@@ -453,7 +453,12 @@ finish:
 	return ok && (err == NULL || *err == NULL);
 }
 
-const clo_sort_impl_ext clo_sort_satradix_ext = { "satradix", clo_sort_satradix_check_status, clo_sort_satradix_host_pipeline };
+static cl_bool clo_sort_satradix_reserve(CloSort* sorter, CCLQueue* cq_exec, size_t numel, GError** err) {
+	return (numel == 0 || satradix_reserve(sorter, cq_exec, numel, err)) ? CL_TRUE : CL_FALSE;
+}
+
+const clo_sort_impl_ext clo_sort_satradix_ext = { "satradix", clo_sort_satradix_check_status, clo_sort_satradix_host_pipeline,
+	clo_sort_satradix_reserve };
 
 typedef struct {
 	clo_sort_satradix_data* data;

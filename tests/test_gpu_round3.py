@@ -240,20 +240,22 @@ def _shard_worker(rank, world, port, etype, n, options, fail, out_dir):
         dist.destroy_process_group()
 
 
-def _run_shard(tmp_path, etype, n, options, fail=None):
+def _run_shard(tmp_path, etype, n, options, fail=None, world=2):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_shard_worker, args=(2, port, etype, n, options, fail, str(tmp_path)), nprocs=2, join=True)
-    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(2)]
-    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(2)]
-    infos = [(tmp_path / ("info_%d.txt" % r)).read_text().split("\n", 1) for r in range(2)]
+    mp.spawn(_shard_worker, args=(world, port, etype, n, options, fail, str(tmp_path)), nprocs=world, join=True)
+    ins = [np.load(tmp_path / ("in_%d.npy" % r)) for r in range(world)]
+    outs = [np.load(tmp_path / ("out_%d.npy" % r)) for r in range(world)]
+    infos = [(tmp_path / ("info_%d.txt" % r)).read_text().split("\n", 1) for r in range(world)]
     bits = 8 * ins[0].dtype.itemsize
+    b = world.bit_length() - 1
     assert np.array_equal(np.concatenate(outs), np.sort(np.concatenate(ins)))
-    assert np.all(outs[0] >> ins[0].dtype.type(bits - 1) == 0) and np.all(outs[1] >> ins[0].dtype.type(bits - 1) == 1)
+    for r in range(world):                      # rank r holds exactly bucket r
+        assert np.all(outs[r] >> ins[0].dtype.type(bits - b) == r)
     return ins, outs, infos
 
 
@@ -273,6 +275,17 @@ def test_c_shard_sort_in_slices(gpu, tmp_path, etype, n, options, slices):
         top = ins[r] >> ins[r].dtype.type(8 * es - 1)
         assert bytes_out == int(np.count_nonzero(top == other)) * es           # exactly the keys of the other rank's bucket
         assert bytes_in == int(np.count_nonzero((ins[other] >> ins[other].dtype.type(8 * es - 1)) == r)) * es
+
+
+@pytest.mark.parametrize("options,slices", [(None, 4), ("slices=8", 8)])
+def test_c_shard_sort_four_ranks_on_one_gpu(gpu, tmp_path, options, slices):
+    """Four ranks (2 bucket bits + 2 or 3 slice bits: the partition's two-split form, 4 and 5 bits) on the
+    one GPU, 2^22 keys each, exchange staged through gloo."""
+    ins, outs, infos = _run_shard(tmp_path, "uint", (1 << 22) + 11, options, world=4)
+    for r in range(4):
+        used, bytes_out, bytes_in, aborted = (int(v) for v in infos[r][0].split())
+        assert used == slices and aborted == 0
+        assert bytes_out == int(np.count_nonzero((ins[r] >> np.uint32(30)) != r)) * 4
 
 
 @pytest.mark.parametrize("fail", [(1, 1), (0, 2)])
