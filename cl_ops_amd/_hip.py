@@ -83,6 +83,7 @@ _sig("clo_hip_msd_workspace_bytes", sz, sz, ci, ci)
 _sig("clo_hip_bitonic_padded_numel", sz, sz)
 _sig("clo_hip_bitonic_simple", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_bitonic_tiled", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
+_sig("clo_hip_bitonic_any", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_kernel_lds_bytes", sz, C.c_char_p, ci, ci)
 _sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
 _sig("clo_hip_bitonic_jit_destroy", None, vp)

@@ -86,11 +86,6 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 	void* jit = clo_sort_get_jit(sorter);
 	if (numel > 1 && jit != NULL) {
 		/* kernels specialised at run time for the user's compare / get_key */
-		if (clo_hip_bitonic_padded_numel(numel) != numel) {
-			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
-				"bitonic sorts with a run-time compiled compare/get_key need a power-of-two numel");
-			BITONIC_FAIL();
-		}
 		int launches = 0;
 		int st = clo_hip_bitonic_jit_sort(jit, ccl_buffer_get_device_ptr(target), numel, tiled, &launches, stream);
 		if (clo_hip_failed(st, err, "clo_hip_bitonic_jit_sort")) BITONIC_FAIL();
@@ -99,14 +94,18 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		const size_t padded = clo_hip_bitonic_padded_numel(numel);
 		void* work = ccl_buffer_get_device_ptr(target);
 		int use_pad = 0;
+		if (padded != numel && (ks->key_shift != 0 || ks->key_bits != 8 * ks->elem_size)) {
+			/* Upstream handles powers of two only (its kernels have no bounds). Padding with a
+			 * sentinel is safe when ties are invisible, i.e. whole-element keys (below); a key
+			 * that is part of the element takes the network's flip form, in place, with the
+			 * comparators that reach past numel skipped (clo_hip_bitonic_any: one launch per step). */
+			int launches = 0;
+			int st = clo_hip_bitonic_any(work, numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind,
+				ks->descending, &launches, stream);
+			if (clo_hip_failed(st, err, "clo_hip_bitonic_any")) BITONIC_FAIL();
+			clo_debug("%s (any numel): numel=%zu launches=%d", evt_name, numel, launches);
+		} else {
 		if (padded != numel) {
-			/* Upstream handles powers of two only (its kernels have no bounds).
-			 * Padding is safe when ties are invisible, i.e. identity keys. */
-			if (ks->key_shift != 0 || ks->key_bits != 8 * ks->elem_size) {
-				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
-					"bitonic sorts of a non-power-of-two numel need the key to be the whole element");
-				BITONIC_FAIL();
-			}
 			if (clo_hip_failed(clo_stream_guard_enter(&state->guard, cq_exec), err, "hipStreamWaitEvent")) BITONIC_FAIL();
 			if (clo_hip_failed(clo_devbuf_reserve(&state->padded, padded * (size_t) ks->elem_size), err, "hipMalloc(bitonic pad)")) BITONIC_FAIL();
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(state->padded.ptr, work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
@@ -123,6 +122,7 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		clo_debug("%s: numel=%zu padded=%zu launches=%d", evt_name, numel, padded, launches);
 		if (use_pad) {
 			if (clo_hip_failed(clo_hip_memcpy_d2d_async(ccl_buffer_get_device_ptr(target), work, bytes, stream), err, "hipMemcpyAsync")) BITONIC_FAIL();
+		}
 		}
 	}
 #undef BITONIC_FAIL

@@ -74,6 +74,21 @@ int clo_hip_bitonic_simple(void* data, size_t numel, int elem_size,
 	}
 }
 
+int clo_hip_bitonic_any(void* data, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, void* stream) {
+	if (launches) *launches = 0;
+	if (numel <= 1) return 0;
+	if (!data) return CLO_HIP_EARGS;
+	hipStream_t s = (hipStream_t) stream;
+	switch (elem_size) {
+		case 1: return any_impl<uint8_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 2: return any_impl<uint16_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 4: return any_impl<uint32_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		case 8: return any_impl<uint64_t>(data, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
 int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
 	int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, void* stream) {
 	if (launches) *launches = 0;

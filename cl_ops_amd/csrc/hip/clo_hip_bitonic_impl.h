@@ -628,6 +628,50 @@ int simple_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_
 	return (int) hipGetLastError();
 }
 
+// Any numel, any key (round 3): the network in its "flip" form, in place, no padding. The first step of a stage
+// compares position o of a block's first half with position B - 1 - o of the block, every other step is a
+// half-cleaner, and EVERY comparator puts the element that compares first at the lower index: elements past
+// numel then behave like +infinity that never moves, and a comparator whose upper index is >= numel is skipped.
+// For keys that are part of the element a sentinel would show in the tie order, which is why the padded
+// direction-bit network (simple_impl / tiled_run) is used for whole-element keys only; upstream itself sorts
+// powers of two only (its kernels have no bounds), so there is no reference tie order to keep here.
+template <typename E>
+__global__ __launch_bounds__(256)
+void clo_bitonic_step_any_kernel(E* __restrict__ data, size_t n, size_t npairs, unsigned stage, unsigned step, key_desc kd) {
+	const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (gid >= npairs) return;
+	const unsigned sh = step - 1;
+	const size_t i1 = ((gid >> sh) << (sh + 1)) | (gid & (((size_t) 1 << sh) - 1));
+	const size_t i2 = step == stage ? (i1 | (((size_t) 1 << stage) - 1)) - (i1 & (((size_t) 1 << sh) - 1)) : i1 + ((size_t) 1 << sh);
+	if (i2 >= n) return;
+	E a = data[i1], b = data[i2];
+	const E a0 = a, b0 = b;
+	cmpxch<E, 0>(a, b, 0u, kd);
+	if (a != a0 || b != b0) { data[i1] = a; data[i2] = b; }
+}
+
+template <typename E>
+int any_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
+	int* launches, hipStream_t s) {
+	E* data = (E*) vdata;
+	key_desc kd; E pad;
+	int st = make_desc<E>(key_shift, key_bits, key_size, key_kind, descending, &kd, &pad);
+	if (st) return st;
+	const size_t n = nlpo2(numel);
+	const unsigned T = log2u(n);
+	int count = 0;
+	const size_t npairs = n / 2;
+	const unsigned blocks = (unsigned) ((npairs + 255) / 256);
+	for (unsigned stage = 1; stage <= T; ++stage)
+		for (unsigned step = stage; step >= 1; --step) {
+			clo_timing_scope timing("bitonic_step", s);
+			hipLaunchKernelGGL((clo_bitonic_step_any_kernel<E>), dim3(blocks), dim3(256), 0, s, data, numel, npairs, stage, step, kd);
+			++count;
+		}
+	if (launches) *launches = count;
+	return (int) hipGetLastError();
+}
+
 inline bool g_no_strided2() { static const bool off = getenv("CLO_BITONIC_NO_STRIDED2") != nullptr; return off; }   // (A/B measurements only)
 
 template <typename E, int NS, int MODE>

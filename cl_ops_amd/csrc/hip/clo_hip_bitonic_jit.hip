@@ -72,6 +72,26 @@ void jit_step(E* __restrict__ data, unsigned long npairs, unsigned stage, unsign
 	data[i2] = b;
 }
 
+// Any numel (round 3): the network in its "flip" form — the first step of a stage compares position o of a
+// block's first half with position B - 1 - o of the block, every other step is a half-cleaner, and EVERY
+// comparator puts the smaller element at the lower index. Elements past numel then behave like +infinity
+// that never moves: a comparator whose upper index is >= numel is simply skipped. (Upstream's network with
+// its direction bit has no such form and upstream sorts powers of two only, so there is no reference order
+// to keep for ties here; for a power of two the direction-bit kernels above are used, as upstream's are.)
+extern "C" __global__ __launch_bounds__(256)
+void jit_step_any(E* __restrict__ data, unsigned long n, unsigned long npairs, unsigned stage, unsigned step) {
+	const unsigned long gid = (unsigned long) blockIdx.x * 256 + threadIdx.x;
+	if (gid >= npairs) return;
+	const unsigned sh = step - 1;
+	const unsigned long i1 = ((gid >> sh) << (sh + 1)) | (gid & ((1ul << sh) - 1));
+	const unsigned long i2 = step == stage ? (i1 | ((1ul << stage) - 1ul)) - (i1 & ((1ul << sh) - 1ul)) : i1 + (1ul << sh);
+	if (i2 >= n) return;
+	E a = data[i1], b = data[i2];
+	cmpxch(a, b, 0u);
+	data[i1] = a;
+	data[i2] = b;
+}
+
 template <int NS>
 __device__ __forceinline__ void strided_body(E* __restrict__ data, unsigned long n, unsigned stage, unsigned p) {
 	constexpr int V = 1 << NS;
@@ -169,7 +189,7 @@ void jit_gselect(const E* __restrict__ in, E* __restrict__ out, unsigned long n)
 
 struct jit_sorter {
 	hipModule_t module = nullptr;
-	hipFunction_t step = nullptr, tile = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipFunction_t step = nullptr, step_any = nullptr, tile = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	int elem_size = 0;
 	int q = 0;
 };
@@ -246,6 +266,7 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	js->q = q;
 	hipError_t e = hipModuleLoadData(&js->module, code.data());
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->step, js->module, "jit_step");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js->step_any, js->module, "jit_step_any");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->tile, js->module, "jit_tile");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->gselect, js->module, "jit_gselect");
 	for (int ns = 1; ns <= q && e == hipSuccess; ++ns) {
@@ -280,19 +301,30 @@ int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t
 	return launch(js->gselect, (unsigned) ((numel + 255) / 256), (hipStream_t) stream, args);
 }
 
-// In-place sort of data[0..numel), numel a power of two. tiled = 0: one launch
-// per step; 1: the tile/strided schedule.
+// In-place sort of data[0..numel). A power of two: tiled = 0: one launch per step; 1: the tile/strided
+// schedule (upstream's network). Any other numel: the flip network, one launch per step.
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream) {
 	jit_sorter* js = (jit_sorter*) handle;
 	if (launches) *launches = 0;
 	if (!js || !data) return CLO_HIP_EARGS;
 	if (numel <= 1) return 0;
-	if ((numel & (numel - 1)) != 0) return CLO_HIP_EARGS;
 	hipStream_t s = (hipStream_t) stream;
 	unsigned T = 0;
 	while (((size_t) 1 << T) < numel) ++T;
 	unsigned long n = numel;
 	int count = 0, st = 0;
+	if ((numel & (numel - 1)) != 0) {   // not a power of two: the flip network over the next one, one launch per step
+		unsigned long npairs = ((unsigned long) 1 << T) / 2;
+		const unsigned blocks = (unsigned) ((npairs + 255) / 256);
+		for (unsigned stage = 1; stage <= T && !st; ++stage)
+			for (unsigned step = stage; step >= 1 && !st; --step) {
+				void* args[] = { &data, &n, &npairs, &stage, &step };
+				st = launch(js->step_any, blocks, s, args);
+				++count;
+			}
+		if (launches) *launches = count;
+		return st;
+	}
 	const unsigned Q = (unsigned) js->q, KL_MAX = 8 + Q;
 
 	if (!tiled || T < Q) {

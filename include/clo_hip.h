@@ -227,6 +227,11 @@ size_t clo_hip_bitonic_padded_numel(size_t numel);
 int clo_hip_bitonic_simple(void* data, size_t numel, int elem_size,
 	int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, void* stream);
+/* In place, ANY numel and any key: the flip form of the network (every comparator ascending, comparators that reach
+ * past numel skipped), one launch per step. What the drivers use for a numel that is not a power of two when the key
+ * is only part of the element (for whole-element keys they pad and run the fast schedules). */
+int clo_hip_bitonic_any(void* data, size_t numel, int elem_size,
+	int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, void* stream);
 int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
 	int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, void* stream);

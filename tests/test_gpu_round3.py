@@ -450,3 +450,28 @@ def test_scan_with_half_sums(gpu, et):
         exact = np.concatenate(([0.0], np.cumsum(b.astype(np.float64))[:-1]))
         assert np.all(np.abs(got - exact) <= 64 * np.finfo(np.float16).eps * (exact + 1.0))
     sc.close()
+
+
+# ----------------------------------------------------------------------------
+# bitonic sorts of any numel with a key that is only part of the element
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic"])
+@pytest.mark.parametrize("n", [2, 3, 1000, 4097, 100003])
+@pytest.mark.parametrize("compare", [None, "((a) < (b))"])
+def test_bitonic_any_numel_with_partial_keys(gpu, alg, n, compare):
+    """Upstream's bitonic kernels have no bounds (powers of two only). Whole-element keys are padded with a
+    sentinel; a key that is only part of the element cannot be (ties with the sentinel would show), so such
+    sorts take the flip form of the network in place, comparators that reach past numel skipped: sorted by
+    the key under `compare`, and a permutation of the input."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, max(2, n // 3), n, dtype=np.uint64)             # many ties
+    a = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    s = clo.Sorter(alg, ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)", compare=compare)
+    got = s.with_host_data(a, q)
+    s.close()
+    k = (got >> np.uint64(32)).astype(np.int64)
+    assert np.all(np.diff(k) >= 0) if compare is None else np.all(np.diff(k) <= 0)
+    assert np.array_equal(np.sort(got), np.sort(a))
