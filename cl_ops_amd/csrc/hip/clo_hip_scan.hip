@@ -388,7 +388,13 @@ unsigned g_scan_max_spins = CLO_MAX_SPINS;   // CLO_MAX_SPINS in the environment
 // shorter tile is what helps — its load, look-back and store phases alternate
 // twice as often.
 constexpr size_t SCAN_BIG_NUMEL = (size_t) 1 << 24;
-constexpr int SCAN_BIG_ROWS = 8;
+#ifndef CLO_SCAN_BIG_ROWS
+#define CLO_SCAN_BIG_ROWS 8
+#endif
+#ifndef CLO_SCAN_BIG_GROUPS
+#define CLO_SCAN_BIG_GROUPS 256
+#endif
+constexpr int SCAN_BIG_ROWS = CLO_SCAN_BIG_ROWS;
 constexpr int scan_threads(size_t numel) { return numel >= SCAN_BIG_NUMEL ? 1024 : 256; }
 constexpr int scan_small_rows(int sum_size) { return sum_size > 4 ? 8 : 16; }
 constexpr size_t scan_tile_elems(size_t numel, int sum_size) {
@@ -429,7 +435,7 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		const unsigned max_spins = g_scan_max_spins;
 		clo_timing_scope timing("scan", s);
 		// as many work-groups as fit the chip at once; each draws tiles until none is left
-		const unsigned groups_big = (unsigned) (tiles < 256 ? tiles : 256), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
+		const unsigned groups_big = (unsigned) (tiles < CLO_SCAN_BIG_GROUPS ? tiles : CLO_SCAN_BIG_GROUPS), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
 		if (scan_threads(n) == 1024)
 			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3(groups_big), dim3(1024), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
