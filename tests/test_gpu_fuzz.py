@@ -91,3 +91,32 @@ def test_fuzz_scan(gpu, seed):
         wide = a.astype(np.int64 if info.min < 0 else np.uint64)
         exp = np.concatenate((np.zeros(1, wide.dtype), np.cumsum(wide[:-1], dtype=wide.dtype))).astype(sdt)
         assert np.array_equal(got, exp), "%s -> %s, n %d" % (et, st, n)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_key_fields(gpu, seed):
+    """Random KEY FIELDS of the element (get_key = a shift and a mask of any width) at sizes on every path of the
+    radix sort, radix 4 / 16 / 256: numpy's stable sort by the field. (Round 3: a 28-bit field on the single-sweep
+    passes came out wrong with every test of whole-type keys green; tools/fuzz_keyfield_gpu.py is the long run.)"""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    rng = np.random.default_rng(4000 + seed)
+    sizes4 = [5, 4097, 16385, 40000, (1 << 17) + 3, (1 << 20) + 1, (1 << 22) + 77, (1 << 23) + 8193]
+    sizes8 = [3, 8193, 30000, (1 << 16) + 3, (1 << 19) + 1, (1 << 21) + 77, (1 << 22) + 4097]
+    for _ in range(10):
+        es = int(rng.choice([4, 8]))
+        et, dt = ("uint", np.uint32) if es == 4 else ("ulong", np.uint64)
+        bits = 8 * es
+        n = int(rng.choice(sizes4 if es == 4 else sizes8)) + int(rng.integers(0, 5))
+        width = int(rng.integers(1, bits + 1))
+        shift = int(rng.integers(0, bits - width + 1))
+        mask = (1 << width) - 1
+        a = rng.integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+        key = (a >> dt(shift)) & dt(mask)
+        kt = "uint" if width <= 32 else "ulong"
+        get_key = "(%s) (((x) >> %d) & 0x%x%s)" % (kt, shift, mask, "ul" if es == 8 else "u")
+        radix = int(rng.choice([4, 16, 256]))
+        s = clo.Sorter("satradix", ctx, et, key_type=kt, get_key=get_key, options="radix=%d" % radix)
+        got = s.with_host_data(a, q)
+        s.close()
+        assert np.array_equal(got, a[np.argsort(key, kind="stable")]), "%s n=%d %s radix=%d" % (et, n, get_key, radix)
