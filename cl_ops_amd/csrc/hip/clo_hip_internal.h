@@ -69,7 +69,8 @@ size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits);
 int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, unsigned shift, int bits,
 	unsigned long long* counts, void* ws, hipStream_t s);
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
-	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s);
+	int key_bits, int digit_bits, clo_keyx kx, const unsigned char* first_dig, void* ws, hipStream_t s);
+int clo_radix4_takes_first_digits(size_t n, int elem_size, int digit_bits);
 size_t clo_radix4_lds_bytes(int elem_size, int digit_bits);
 // single-sweep passes (clo_hip_radix1.hip); ws: its own region, status: the workspace's status word
 int clo_radix1_applies(size_t n, int elem_size, int digit_bits);

@@ -74,8 +74,19 @@ int clo_hip_radix_polls(size_t numel, int elem_size, int digit_bits) {
 	return clo_radix1_applies(numel, elem_size, digit_bits) ? 1 : 0;
 }
 
+int clo_hip_radix_takes_first_digits(size_t numel, int elem_size, int key_kind, int digit_bits) {
+	return key_kind == 0 ? clo_radix4_takes_first_digits(numel, elem_size, digit_bits) : 0;
+}
+
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits,
+	void* workspace, size_t workspace_bytes, void* stream) {
+	return clo_hip_radix_sort_fed(src, dst, tmp, numel, elem_size, key_shift, key_bits, key_kind, digit_bits, nullptr,
+		workspace, workspace_bytes, stream);
+}
+
+int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
+	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits, const unsigned char* first_digits,
 	void* workspace, size_t workspace_bytes, void* stream) {
 
 	if (numel == 0) return 0;
@@ -88,7 +99,7 @@ int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	if (workspace_bytes < clo_hip_radix_workspace_bytes(numel, elem_size, key_bits, digit_bits)) return CLO_HIP_EWORKSPACE;
 	hipStream_t s = (hipStream_t) stream;
 	const clo_keyx kx = clo_keyx_make(key_kind, key_shift, key_bits);
-	return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, workspace, s);
+	return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, first_digits, workspace, s);
 }
 
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {

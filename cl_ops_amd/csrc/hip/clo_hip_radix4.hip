@@ -301,8 +301,12 @@ rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits, bool digits = t
 	return L;
 }
 
+// first_dig (optional): the FIRST pass's combined digit of every element, one byte each, in source order, handed
+// over by whoever produced the keys (clo_hip_radix_sort_fed): the first histogram then reads n bytes instead of
+// the elements — the one re-read of the keys the sort has left.
 template <typename E, int LB, int HB>
-int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, clo_keyx kx, void* ws, hipStream_t s) {
+int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_bits, clo_keyx kx, const unsigned char* first_dig,
+	void* ws, hipStream_t s) {
 	constexpr int PB = LB + HB;   // key bits per trip through HBM
 	const int passes = (key_bits + PB - 1) / PB;
 	const rp_layout L = rp_make_layout(n, (int) sizeof(E), PB);
@@ -335,8 +339,9 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		{
 			clo_timing_scope timing("radix_hist", s);
 			// (from the second pass on: out of the digit bytes the pass before left behind)
-			const int st = (dig && p > 0)
-				? clo_radixw_launch_tilehist_bytes(dig, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, tiles, big, s)
+			const unsigned char* hist_bytes = (dig && p > 0) ? dig : ((DIG_OK && big && p == 0 && kx.kind == 0) ? first_dig : nullptr);
+			const int st = hist_bytes
+				? clo_radixw_launch_tilehist_bytes(hist_bytes, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, tiles, big, s)
 				: clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
 					thist, tinfo, tiles, big, p == 0 ? kx : kx_none, s);
 			if (st != 0) return st;
@@ -384,8 +389,8 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 
 template <typename E>
 int rp_dispatch(const void* src, void* dst, void* tmp, size_t n, int key_shift, int key_bits, int digit_bits,
-	clo_keyx kx, void* ws, hipStream_t s) {
-	#define CLO_RP(LB, HB) return rp_sort_impl<E, LB, HB>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, ws, s)
+	clo_keyx kx, const unsigned char* first_dig, void* ws, hipStream_t s) {
+	#define CLO_RP(LB, HB) return rp_sort_impl<E, LB, HB>((const E*) src, (E*) dst, (E*) tmp, n, key_shift, key_bits, kx, first_dig, ws, s)
 	switch (digit_bits) {
 		case 1: CLO_RP(1, 1);
 		case 2: CLO_RP(2, 2);
@@ -531,8 +536,15 @@ size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
 		+ (2 * (threads / 64) * hmax + ((size_t) 1 << pass_bits) + 4) * sizeof(unsigned);
 }
 
+// 1: a sort of this shape reads caller-provided first digits (the chain-free passes on big tiles, radix 16 / 256)
+int clo_radix4_takes_first_digits(size_t n, int elem_size, int digit_bits) {
+	if (elem_size < 4 || (digit_bits != 4 && digit_bits != 8) || getenv("CLO_RADIX_NO_DIGITS") != nullptr) return 0;
+	if (clo_radix1_applies(n, elem_size, digit_bits)) return 0;
+	return clo_radix_big_tiles(n, elem_size) ? 1 : 0;
+}
+
 int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_size, int key_shift,
-	int key_bits, int digit_bits, clo_keyx kx, void* ws, hipStream_t s) {
+	int key_bits, int digit_bits, clo_keyx kx, const unsigned char* first_dig, void* ws, hipStream_t s) {
 	const size_t small_max = elem_size == 8 ? (size_t) small_big<uint64_t>::TILE : (size_t) small_big<uint32_t>::TILE;
 	if (n <= small_max && digit_bits <= 4) {   // one launch for the whole sort
 		switch (elem_size) {
@@ -547,10 +559,10 @@ int clo_radix4_sort(const void* src, void* dst, void* tmp, size_t n, int elem_si
 		return clo_radix1_sort(src, dst, tmp, n, elem_size, key_shift, key_bits, kx,
 			(char*) ws + r4_pair_workspace_bytes(n, elem_size, digit_bits), (unsigned*) ws, s);
 	switch (elem_size) {
-		case 1: return rp_dispatch<uint8_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
-		case 2: return rp_dispatch<uint16_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
-		case 4: return rp_dispatch<uint32_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
-		case 8: return rp_dispatch<uint64_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, ws, s);
+		case 1: return rp_dispatch<uint8_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, first_dig, ws, s);
+		case 2: return rp_dispatch<uint16_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, first_dig, ws, s);
+		case 4: return rp_dispatch<uint32_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, first_dig, ws, s);
+		case 8: return rp_dispatch<uint64_t>(src, dst, tmp, n, key_shift, key_bits, digit_bits, kx, first_dig, ws, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }

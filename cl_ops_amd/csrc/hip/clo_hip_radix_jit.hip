@@ -50,13 +50,15 @@ __device__ __forceinline__ UK jit_ordered_key(const E x) {
 	return u;
 }
 
-// pairs[i] = (low 32 bits of the ordered key, i)  — the whole key when it has <= 32 bits
+// pairs[i] = (low 32 bits of the ordered key, i)  — the whole key when it has <= 32 bits;
+// dig (optional): the first radix pass's digit of pair i, one byte (clo_hip_radix_sort_fed)
 extern "C" __global__ __launch_bounds__(256)
-void jit_extract(const E* __restrict__ in, unsigned long long* __restrict__ pairs, unsigned long n) {
+void jit_extract(const E* __restrict__ in, unsigned long long* __restrict__ pairs, unsigned long n, unsigned char* __restrict__ dig) {
 	const unsigned long i = (unsigned long) blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
 	const unsigned long long u = (unsigned long long) jit_ordered_key(in[i]);
 	pairs[i] = (u << 32) | (unsigned long long) (unsigned) i;
+	if (dig) dig[i] = (unsigned char) u;
 }
 
 // 8-byte keys, second round: out[i] = (high 32 bits of the ordered key of x[j], j), j = index in pairs[i]
@@ -181,14 +183,18 @@ int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs
 	hipStream_t s = (hipStream_t) stream;
 	unsigned long n = numel;
 	const unsigned blocks = (unsigned) ((numel + 255) / 256);
+	// The extractor touches every key anyway: it also writes the first pass's digit of every pair, one byte each,
+	// into the ping-pong partner of the pairs (free until the first pass kernel writes it), and the sort's first
+	// histogram reads those numel bytes instead of numel 8-byte pairs.
+	unsigned char* dig = clo_hip_radix_takes_first_digits(numel, 8, 0, digit_bits) ? (unsigned char*) pairs_tmp : nullptr;
 	{
 		clo_timing_scope timing("radix_extract", s);
-		void* args[] = { (void*) &src, &pairs, &n };
+		void* args[] = { (void*) &src, &pairs, &n, &dig };
 		const hipError_t e = hipModuleLaunchKernel(rj->extract, blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
 		if (e != hipSuccess) return (int) e;
 	}
 	const int low_bits = rj->key_size >= 4 ? 32 : 8 * rj->key_size;
-	int st = clo_hip_radix_sort(pairs, pairs, pairs_tmp, numel, 8, 32, low_bits, 0, digit_bits,
+	int st = clo_hip_radix_sort_fed(pairs, pairs, pairs_tmp, numel, 8, 32, low_bits, 0, digit_bits, dig,
 		workspace, workspace_bytes, stream);
 	if (st != 0) return st;
 	void* sorted = pairs;      // where the sorted (key, index) pairs are

@@ -172,6 +172,17 @@ int clo_hip_radix_polls(size_t numel, int elem_size, int digit_bits);
 int clo_hip_radix_sort(const void* src, void* dst, void* tmp, size_t numel,
 	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits,
 	void* workspace, size_t workspace_bytes, void* stream);
+/* The same sort FED by whoever produced the keys: first_digits[i] = the low 8 bits of element i's key field,
+ * (elem[i] >> key_shift) & 0xff (device memory, numel bytes, read before anything is written — it may live in
+ * `tmp`). The one re-read of the keys the sort has left is its first histogram; a producer that touches every
+ * key anyway (a key extractor, a generator, the pass before in a pipeline) writes those bytes for nearly nothing
+ * and the histogram reads numel bytes instead of numel elements. clo_hip_radix_takes_first_digits says whether a
+ * sort of this shape reads them (1: the chain-free passes on 16 384-element tiles, radix 16 or 256, unsigned
+ * keys) — otherwise they are ignored, NULL is always allowed. */
+int clo_hip_radix_takes_first_digits(size_t numel, int elem_size, int key_kind, int digit_bits);
+int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
+	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits, const unsigned char* first_digits,
+	void* workspace, size_t workspace_bytes, void* stream);
 
 /* MSD bucket partition used by the multi-GPU exchange (new
  * functionality): stable split of src into 1<<bucket_bits buckets by the top

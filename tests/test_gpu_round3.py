@@ -475,3 +475,35 @@ def test_bitonic_any_numel_with_partial_keys(gpu, alg, n, compare):
     k = (got >> np.uint64(32)).astype(np.int64)
     assert np.all(np.diff(k) >= 0) if compare is None else np.all(np.diff(k) <= 0)
     assert np.array_equal(np.sort(got), np.sort(a))
+
+
+# ----------------------------------------------------------------------------
+# a radix sort fed with its first digits by the producer of the keys
+# ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind,logn,shift,bits", [("uint", 26, 0, 32), ("ulong", 24, 32, 32), ("ulong", 24, 0, 64), ("uint", 20, 0, 32)])
+def test_radix_sort_fed_with_first_digits(gpu, kind, logn, shift, bits):
+    """clo_hip_radix_sort_fed: the caller hands over (elem >> key_shift) & 0xff per element and the first histogram
+    reads those bytes instead of the elements (big tiles only; elsewhere they are ignored). Same result as the plain
+    sort; the bytes may live in `tmp`."""
+    import cl_ops_amd as clo
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    ctx, q = gpu
+    dt = np.uint32 if kind == "uint" else np.uint64
+    es = np.dtype(dt).itemsize
+    n = (1 << logn) + 1234
+    a = np.random.default_rng(logn + shift).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    key = (a >> dt(shift)) & dt((1 << bits) - 1 if bits < 64 else np.iinfo(dt).max)
+    takes = lib.clo_hip_radix_takes_first_digits(n, es, 0, 4)
+    assert takes == (1 if n * es >= ((64 if es == 8 else 256) << 20) else 0)
+    wsb = lib.clo_hip_radix_workspace_bytes(n, es, bits, 4)
+    src, dst, tmp, ws = clo.Buffer(ctx, n * es), clo.Buffer(ctx, n * es), clo.Buffer(ctx, n * es), clo.Buffer(ctx, wsb)
+    src.write(q, a)
+    tmp.write(q, (key & dt(0xff)).astype(np.uint8))                        # the digits, in the scratch buffer
+    ws.write(q, np.zeros(128, np.uint32))
+    _hip.check(lib.clo_hip_radix_sort_fed(src.ptr, dst.ptr, tmp.ptr, n, es, shift, bits, 0, 4, tmp.ptr, ws.ptr, wsb, q.stream))
+    q.finish()
+    assert np.array_equal(dst.read(q, dt, n), a[np.argsort(key, kind="stable")])
+    for b in (src, dst, tmp, ws):
+        b.close()
