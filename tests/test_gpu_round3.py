@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # ----------------------------------------------------------------------------
-# give-ups of the single-sweep radix passes (the library's path for 2^15 .. 2^23 keys)
+# give-ups of the single-sweep radix passes (the library's path for 2^15 .. 2^22 keys)
 # ----------------------------------------------------------------------------
 
 def test_sort_lookback_timeout_is_reported_on_every_queue_shape(gpu, monkeypatch):
@@ -87,6 +87,7 @@ def test_sweep_ticket_pools(gpu, monkeypatch, pools, kind, logn):
     like) and eight per-XCD pools give the same, correct order."""
     import cl_ops_amd as clo
     ctx, q = gpu
+    monkeypatch.setenv("CLO_RADIX_SWEEP", "1")            # (the library itself leaves this path above 512 tiles)
     monkeypatch.setenv("CLO_R1_POOLS", pools)
     n = (1 << logn) + 12345
     a = O.bench_rand(logn, kind, n)
@@ -378,12 +379,13 @@ def test_gselect_with_runtime_compiled_macros(gpu, case):
 
 @pytest.mark.parametrize("key_bits", [28, 20, 12, 4])
 @pytest.mark.parametrize("logn", [16, 20, 22])
-def test_sweep_passes_with_an_empty_high_digit(gpu, key_bits, logn):
+def test_sweep_passes_with_an_empty_high_digit(gpu, monkeypatch, key_bits, logn):
     """A key width that is 4 modulo 8 makes the last single-sweep pass a one-digit pass (no second
     local split): it must still look back at ALL its predecessors (round 2's kernel took the rows it
     would have requested from inside the second split as 'valid, zero')."""
     import cl_ops_amd as clo
     ctx, q = gpu
+    monkeypatch.setenv("CLO_RADIX_SWEEP", "1")
     n = (1 << logn) + 321
     a = O.bench_rand(key_bits + logn, "uint", n)
     mask = (1 << key_bits) - 1

@@ -50,6 +50,12 @@ def bench(kind, log2n):
     bd.close()
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "edge":   # around the switch between the two paths (512 .. 1024 tiles)
+    for rep in range(2):
+        for kind, ls in (("u32", (21, 22, 23)), ("u64", (20, 21, 22, 23)), ("pairs", (20, 21, 22, 23))):
+            for l in ls:
+                bench(kind, l)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "big":   # where should the default switch back for 8-byte elements?
     for rep in range(2):
         for kind in ("u64", "pairs", "u32"):
