@@ -84,11 +84,16 @@ int clo_bitonic_tiled_e4(void* data, size_t numel, int key_shift, int key_bits, 
 int clo_bitonic_tiled_e8(void* data, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending, int* launches, hipStream_t s);
 size_t clo_radixw_lds_bytes(int digit_bits);
 // tinfo: one word per tile, 1 = one bin holds the whole tile (read by the pass kernel)
+// partial: the counter scan's workspace (clo_radixw_partial_rows(tiles) rows of 1 << bits words); the histogram launch zeroes
+// the hand-off words of the scan that follows it on the stream (clo_radixw_launch_offsets), which returns in *dbase the row
+// of digit bases the pass kernel adds to toff[tile][digit] (null: toff is final)
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
-	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, clo_keyx kx, hipStream_t s);
+	unsigned* thist, unsigned* tinfo, unsigned* partial, unsigned tiles, bool big, clo_keyx kx, hipStream_t s);
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
-	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, hipStream_t s);
-int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff, hipStream_t s);
+	unsigned* thist, unsigned* tinfo, unsigned* partial, unsigned tiles, bool big, hipStream_t s);
+int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff,
+	const unsigned** dbase, hipStream_t s);
+size_t clo_radixw_partial_rows(size_t tiles);
 
 typedef unsigned long long clo_u64;
 

@@ -33,7 +33,7 @@
 // out). Two ways of drawing them (r1_pass::pools):
 //   1 pool   ONE counter, tickets = tile numbers: whatever the device looks like,
 //            every tile a work-group can be waiting for has been handed out. The
-//            library's default (it takes this path for 4 .. 512 tiles).
+//            library's default (it takes this path for 4 .. 256 tiles).
 //   8 pools  one counter per XCD, chunk j of pool x = global chunk 8*j + x, the
 //            XCD read from the hardware (XCC_ID): the 16 tiles of a chunk run
 //            behind one L2, where the boundary lines of neighbouring runs merge
@@ -649,13 +649,15 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
-	// The library's choice (measured; profiles/r03_sweep_sizes*.txt, r03_sweep_edge.txt):
-	// 4 .. 512 tiles (2^15 .. 2^22 4-byte elements, 2^14 .. 2^21 8-byte ones): the sort is launch-bound and
-	// the sweeps need 6 launches instead of 12: 3-33 % less time (and half the events on a profiling
-	// queue). Above that the chain-free passes are ahead — since round 3, whose counter-scan kernels cost
-	// 10 us less per pass, already at 1024 tiles (2^23 uint32: 0.163 vs 0.191 ms, 2^22 pairs: 0.146 vs 0.169;
-	// round 2 switched at 1024) — and no work-group ever waits for another there.
-	return tiles >= 4 && tiles <= 512;
+	// The library's choice (measured; profiles/r03_sweep_sizes*.txt, r03_sweep_edge*.txt):
+	// 4 .. 256 tiles (2^15 .. 2^21 4-byte elements, 2^14 .. 2^20 8-byte ones): the sort is launch-bound and
+	// the sweeps need 6 launches instead of 12: 5-25 % less time (and half the events on a profiling
+	// queue). Above that the chain-free passes are ahead, and no work-group ever waits for another's
+	// result there. The switch moved down as their counter scan got cheaper: round 2 switched at 1024 tiles,
+	// round 3 at 512 when the scan's three kernels lost 10 us per pass, then at 256 when they became
+	// one launch (2^22 uint32: 0.104 vs 0.119 ms, 2^23: 0.144 vs 0.190; 2^21 uint64: 0.187 vs 0.199;
+	// 2^21 pairs: 0.093 vs 0.107 — at 2^21 uint32 the sweeps still win, 0.090 vs 0.095).
+	return tiles >= 4 && tiles <= 256;
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

@@ -55,7 +55,8 @@ template <typename E, int LB, int HB, bool BIG, bool DIG = false>
 __global__ __launch_bounds__((pair_shape<E, BIG>::THREADS), (pair_shape<E, BIG>::THREADS >= 1024 ? 8 : 6))   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (59 used); BIG: 2 x 16 waves, <= 64
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
-	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, const unsigned* __restrict__ tinfo, int aligned,
+	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, const unsigned* __restrict__ dbase,
+	const unsigned* __restrict__ tinfo, int aligned,
 	clo_keyx kx_in, clo_keyx kx_out, unsigned char* __restrict__ dig_out = nullptr, unsigned next_shift = 0) {
 
 	constexpr int THREADS = pair_shape<E, BIG>::THREADS;
@@ -91,6 +92,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	if (tid < (unsigned) R2) {
 		h2 = thist[(size_t) tile * R2 + tid];
 		goff = toff[(size_t) tile * R2 + tid];
+		if (dbase) goff += dbase[tid];   // (the one-launch counter scan keeps the digit bases in a row of their own)
 	}
 	E key[ITEMS];
 	if (full) {
@@ -291,7 +293,7 @@ rp_layout rp_make_layout(size_t n, int elem_size, int pass_bits, bool digits = t
 	L.thist = CLO_WS_HEADER_BYTES;
 	L.toff = L.thist + per;
 	L.partial = L.toff + per;
-	L.tinfo = L.partial + (((L.tiles / 128 + 1) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
+	L.tinfo = L.partial + ((clo_radixw_partial_rows(L.tiles) * R2 * sizeof(unsigned) + 255) & ~(size_t) 255);
 	L.total = L.tinfo + ((L.tiles * sizeof(unsigned) + 255) & ~(size_t) 255);
 	L.dig = 0;
 	if (digits && clo_radix_digit_stream(n, elem_size)) {
@@ -341,14 +343,15 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			// (from the second pass on: out of the digit bytes the pass before left behind)
 			const unsigned char* hist_bytes = (dig && p > 0) ? dig : ((DIG_OK && big && p == 0 && kx.kind == 0) ? first_dig : nullptr);
 			const int st = hist_bytes
-				? clo_radixw_launch_tilehist_bytes(hist_bytes, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, tiles, big, s)
+				? clo_radixw_launch_tilehist_bytes(hist_bytes, n, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, partial, tiles, big, s)
 				: clo_radixw_launch_tilehist(cur_in, n, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo,
-					thist, tinfo, tiles, big, p == 0 ? kx : kx_none, s);
+					thist, tinfo, partial, tiles, big, p == 0 ? kx : kx_none, s);
 			if (st != 0) return st;
 		}
+		const unsigned* dbase = nullptr;
 		{
 			clo_timing_scope timing("radix_offsets", s);
-			const int st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, s);
+			const int st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, &dbase, s);
 			if (st != 0) return st;
 		}
 		{
@@ -361,20 +364,20 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 					if constexpr (DIG_OK) {
 						if (dig && p + 1 < passes) {
 							hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-								cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo, aligned, kin, kout,
+								cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, aligned, kin, kout,
 								dig, (unsigned) (key_shift + (p + 1) * PB));
 							done = true;
 						}
 					}
 					if (!done)
 						hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo, aligned, kin, kout, nullptr, 0u);
+							cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, aligned, kin, kout, nullptr, 0u);
 					cur_in = cur_out;
 					continue;
 				}
 			}
 			hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
-				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo, aligned, kin, kout, nullptr, 0u);
+				cur_in, cur_out, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, aligned, kin, kout, nullptr, 0u);
 		}
 		cur_in = cur_out;
 	}
@@ -447,19 +450,20 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	clo_timing_scope timing("msd_partition", s);
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
 	const unsigned mask_lo = TWO ? (1u << LB) - 1u : R - 1u, mask_hi = TWO ? (1u << HB) - 1u : 0u;
-	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tinfo, tiles, big, kx_none, s);
+	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tinfo, partial, tiles, big, kx_none, s);
 	if (st != 0) return st;
 	if (counts)
 		hipLaunchKernelGGL((clo_radix4_counts_kernel<R, (1 << PB)>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);
-	st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, s);
+	const unsigned* dbase = nullptr;
+	st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, &dbase, s);
 	if (st != 0) return st;
 	if (big)
 		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
-			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo,
+			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	else
 		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
-			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, (const unsigned*) tinfo,
+			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
 	return (int) hipGetLastError();
 }

@@ -306,7 +306,7 @@ template <typename E> struct sweep_shape {
 // Shape of a tile of the chain-free pair passes (= the tiles of clo_hip_radixw.hip's
 // histogram). Two shapes, chosen per sort by the array's size (clo_radix_big_tiles):
 // 512 threads x 16 elements (8 for 8-byte elements) with the table of ends next to
-// the 32 KiB stage, 3 work-groups per CU; and, for arrays of 256 MiB and more (64 MiB
+// the 32 KiB stage, 3 work-groups per CU; and, for arrays of 256 MiB and more (32 MiB
 // of 8-byte elements), BIG:
 // 1024 threads on twice the tile, the table inside the 64 KiB stage (ALIAS), 2
 // work-groups per CU — runs of 256 bytes per digit pair and tile instead of 128 in
@@ -318,11 +318,12 @@ template <typename E, bool BIG> struct pair_shape {
 	static constexpr int TILE = THREADS * ITEMS;
 	static constexpr bool ALIAS = BIG && sizeof(E) >= 4;
 };
-// (8-byte elements gain from 64 MiB on — their digit stream is an eighth of the
-// array — 4-byte ones from 256 MiB: measured)
+// (8-byte elements gain from 32 MiB on — their digit stream is an eighth of the
+// array; 2^22 uint64 0.254 -> 0.234 ms, pairs 0.127 -> 0.119, profiles/r03_big_tile_threshold.txt —
+// 4-byte ones from 256 MiB: measured)
 inline size_t clo_big_tile_bytes(int elem_size) {   // CLO_RADIX_BIG_MIB: one threshold in MiB for both (A/B runs; read once)
 	static const size_t v = getenv("CLO_RADIX_BIG_MIB") ? (size_t) strtoull(getenv("CLO_RADIX_BIG_MIB"), nullptr, 10) << 20 : 0;
-	return v ? v : ((size_t) (elem_size == 8 ? 64 : 256) << 20);
+	return v ? v : ((size_t) (elem_size == 8 ? 32 : 256) << 20);
 }
 inline bool clo_radix_big_tiles(size_t n, int elem_size) { return elem_size >= 4 && n * (size_t) elem_size >= clo_big_tile_bytes(elem_size); }
 // The digit stream (one byte per element between two passes) goes with the

@@ -28,6 +28,14 @@ template <typename E, bool BIG> struct rw_shape {
 	static constexpr int ITEMS = TILE / THREADS;
 };
 
+// The histogram kernels also zero the hand-off words of the counter scan that follows them on the stream
+// (clo_radixw_offsets_lb_kernel: chunk sums with a "written" bit, the ticket): word i by the thread that owns
+// counter i of the launch — no launch of its own, and the scan of the pass before has long finished with them.
+__device__ __forceinline__ void rw_clear(unsigned* __restrict__ clear, unsigned clear_words, unsigned i) {
+	if (i < clear_words) clear[i] = 0u;
+}
+
+
 // One word per tile beside its histogram row: 1 when ONE bin holds the whole tile (every element of the
 // tile carries the same digit: small keys, a shared prefix, equal keys). The pass kernel reads it with a
 // scalar load and sends such a tile past its two local splits (clo_hip_radix4.hip: the split of a
@@ -47,7 +55,8 @@ __device__ __forceinline__ void rw_tile_info(unsigned h, unsigned count, unsigne
 template <typename E, int BITS, bool BIG>
 __global__ __launch_bounds__((rw_shape<E, BIG>::THREADS))
 void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
-	unsigned* __restrict__ thist, unsigned* __restrict__ tinfo, int aligned, clo_keyx kx) {
+	unsigned* __restrict__ thist, unsigned* __restrict__ tinfo, int aligned, clo_keyx kx,
+	unsigned* __restrict__ clear, unsigned clear_words) {
 	constexpr int R = 1 << BITS;
 	constexpr int ITEMS = rw_shape<E, BIG>::ITEMS;
 	constexpr int TILE = rw_shape<E, BIG>::TILE;
@@ -102,6 +111,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 		}
 		thist[(size_t) blockIdx.x * R + d] = h;
 		rw_tile_info(h, count, tinfo);
+		rw_clear(clear, clear_words, blockIdx.x * R + d);
 	}
 }
 
@@ -111,7 +121,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 template <int BITS, int ITEMS, int THREADS>   // ITEMS bytes per thread: 16 (4-byte elements) or 8; THREADS of the tile's shape
 __global__ __launch_bounds__(THREADS)
 void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist,
-	unsigned* __restrict__ tinfo) {
+	unsigned* __restrict__ tinfo, unsigned* __restrict__ clear, unsigned clear_words) {
 	constexpr int R = 1 << BITS;
 	constexpr int TILE = THREADS * ITEMS;
 	constexpr int COPIES = 32;
@@ -153,6 +163,7 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 		}
 		thist[(size_t) blockIdx.x * R + d] = h;
 		rw_tile_info(h, count, tinfo);
+		rw_clear(clear, clear_words, blockIdx.x * R + d);
 	}
 }
 
@@ -160,24 +171,31 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 // counts[tile][digit] -> offsets[tile][digit] in digit-major order:
 //   off[t][d] = sum_{d'<d} total[d'] + sum_{t'<t} cnt[t'][d]
 // (exactly upstream's exclusive scan of counters[num_wgs*d + wg]). A row of R
-// counters is contiguous, thread = digit: every access is coalesced. Three
-// small kernels: sums of chunks of RW_CHUNK tiles, a one-work-group scan of the
-// chunk sums, the walk over each chunk's tiles.
+// counters is contiguous, thread = digit: every access is coalesced.
 //
-// These kernels move a few MB and are bound by LATENCY: a thread that walks its
-// rows one after the other pays a round trip per row (round 2: 256 threads, one
-// thread per digit walking 128 rows, 8 loads in flight: 16-25 us for the three
-// launches, a quarter of a 2^24-key sort). Round 3: 1024 threads = G groups of R
-// threads, group g owns SUB = RW_CHUNK / G consecutive rows of the chunk and requests
-// ALL of them at once (SUB registers, fully unrolled); the groups meet in LDS. One
-// round trip per kernel instead of SUB: 15 / 19 us per pass at 2^24 / 2^28 keys. What is
-// left is three launches' worth of launch + one round trip each. Tried and dropped
-// (profiles/r03_hist_chain_probe.txt): the first two steps chained onto the
-// histogram kernel (write-through rows, arrival counters, the last arrival sums: the
-// histogram kernel, bound by its loads in flight, lost 0.07 ms per pass to the arrivals);
-// the chunk scan folded into the offsets kernel, every work-group re-deriving its chunk's
-// start from all chunk sums (25.7 instead of 19.3 us at 2^28, 19.3 instead of 15.1 at 2^24:
-// 128 KiB of L2 reads per work-group cost more than the launch they replace).
+// This step moves a few MB and is bound by LATENCY. History: round 2 walked the rows (a
+// round trip per row: 16-25 us for three launches — sums of chunks of RW_CHUNK tiles, a
+// one-work-group scan of the chunk sums, the walk over each chunk's tiles —, a quarter of a
+// 2^24-key sort); round 3 first gave every thread group SUB = RW_CHUNK / G consecutive rows,
+// requested all at once (13.5 / 16.6 us at 2^24 / 2^28 keys: three launches of a launch + one
+// round trip each, profiles/r03_kernel_timeline_2p24.txt), then made it ONE launch:
+//
+// work-group = chunk, in the order of a ticket. It sums its chunk's rows (all in registers), PUBLISHES the
+// chunk's digit sums — one word each, bit 31 = written, agent scope — and reads the sums of every chunk before
+// it: those never wait for anything before they publish, and the ticket says they have started, so the wait is
+// bounded by their one load and there is nothing to give up on (no chain: chunk c adds up c published rows, thread
+// group g the chunks g, g + G, ..., eight requests in flight). What no chunk can know without waiting for LATER
+// chunks is the digit bases (the totals of all smaller digits): the chunk with the last ticket has them when it
+// is done and leaves them in a row of their own (dbase); the pass kernel adds dbase[digit] to the offset it
+// reads — toff holds sum_{t' < t} cnt[t'][d] only. The hand-off words (sums, ticket) are zeroed by the histogram
+// kernel that precedes this one on the stream (rw_clear). 2^24 keys 0.240 -> 0.221 ms per sort, 2^25 0.409 ->
+// 0.385, 2^28 2.51 -> 2.46 (profiles/r03_counter_scan_one_launch.txt).
+// Tried and dropped on the way (profiles/r03_hist_chain_probe.txt): the chunk sums chained onto the
+// histogram kernel (write-through rows, arrival counters, the last arrival sums: the histogram kernel, bound by
+// its loads in flight, lost 0.07 ms per pass to the arrivals); the chunk scan folded into the offsets kernel
+// with every work-group re-deriving its chunk's start from ALL chunk sums, digit bases included (128 KiB of L2
+// reads per work-group cost more than the launch they replaced).
+//   partial: rows 0 .. chunks-1 the sums, row `chunks` word 0 the ticket, row chunks+1 dbase
 // ---------------------------------------------------------------------------
 constexpr int RW_CS_THREADS = 1024;
 template <int R> struct rw_cs {
@@ -186,114 +204,27 @@ template <int R> struct rw_cs {
 	static_assert(G * SUB == RW_CHUNK && G * R <= RW_CS_THREADS, "the groups tile the chunk");
 };
 
+constexpr unsigned RW_WRITTEN = 0x80000000u;
 template <int R>
 __global__ __launch_bounds__(RW_CS_THREADS)
-void clo_radixw_chunksum_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned* __restrict__ partial) {
+void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned chunks,
+	unsigned* __restrict__ partial, unsigned* __restrict__ toff) {
 	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
-	__shared__ unsigned s_p[G * R];
-	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R;
-	const unsigned t0 = blockIdx.x * RW_CHUNK;
-	const unsigned t1 = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
-	if (g < (unsigned) G) {
-		unsigned v[SUB];
-		#pragma unroll
-		for (int k = 0; k < SUB; ++k) {
-			const unsigned t = t0 + g * SUB + k;
-			v[k] = t < t1 ? thist[(size_t) t * R + d] : 0u;
-		}
-		unsigned sum = 0;
-		#pragma unroll
-		for (int k = 0; k < SUB; ++k) sum += v[k];
-		s_p[g * R + d] = sum;
-	}
-	__syncthreads();
-	if (tid < (unsigned) R) {
-		unsigned tot = 0;
-		#pragma unroll 8
-		for (int k = 0; k < G; ++k) tot += s_p[k * R + tid];
-		partial[(size_t) blockIdx.x * R + tid] = tot;
-	}
-}
-
-// Chunk sums -> for every (chunk, digit) the offset of the chunk's first tile:
-// digit base (exclusive scan of the digit totals over the digits) + count of
-// the digit in earlier chunks. ONE work-group: thread (g, d) owns a contiguous
-// range of chunks — all of them in registers at once when there are at most
-// RW_CS_REGS per thread (up to 128 chunks = 16 384 tiles with R = 256), else walked
-// twice —, the groups are combined through LDS. In place: partial[c][d] becomes that offset.
-constexpr int RW_CS_REGS = 32;
-template <int R>
-__global__ __launch_bounds__(RW_CS_THREADS)
-void clo_radixw_chunkscan_kernel(unsigned* __restrict__ partial, unsigned chunks) {
-	constexpr int G = RW_CS_THREADS / R;   // thread groups: each owns chunks / G chunks
-	__shared__ unsigned s_g[G * R], s_w[4];
+	constexpr int GA = RW_CS_THREADS / R;   // thread groups of the look-back (all threads)
+	constexpr int LB = 8;                   // published rows a thread asks for at once
+	__shared__ unsigned s_p[G * R], s_lb[GA * R], s_w[4], s_c;
 	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
-	const unsigned per = (chunks + G - 1) / G;
-	const unsigned c0 = g * per < chunks ? g * per : chunks, c1 = c0 + per < chunks ? c0 + per : chunks;
-	const bool in_regs = per <= (unsigned) RW_CS_REGS;   // (the same for every thread)
-	unsigned v[RW_CS_REGS];
-	unsigned sum = 0;
-	if (in_regs) {
-		#pragma unroll
-		for (int k = 0; k < RW_CS_REGS; ++k) v[k] = c0 + k < c1 ? partial[(size_t) (c0 + k) * R + d] : 0u;
-		#pragma unroll
-		for (int k = 0; k < RW_CS_REGS; ++k) sum += v[k];
-	} else {
-		#pragma unroll 8
-		for (unsigned c = c0; c < c1; ++c) sum += partial[(size_t) c * R + d];
-	}
-	s_g[g * R + d] = sum;
+	if (tid == 0) s_c = __hip_atomic_fetch_add(&partial[(size_t) chunks * R], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// (Requesting the rows of chunk blockIdx.x while the ticket is on its way, to load again when the ticket
+	// names another chunk, was slower — 7.9 instead of 5.9 us at 2^24 keys: work-groups of different XCDs do not
+	// start in the order of their numbers often enough.)
 	__syncthreads();
-	unsigned before = 0, tot = 0;
-	#pragma unroll 4
-	for (int k = 0; k < G; ++k) {
-		const unsigned x = s_g[k * R + d];
-		if ((unsigned) k < g) before += x;
-		tot += x;
-	}
-	// exclusive scan of the digit totals over the digits (threads 0..R-1 carry them)
-	const unsigned t = tid < (unsigned) R ? tot : 0u;
-	const unsigned incl = clo_wave_scan_inclusive<unsigned>(t, lane);
-	if (lane == 63 && wave < 4) s_w[wave] = incl;   // R <= 256: the digits sit in the first four waves
-	__syncthreads();
-	unsigned dbase = incl - t;
-	#pragma unroll
-	for (unsigned w = 0; w < 4; ++w) if (w < wave) dbase += s_w[w];
-	__syncthreads();
-	if (tid < (unsigned) R) s_g[tid] = dbase;   // (row 0 of s_g is free again: every thread has read it)
-	__syncthreads();
-	unsigned run = s_g[d] + before;
-	if (in_regs) {
-		#pragma unroll
-		for (int k = 0; k < RW_CS_REGS; ++k) {
-			if (c0 + k < c1) partial[(size_t) (c0 + k) * R + d] = run;
-			run += v[k];
-		}
-	} else {
-		#pragma unroll 8
-		for (unsigned c = c0; c < c1; ++c) {
-			const unsigned x = partial[(size_t) c * R + d];
-			partial[(size_t) c * R + d] = run;
-			run += x;
-		}
-	}
-}
-
-// Offsets of the tiles of one chunk: thread (g, d) owns SUB consecutive tiles, all requested at once.
-template <int R>
-__global__ __launch_bounds__(RW_CS_THREADS)
-void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tiles,
-	const unsigned* __restrict__ cbase, unsigned* __restrict__ toff) {
-	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
-	__shared__ unsigned s_a[G * R];
-	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R;
-	const unsigned t0 = blockIdx.x * RW_CHUNK;
+	const unsigned c = s_c;
+	const unsigned t0 = c * RW_CHUNK;
 	const unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
 	const bool active = g < (unsigned) G;
 	unsigned v[SUB];
-	unsigned run = 0;
 	if (active) {
-		run = cbase[(size_t) blockIdx.x * R + d];
 		#pragma unroll
 		for (int k = 0; k < SUB; ++k) {
 			const unsigned t = t0 + g * SUB + k;
@@ -302,11 +233,54 @@ void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 		unsigned own = 0;
 		#pragma unroll
 		for (int k = 0; k < SUB; ++k) own += v[k];
-		s_a[g * R + d] = own;
+		s_p[g * R + d] = own;
 	}
 	__syncthreads();
+	unsigned tot = 0;
+	if (tid < (unsigned) R) {
+		#pragma unroll 8
+		for (int k = 0; k < G; ++k) tot += s_p[k * R + tid];
+		__hip_atomic_store(&partial[(size_t) c * R + tid], tot | RW_WRITTEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	// the chunks before this one
+	unsigned acc = 0;
+	for (unsigned b = g; b < c; b += (unsigned) (GA * LB)) {
+		unsigned x[LB];
+		bool ok;
+		do {
+			#pragma unroll
+			for (int k = 0; k < LB; ++k) {
+				const unsigned cc = b + (unsigned) (k * GA);
+				x[k] = cc < c ? __hip_atomic_load(&partial[(size_t) cc * R + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RW_WRITTEN;
+			}
+			ok = true;
+			#pragma unroll
+			for (int k = 0; k < LB; ++k) ok = ok && (x[k] & RW_WRITTEN) != 0u;
+			if (!ok) __builtin_amdgcn_s_sleep(1);
+		} while (!ok);
+		#pragma unroll
+		for (int k = 0; k < LB; ++k) acc += x[k] & ~RW_WRITTEN;
+	}
+	s_lb[g * R + d] = acc;
+	__syncthreads();
+	unsigned before = 0;
+	#pragma unroll 8
+	for (int k = 0; k < GA; ++k) before += s_lb[k * R + d];
+	if (c + 1u == chunks) {   // (the same for the whole work-group) the digit bases: exclusive scan of the totals over the digits
+		const unsigned t = tid < (unsigned) R ? before + tot : 0u;
+		const unsigned incl = clo_wave_scan_inclusive<unsigned>(t, lane);
+		if (lane == 63 && wave < 4) s_w[wave] = incl;   // R <= 256: the digits sit in the first four waves
+		__syncthreads();
+		if (tid < (unsigned) R) {
+			unsigned dbase = incl - t;
+			#pragma unroll
+			for (unsigned w = 0; w < 4; ++w) if (w < wave) dbase += s_w[w];
+			partial[(size_t) (chunks + 1u) * R + tid] = dbase;
+		}
+	}
 	if (!active) return;
-	for (unsigned k = 0; k < g; ++k) run += s_a[k * R + d];
+	unsigned run = before;
+	for (unsigned k = 0; k < g; ++k) run += s_p[k * R + d];
 	#pragma unroll
 	for (int k = 0; k < SUB; ++k) {
 		const unsigned t = t0 + g * SUB + k;
@@ -315,8 +289,7 @@ void clo_radixw_offsets_kernel(const unsigned* __restrict__ thist, unsigned tile
 	}
 }
 
-// Up to RW_CHUNK tiles (one chunk): the three steps above in one launch of one
-// work-group — arrays of 2^13 .. 2^20 elements are launch-bound.
+// One tile (nothing to hand over, nobody to zero a ticket): the scan in one work-group, as in round 2.
 template <int R>
 __global__ __launch_bounds__(256)
 void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned* __restrict__ toff) {
@@ -363,15 +336,18 @@ void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned til
 // ---- the histogram / counter-scan steps for any digit width 1..8 (used by
 // the digit-pair passes of clo_hip_radix4.hip) ----
 
+unsigned clo_radixw_clear_words(int bits, unsigned tiles);
+
 template <typename E>
 static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift, unsigned mask, unsigned* thist, unsigned* tinfo,
-	unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
+	unsigned* partial, unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
 	const int aligned = (int) ((uintptr_t) in % 16 == 0);
+	const unsigned clear_words = partial ? clo_radixw_clear_words(bits, tiles) : 0u;
 	#define CLO_RW_TH(B) case B: \
 		if (big && sizeof(E) >= 4) hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B, (sizeof(E) >= 4)>), dim3(tiles), dim3(rw_shape<E, (sizeof(E) >= 4)>::THREADS), 0, s, \
-			(const E*) in, n, shift, mask, thist, tinfo, aligned, kx); \
+			(const E*) in, n, shift, mask, thist, tinfo, aligned, kx, partial, clear_words); \
 		else hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, B, false>), dim3(tiles), dim3(rw_shape<E, false>::THREADS), 0, s, \
-			(const E*) in, n, shift, mask, thist, tinfo, aligned, kx); \
+			(const E*) in, n, shift, mask, thist, tinfo, aligned, kx, partial, clear_words); \
 		break
 	switch (bits) {
 		CLO_RW_TH(1); CLO_RW_TH(2); CLO_RW_TH(3); CLO_RW_TH(4); CLO_RW_TH(5); CLO_RW_TH(6); CLO_RW_TH(7); CLO_RW_TH(8);
@@ -381,22 +357,24 @@ static int rw_launch_tilehist(const void* in, size_t n, int bits, unsigned shift
 	return (int) hipGetLastError();
 }
 
-// `big`: the tiles are those of clo_radix_big_tiles(n, elem_size) (clo_hip_radix_rank.h)
+// `big`: the tiles are those of clo_radix_big_tiles(n, elem_size) (clo_hip_radix_rank.h); `partial`: the
+// counter scan's workspace (clo_radixw_launch_offsets follows on the same stream), whose hand-off words this launch zeroes
 int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits, unsigned shift, unsigned mask,
-	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
+	unsigned* thist, unsigned* tinfo, unsigned* partial, unsigned tiles, bool big, clo_keyx kx, hipStream_t s) {
 	switch (elem_size) {
-		case 1: return rw_launch_tilehist<uint8_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
-		case 2: return rw_launch_tilehist<uint16_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
-		case 4: return rw_launch_tilehist<uint32_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
-		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tinfo, tiles, big, kx, s);
+		case 1: return rw_launch_tilehist<uint8_t>(in, n, bits, shift, mask, thist, tinfo, partial, tiles, big, kx, s);
+		case 2: return rw_launch_tilehist<uint16_t>(in, n, bits, shift, mask, thist, tinfo, partial, tiles, big, kx, s);
+		case 4: return rw_launch_tilehist<uint32_t>(in, n, bits, shift, mask, thist, tinfo, partial, tiles, big, kx, s);
+		case 8: return rw_launch_tilehist<uint64_t>(in, n, bits, shift, mask, thist, tinfo, partial, tiles, big, kx, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }
 
 // Histograms out of the digit stream (tiles of the shape `big` names).
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
-	unsigned* thist, unsigned* tinfo, unsigned tiles, bool big, hipStream_t s) {
-	#define CLO_RW_THB1(B, I, T) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T>), dim3(tiles), dim3(T), 0, s, dig, n, mask, thist, tinfo)
+	unsigned* thist, unsigned* tinfo, unsigned* partial, unsigned tiles, bool big, hipStream_t s) {
+	const unsigned clear_words = partial ? clo_radixw_clear_words(bits, tiles) : 0u;
+	#define CLO_RW_THB1(B, I, T) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T>), dim3(tiles), dim3(T), 0, s, dig, n, mask, thist, tinfo, partial, clear_words)
 	#define CLO_RW_THB(B) case B: \
 		if (!big) return CLO_HIP_EUNSUPPORTED;   /* (the stream goes with the big tiles) */ \
 		if (elem_size == 8) CLO_RW_THB1(B, 8, 1024); else CLO_RW_THB1(B, 16, 1024); \
@@ -411,10 +389,21 @@ int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int ele
 	return (int) hipGetLastError();
 }
 
-int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff, hipStream_t s) {
+// Words of `partial` the histogram launch zeroes for the scan: the chunk sums and the ticket's row (0: one tile, nothing to hand over).
+unsigned clo_radixw_clear_words(int bits, unsigned tiles) {
 	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
+	return tiles > 1 ? ((chunks + 1u) << bits) : 0u;   // (chunks + 1 <= tiles: every word has a thread of the launch)
+}
+// Rows of (1 << bits) words `partial` needs.
+size_t clo_radixw_partial_rows(size_t tiles) { return (tiles + RW_CHUNK - 1) / RW_CHUNK + 2; }
+
+// *dbase: null — toff holds the final offsets (one tile) —, or the row of digit bases the consumer adds to toff[tile][digit].
+int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff,
+	const unsigned** dbase, hipStream_t s) {
+	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
+	*dbase = nullptr;
 	#define CLO_RW_OFF1(B) case B: hipLaunchKernelGGL((clo_radixw_offsets1_kernel<(1 << B)>), dim3(1), dim3(256), 0, s, thist, tiles, toff); break
-	if (chunks == 1) {
+	if (tiles == 1) {
 		switch (bits) {
 			CLO_RW_OFF1(1); CLO_RW_OFF1(2); CLO_RW_OFF1(3); CLO_RW_OFF1(4); CLO_RW_OFF1(5); CLO_RW_OFF1(6); CLO_RW_OFF1(7); CLO_RW_OFF1(8);
 			default: return CLO_HIP_EUNSUPPORTED;
@@ -422,15 +411,14 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 		return (int) hipGetLastError();
 	}
 	#undef CLO_RW_OFF1
-	#define CLO_RW_OFF(B) case B: \
-		hipLaunchKernelGGL((clo_radixw_chunksum_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, partial); \
-		hipLaunchKernelGGL((clo_radixw_chunkscan_kernel<(1 << B)>), dim3(1), dim3(RW_CS_THREADS), 0, s, partial, chunks); \
-		hipLaunchKernelGGL((clo_radixw_offsets_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, (const unsigned*) partial, toff); break
+	#define CLO_RW_LB(B) case B: \
+		hipLaunchKernelGGL((clo_radixw_offsets_lb_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, chunks, partial, toff); break
 	switch (bits) {
-		CLO_RW_OFF(1); CLO_RW_OFF(2); CLO_RW_OFF(3); CLO_RW_OFF(4); CLO_RW_OFF(5); CLO_RW_OFF(6); CLO_RW_OFF(7); CLO_RW_OFF(8);
+		CLO_RW_LB(1); CLO_RW_LB(2); CLO_RW_LB(3); CLO_RW_LB(4); CLO_RW_LB(5); CLO_RW_LB(6); CLO_RW_LB(7); CLO_RW_LB(8);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
-	#undef CLO_RW_OFF
+	#undef CLO_RW_LB
+	*dbase = partial + ((size_t) (chunks + 1u) << bits);
 	return (int) hipGetLastError();
 }
 

@@ -87,7 +87,7 @@ def test_sweep_ticket_pools(gpu, monkeypatch, pools, kind, logn):
     like) and eight per-XCD pools give the same, correct order."""
     import cl_ops_amd as clo
     ctx, q = gpu
-    monkeypatch.setenv("CLO_RADIX_SWEEP", "1")            # (the library itself leaves this path above 512 tiles)
+    monkeypatch.setenv("CLO_RADIX_SWEEP", "1")            # (the library itself leaves this path above 256 tiles)
     monkeypatch.setenv("CLO_R1_POOLS", pools)
     n = (1 << logn) + 12345
     a = O.bench_rand(logn, kind, n)
@@ -95,6 +95,25 @@ def test_sweep_ticket_pools(gpu, monkeypatch, pools, kind, logn):
     got = s.with_host_data(a, q)
     s.close()
     assert np.array_equal(got, np.sort(a))
+
+
+@pytest.mark.parametrize("kind,n,opts", [("uint", (1 << 22) + 12345, None), ("uint", (1 << 26) + 999, None), ("ulong", (1 << 23) + 5, None),
+                                         ("uint", 8192 * 2 + 1, None), ("uint", 8192 * 129 + 3, None), ("uint", (1 << 23) + 1, "radix=4"),
+                                         ("ulong", (1 << 22) + 7, "radix=256")])
+def test_counter_scan_in_one_launch(gpu, monkeypatch, kind, n, opts):
+    """The chain-free passes' counter scan (ticketed chunks, published chunk sums, digit bases in
+    a row of their own): 2, 3, 129+ tiles, many chunks, both tile shapes, radix 4 / 16 / 256."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    monkeypatch.setenv("CLO_RADIX_SWEEP", "0")
+    logn = int(np.ceil(np.log2(n)))
+    a = O.bench_rand(logn, kind, n)
+    s = clo.Sorter("satradix", ctx, kind, options=opts)
+    got = s.with_host_data(a, q)
+    again = s.with_host_data(a[::-1].copy(), q)          # (the same workspace: hand-off words zeroed by the histogram)
+    s.close()
+    assert np.array_equal(got, np.sort(a))
+    assert np.array_equal(again, np.sort(a))
 
 
 # ----------------------------------------------------------------------------

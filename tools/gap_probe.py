@@ -2,12 +2,13 @@
 rocprofv3 --kernel-trace CSV. usage: python tools/gap_probe.py <dir with *_kernel_trace.csv> [kernels per sort]"""
 import csv
 import glob
+import os
 import sys
 
-f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)   # the newest run
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda r: r[0])
 rows = [r for r in rows if "clo_" in r[2]]
-per = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+per = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 rows = rows[len(rows) // 2 // per * per:]            # the second half: warm
 dur, gap, names = {}, {}, []
 for i, (s, e, n) in enumerate(rows):

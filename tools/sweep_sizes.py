@@ -50,9 +50,9 @@ def bench(kind, log2n):
     bd.close()
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "edge":   # around the switch between the two paths (512 .. 1024 tiles)
+if len(sys.argv) > 1 and sys.argv[1] == "edge":   # around the switch between the two paths
     for rep in range(2):
-        for kind, ls in (("u32", (21, 22, 23)), ("u64", (20, 21, 22, 23)), ("pairs", (20, 21, 22, 23))):
+        for kind, ls in (("u32", (17, 18, 19, 20, 21, 22, 23)), ("u64", (17, 18, 19, 20, 21, 22, 23)), ("pairs", (18, 20, 21, 22, 23))):
             for l in ls:
                 bench(kind, l)
     sys.exit(0)
