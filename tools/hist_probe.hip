@@ -27,6 +27,12 @@ __global__ void fill_kernel(unsigned* p, size_t words, unsigned mode) {
 __global__ void flush_kernel(vec4u* p, size_t n) {
 	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) p[i] = vec4u{ 1u, 2u, 3u, (unsigned) i };
 }
+// HIST_PROBE_CLEAN=1: the caches are filled by READING the junk — nothing dirty is left for the histogram's reads to push out
+__global__ void flush_read_kernel(const vec4u* p, size_t n, unsigned* sink) {
+	unsigned acc = 0;
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) { const vec4u x = p[i]; acc += x[0] ^ x[3]; }
+	if (acc == 0x1234567u) *sink = acc;
+}
 
 // MODE 0: 32 copies of dword counters (the shipped kernel); 1: 64 copies of packed 16-bit pairs (lane-private);
 // 2: 32 copies packed; 3: loads only; 4: adds only (synthetic digits)
@@ -113,6 +119,66 @@ void hist_kernel(const unsigned char* __restrict__ dig, unsigned tiles, unsigned
 	}
 }
 
+// Straight-line pipeline (round 3, second look): TPW consecutive tiles per work-group, the bytes of tile t + DIST requested
+// before tile t is counted, every load unconditional (addresses clamped) and the loop fully unrolled, so that the
+// compiler can count what is outstanding (the TPW variants above end up behind s_waitcnt vmcnt(0): their prefetch sits
+// in a branch). TWO: two counter arrays, the next one zeroed while this one is reduced (one barrier less per tile).
+template <int TPW, int DIST, bool TWO>
+__global__ __launch_bounds__(1024)
+void hist_pipe_kernel(const unsigned char* __restrict__ dig, unsigned tiles, unsigned* __restrict__ thist) {
+	constexpr int THREADS = 1024, COPIES = 32, WORDS = 256 * COPIES;
+	__shared__ __attribute__((aligned(16))) unsigned s_cnt[TWO ? 2 * WORDS : WORDS];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, cp = lane & (COPIES - 1);
+	const unsigned tile0 = blockIdx.x * TPW;
+	vec4u buf[DIST + 1];
+	#pragma unroll
+	for (int t = 0; t < DIST; ++t) {
+		const unsigned tl = tile0 + t < tiles ? tile0 + t : tiles - 1;
+		buf[t] = reinterpret_cast<const vec4u*>(dig + (size_t) tl * TILE)[tid];
+	}
+	if (TWO) {
+		for (unsigned i = tid; i < (unsigned) (WORDS / 4); i += THREADS) reinterpret_cast<vec4u*>(s_cnt)[i] = vec4u{ 0u, 0u, 0u, 0u };
+	}
+	#pragma unroll
+	for (int t = 0; t < TPW; ++t) {
+		unsigned* cnt = s_cnt + (TWO ? (t & 1) * WORDS : 0);
+		if (t + DIST < TPW) {
+			const unsigned tl = tile0 + t + DIST < tiles ? tile0 + t + DIST : tiles - 1;
+			buf[(t + DIST) % (DIST + 1)] = reinterpret_cast<const vec4u*>(dig + (size_t) tl * TILE)[tid];
+		}
+		if (!TWO) {
+			for (unsigned i = tid; i < (unsigned) (WORDS / 4); i += THREADS) reinterpret_cast<vec4u*>(cnt)[i] = vec4u{ 0u, 0u, 0u, 0u };
+		}
+		__syncthreads();
+		const vec4u v = buf[t % (DIST + 1)];
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			#pragma unroll
+			for (int b = 0; b < 4; ++b) atomicAdd(&cnt[(((v[q] >> (8 * b)) & 255u) << 5) + cp], 1u);
+		}
+		__syncthreads();
+		if (TWO && t + 1 < TPW) {   // the other array, for the next tile (its last reader finished before the barrier above)
+			unsigned* nxt = s_cnt + ((t + 1) & 1) * WORDS;
+			for (unsigned i = tid; i < (unsigned) (WORDS / 4); i += THREADS) reinterpret_cast<vec4u*>(nxt)[i] = vec4u{ 0u, 0u, 0u, 0u };
+		}
+		if (tid < 256u && tile0 + t < tiles) {
+			const vec4u* row = reinterpret_cast<const vec4u*>(&cnt[tid * COPIES]);
+			unsigned h = 0;
+			#pragma unroll
+			for (int k = 0; k < COPIES / 4; ++k) {
+				const vec4u x = row[(k + tid) & (COPIES / 4 - 1)];
+				h += x[0] + x[1] + x[2] + x[3];
+			}
+			thist[(size_t) (tile0 + t) * 256 + tid] = h;
+		}
+		if (!TWO && t + 1 < TPW) __syncthreads();
+	}
+}
+template <int TPW, int DIST, bool TWO>
+void launch_pipe(const unsigned char* dig, unsigned tiles, unsigned* thist, hipStream_t s) {
+	hipLaunchKernelGGL((hist_pipe_kernel<TPW, DIST, TWO>), dim3((tiles + TPW - 1) / TPW), dim3(1024), 0, s, dig, tiles, thist);
+}
+
 // Wave-private counting without LDS atomics where a wave's lanes agree: lanes that hold the same byte value are
 // found with one pass of v_cmp per DISTINCT value (skewed inputs); kept out: uniform bytes have ~60 distinct per 64.
 
@@ -133,6 +199,16 @@ int main(int argc, char** argv) {
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	const variant vs[] = {
 		{ "1024x16 u32x32 (shipped)", launch<1024, 0, 1> },
+		{ "pipe 2 tiles/wg, 1 ahead", launch_pipe<2, 1, false> },
+		{ "pipe 4 tiles/wg, 1 ahead", launch_pipe<4, 1, false> },
+		{ "pipe 4 tiles/wg, 2 ahead", launch_pipe<4, 2, false> },
+		{ "pipe 8 tiles/wg, 1 ahead", launch_pipe<8, 1, false> },
+		{ "pipe 8 tiles/wg, 2 ahead", launch_pipe<8, 2, false> },
+		{ "pipe 8 tiles/wg, 3 ahead", launch_pipe<8, 3, false> },
+		{ "pipe 16 tiles/wg, 2 ahead", launch_pipe<16, 2, false> },
+		{ "pipe 4 tiles/wg, 2 ahead, 2 arrays", launch_pipe<4, 2, true> },
+		{ "pipe 8 tiles/wg, 2 ahead, 2 arrays", launch_pipe<8, 2, true> },
+		{ "pipe 16 tiles/wg, 2 ahead, 2 arrays", launch_pipe<16, 2, true> },
 		{ "1024x16 packed16x64", launch<1024, 1, 1> },
 		{ "1024x16 packed16x32", launch<1024, 2, 1> },
 		{ "1024x16 loads only", launch<1024, 3, 1> },
@@ -153,6 +229,8 @@ int main(int argc, char** argv) {
 		{ "256x64 adds only", launch<256, 4, 1> },
 		{ "256x64 packed16x32, 2 tiles/wg", launch<256, 2, 2> },
 	};
+	const bool clean = getenv("HIST_PROBE_CLEAN") != nullptr;
+	if (clean) hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, s, junk, junk_bytes / 16);
 	std::vector<unsigned> h_ref((size_t) tiles * 256), h_got((size_t) tiles * 256);
 	for (unsigned mode = 0; mode < 3; ++mode) {
 		hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, s, (unsigned*) dig, n / 4, mode);
@@ -162,7 +240,8 @@ int main(int argc, char** argv) {
 			const int reps = 6;
 			CK(hipMemsetAsync(thist, 0xff, (size_t) tiles * 1024, s));
 			for (int r = 0; r < reps; ++r) {
-				hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, s, junk, junk_bytes / 16);   // what a pass kernel leaves in the caches: not the stream
+				if (clean) hipLaunchKernelGGL(flush_read_kernel, dim3(4096), dim3(256), 0, s, (const vec4u*) junk, junk_bytes / 16, ref);
+				else hipLaunchKernelGGL(flush_kernel, dim3(4096), dim3(256), 0, s, junk, junk_bytes / 16);   // what a pass kernel leaves in the caches: not the stream, and dirty
 				CK(hipEventRecord(e0, s));
 				vs[i].launch(dig, tiles, thist, s);
 				CK(hipEventRecord(e1, s));
