@@ -185,7 +185,9 @@ CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, 
 	char* sort_options = shard_options(options, &slices, err);
 	if (!sort_options) return NULL;
 	if (slices == 0) slices = 4;
-	if (world == 1) slices = 1;
+	/* (one rank has nothing to exchange; CLO_SHARD_TEST_EXCHANGE_ALONE keeps the slices and sends the rank's keys
+	 * to itself through the whole protocol: the only way to run the exchange over RCCL on a one-GPU box) */
+	if (world == 1 && !getenv("CLO_SHARD_TEST_EXCHANGE_ALONE")) slices = 1;
 	int sbits = 0;
 	while ((1 << sbits) < slices) ++sbits;
 	CloShardSort* ss = (CloShardSort*) calloc(1, sizeof(*ss));
@@ -280,7 +282,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 	const size_t bytes = numel * (size_t) es;
 	ss->have_phase = 0;
 
-	if (G == 1) {   /* nothing to exchange: a copy and the local sort */
+	if (G == 1 && S == 1) {   /* nothing to exchange: a copy and the local sort */
 		if (numel > 0 && bytes > ccl_buffer_get_size(data_in)) {
 			clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "numel (%zu) exceeds the size of the device buffer", numel);
 			return NULL;

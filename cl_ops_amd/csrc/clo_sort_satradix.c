@@ -340,7 +340,11 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 	st = clo_devbuf_reserve(&r->in, numel * (size_t) es);
 	if (st == 0) st = clo_devbuf_reserve(&r->part, numel * (size_t) es);
 	if (st == 0) st = clo_devbuf_reserve(&r->counts, sizeof(counts));
-	if (st == 0) st = clo_devbuf_reserve(&r->msd_ws, clo_hip_msd_workspace_bytes(chunk, es, SAT_PIPE_BITS));
+	if (st == 0) {   /* (not monotone in the size — the tile shape changes with it: the last chunk may need more than a full one) */
+		const size_t last = numel - (size_t) (nchunks - 1) * chunk;
+		const size_t w_full = clo_hip_msd_workspace_bytes(chunk, es, SAT_PIPE_BITS), w_last = clo_hip_msd_workspace_bytes(last, es, SAT_PIPE_BITS);
+		st = clo_devbuf_reserve(&r->msd_ws, w_full > w_last ? w_full : w_last);
+	}
 	if (st != 0) goto finish;
 	p.r = r; p.out_host = (char*) data_out; p.es = (size_t) es;
 	void* s_in = ccl_queue_get_stream(cq_comm);

@@ -297,6 +297,31 @@ def test_c_shard_sort_in_slices(gpu, tmp_path, etype, n, options, slices):
         assert bytes_in == int(np.count_nonzero((ins[other] >> ins[other].dtype.type(8 * es - 1)) == r)) * es
 
 
+@pytest.mark.parametrize("etype,options,slices", [("uint", None, 4), ("ulong", "slices=8", 8), ("uint", "slices=2", 2)])
+def test_c_shard_sort_slices_over_real_rccl_world_one(gpu, monkeypatch, etype, options, slices):
+    """One rank, but everything else as on a node: the RCCL communicator, the slices' grouped
+    send/recv on the transfer stream, the events between it and the exec stream, the slice
+    sorts in place. (RCCL refuses two ranks on one device: more ranks go through the staged
+    transport above.)"""
+    import torch
+    from cl_ops_amd.multigpu import CShardedSorter
+    monkeypatch.setenv("CLO_SHARD_TEST_EXCHANGE_ALONE", "1")      # (one rank alone would skip the exchange)
+    dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
+    n = (1 << 23) + 4099
+    a = np.random.default_rng(17).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    t = torch.from_numpy(a.view(tdt).copy()).cuda()
+    s = CShardedSorter(etype, 0, options=options)
+    for rep in range(2):                                   # (the second call reuses every buffer and event)
+        out, m = s.sort(t)
+        s.check()
+        torch.cuda.synchronize()
+        assert m == n and np.array_equal(out.cpu().numpy().view(dt), np.sort(a))
+        x = s.ss.exchange()
+        assert x["slices"] == slices and x["bytes_out"] == 0 and x["bytes_in"] == 0      # nothing leaves the only rank
+    assert np.array_equal(t.cpu().numpy().view(dt), a)
+    s.close()
+
+
 @pytest.mark.parametrize("options,slices", [(None, 4), ("slices=8", 8)])
 def test_c_shard_sort_four_ranks_on_one_gpu(gpu, tmp_path, options, slices):
     """Four ranks (2 bucket bits + 2 or 3 slice bits: the partition's two-split form, 4 and 5 bits) on the
@@ -326,7 +351,8 @@ def test_c_shard_ranks_fail_together(gpu, tmp_path, fail):
 # clo_sort_with_host_data with the transfers overlapped
 # ----------------------------------------------------------------------------
 
-@pytest.mark.parametrize("kind,n", [("uint", (1 << 24) + 12345), ("ulong", 1 << 24), ("pairs", (1 << 24) + 7), ("uint", 1 << 25)])
+@pytest.mark.parametrize("kind,n", [("uint", (1 << 24) + 12345), ("ulong", 1 << 24), ("pairs", (1 << 24) + 7), ("uint", 1 << 25),
+                                    ("ulong", (1 << 25) + 13)])   # (the last chunk is of the other tile shape than the full ones)
 @pytest.mark.parametrize("two_queues", [False, True])
 def test_sort_host_data_pipelined_equals_blocking(gpu, monkeypatch, kind, n, two_queues):
     """With CLO_SORT_HOST_PIPELINE=1 satradix's host-data path splits every chunk by the top 4 key bits
