@@ -158,14 +158,14 @@ def contract_bytes_per_elem(workload, radix, log2n):
 
 
 DOMINANT_KERNEL = {"satradix_u32": "radix_pass", "satradix_pairs": "radix_pass", "satradix_u64": "radix_pass",
-                   "scan": "scan", "abitonic": "bitonic_tile", "sbitonic": "bitonic_step"}
+                   "scan": "scan", "abitonic": "bitonic_tile", "sbitonic": "bitonic_presort"}
 
 # kernel families a step may launch (the labels of clo_hip_timing_read, include/clo_hip.h)
 FAMILIES = {
     "satradix": ["radix_ghist", "radix_sweep", "radix_hist", "radix_offsets", "radix_pass", "radix_small"],
     "scan": ["scan"],
     "abitonic": ["bitonic_presort", "bitonic_tile", "bitonic_strided", "bitonic_strided2"],
-    "sbitonic": ["bitonic_step"],
+    "sbitonic": ["bitonic_presort", "bitonic_tile", "bitonic_strided", "bitonic_strided2", "bitonic_step"],   # (the tiled schedule; CLO_SBITONIC_STEPS=1: bitonic_step)
 }
 
 
@@ -177,7 +177,7 @@ def min_moved_bytes(label, n, es, radix, key_bits=None):
     pass_bits = 2 * bits if bits <= 4 else bits
     key_bits = key_bits or 8 * es
     passes = -(-key_bits // pass_bits)
-    big = es >= 4 and n * es >= ((64 if es == 8 else 256) << 20)   # clo_radix_big_tiles (clo_hip_radix_rank.h)
+    big = es >= 4 and n * es >= ((32 if es == 8 else 256) << 20)   # clo_radix_big_tiles (clo_hip_radix_rank.h)
     tile = (1024 if big else 512) * (8 if es == 8 else 16)
     counters = -(-n // tile) * (1 << pass_bits) * 4          # one row of counters per tile
     sweep_counters = -(-n // (512 * (8 if es == 8 else 16))) * (1 << pass_bits) * 4   # (the sweeps keep 512-thread tiles)

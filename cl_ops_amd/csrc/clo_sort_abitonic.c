@@ -38,7 +38,7 @@ static CCLEvent* clo_sort_abitonic_sort_with_device_data(CloSort* sorter, CCLQue
 	GError** err) {
 	(void) lws_max;
 	clo_sort_abitonic_data* data = (clo_sort_abitonic_data*) clo_sort_get_data(sorter);
-	return clo_bitonic_run(sorter, &data->state, 1, "abit_tile", "abit_copy",
+	return clo_bitonic_run(sorter, &data->state, 1, 0, "abit_tile", "abit_copy",
 		cq_exec, cq_comm, data_in, data_out, numel, err);
 }
 

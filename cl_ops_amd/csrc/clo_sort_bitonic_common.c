@@ -29,7 +29,7 @@ static int bitonic_enqueue(void* user, void* stream) {
 		: clo_hip_bitonic_simple(c->work, c->numel, ks->elem_size, ks->key_shift, ks->key_bits, ks->key_size, ks->key_kind, ks->descending, c->launches, stream);
 }
 
-CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, const char* evt_name,
+CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, int one_name, const char* evt_name,
 	const char* copy_evt_name, CCLQueue* cq_exec, CCLQueue* cq_comm, CCLBuffer* data_in,
 	CCLBuffer* data_out, size_t numel, GError** err) {
 
@@ -73,10 +73,15 @@ CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, 
 		{ "bitonic_step", "sbitonic_ndrange" }, { "bitonic_presort", "abit_presort" }, { "bitonic_tile", "abit_merge" },
 		{ "bitonic_strided", "abit_strided" }, { "bitonic_strided2", "abit_strided2" }
 	};
+	/* (sbitonic: every launch under the one name upstream gives its events, whatever schedule runs) */
+	static const clo_kname knames_one[] = {
+		{ "bitonic_step", "sbitonic_ndrange" }, { "bitonic_presort", "sbitonic_ndrange" }, { "bitonic_tile", "sbitonic_ndrange" },
+		{ "bitonic_strided", "sbitonic_ndrange" }, { "bitonic_strided2", "sbitonic_ndrange" }
+	};
 	const int per_kernel = ccl_queue_is_profiling(cq_exec) && numel > 1;
 	clo_kernel_events ke;
 	if (per_kernel) {
-		clo_kernel_events_install(&ke, cq_exec, knames, sizeof(knames) / sizeof(knames[0]), evt_name);
+		clo_kernel_events_install(&ke, cq_exec, one_name ? knames_one : knames, sizeof(knames) / sizeof(knames[0]), evt_name);
 	} else {
 		evt = ccl_queue_begin_command(cq_exec, evt_name, err);
 		if (!evt) return NULL;

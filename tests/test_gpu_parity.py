@@ -432,13 +432,15 @@ def test_satradix_repeated_calls_changing_buffers_and_sizes(gpu, n):
     s.close()
 
 
-def test_sbitonic_graph_replay_sees_new_data_and_new_buffers(gpu):
-    """From the third call with the same (buffer, numel, queue) on, sbitonic
+def test_sbitonic_graph_replay_sees_new_data_and_new_buffers(gpu, monkeypatch):
+    """The one-launch-per-step schedule (CLO_SBITONIC_STEPS=1; sbitonic's default is the tiled
+    schedule): from the third call with the same (buffer, numel, queue) on it
     replays its 136 launches from a captured graph: new contents, another
     buffer, another size and a profiling run in between must all come out sorted."""
     import cl_ops_amd as clo
     from cl_ops_amd._hip import lib
     ctx, q = gpu
+    monkeypatch.setenv("CLO_SBITONIC_STEPS", "1")
     n = 1 << 16
     s = clo.Sorter("sbitonic", ctx, "uint")
     b1, b2 = clo.Buffer(ctx, 4 * n), clo.Buffer(ctx, 4 * n)

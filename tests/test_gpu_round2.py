@@ -142,26 +142,40 @@ def test_profiling_queue_gets_one_event_per_kernel(gpu):
     assert "clo_scan_blelloch_wgscan" in prof2.aggregates()
     sc.close()
 
-    s = clo.Sorter("sbitonic", ctx, "uint")
-    src.write(qp, a[:1 << 10])
-    clo.Profiler(qp).duration_ns()
-    s.with_device_data(qp, src, None, 1 << 10)
-    s.with_device_data(qp, src, None, 1 << 10)   # a repeat: no graph replay on a profiling queue
-    prof3 = clo.Profiler(qp)
-    prof3.duration_ns()
-    assert set(prof3.aggregates()) == {"sbitonic_ndrange"}
-    assert np.array_equal(src.read(qp, np.uint32, 1 << 10), np.sort(a[:1 << 10]))
-    s.close()
+    for steps in ("1", None):                     # one launch per step, then the default tiled schedule: one event name either way
+        if steps:
+            os.environ["CLO_SBITONIC_STEPS"] = steps
+        else:
+            os.environ.pop("CLO_SBITONIC_STEPS", None)
+        try:
+            s = clo.Sorter("sbitonic", ctx, "uint")
+            m = 1 << 16
+            src.write(qp, a[:m])
+            clo.Profiler(qp).duration_ns()
+            s.with_device_data(qp, src, None, m)
+            s.with_device_data(qp, src, None, m)   # a repeat: no graph replay on a profiling queue
+            prof3 = clo.Profiler(qp)
+            prof3.duration_ns()
+            assert set(prof3.aggregates()) == {"sbitonic_ndrange"}
+            assert np.array_equal(src.read(qp, np.uint32, m), np.sort(a[:m]))
+            s.close()
+            if steps:
+                prof3.close()
+        finally:
+            os.environ.pop("CLO_SBITONIC_STEPS", None)
     for x in (prof, prof2, prof3, src, dst, qp):
         x.close()
 
 
-def test_sbitonic_repeats_on_an_uncapturable_stream(gpu):
-    """Graph replay is best effort: the legacy NULL stream (a queue adopted from
-    torch's default stream) cannot be captured — repeated identical sorts on it
-    must still sort."""
+@pytest.mark.parametrize("steps", [True, False])
+def test_sbitonic_repeats_on_an_uncapturable_stream(gpu, monkeypatch, steps):
+    """Graph replay (the one-launch-per-step schedule, CLO_SBITONIC_STEPS=1) is best effort: the
+    legacy NULL stream (a queue adopted from torch's default stream) cannot be captured —
+    repeated identical sorts on it must still sort. The default tiled schedule beside it."""
     import cl_ops_amd as clo
     ctx, _ = gpu
+    if steps:
+        monkeypatch.setenv("CLO_SBITONIC_STEPS", "1")
     q0 = clo.Queue(ctx, stream=0)
     n = 1 << 12
     buf = clo.Buffer(ctx, n * 4)
