@@ -116,6 +116,32 @@ def test_counter_scan_in_one_launch(gpu, monkeypatch, kind, n, opts):
     assert np.array_equal(again, np.sort(a))
 
 
+def test_two_sorters_on_two_queues_at_once(gpu):
+    """Two sorts in flight on two streams: the counter scans' tickets and hand-off words live in
+    each sorter's own workspace, and no work-group waits for one that has not started."""
+    import cl_ops_amd as clo
+    ctx, q = gpu
+    q2 = clo.Queue(ctx)
+    n1, n2 = (1 << 25) + 3, (1 << 24) + 77
+    a1, a2 = O.bench_rand(25, "uint", n1), O.bench_rand(24, "ulong", n2)
+    s1, s2 = clo.Sorter("satradix", ctx, "uint"), clo.Sorter("satradix", ctx, "ulong")
+    b1, o1 = clo.Buffer(ctx, a1.nbytes), clo.Buffer(ctx, a1.nbytes)
+    b2, o2 = clo.Buffer(ctx, a2.nbytes), clo.Buffer(ctx, a2.nbytes)
+    b1.write(q, a1)
+    b2.write(q2, a2)
+    q.finish()
+    q2.finish()
+    for _ in range(6):                       # (nothing synchronises in between: the kernels of both interleave)
+        s1.with_device_data(q, b1, o1, n1)
+        s2.with_device_data(q2, b2, o2, n2)
+    q.finish()
+    q2.finish()
+    assert np.array_equal(o1.read(q, np.uint32, n1), np.sort(a1))
+    assert np.array_equal(o2.read(q2, np.uint64, n2), np.sort(a2))
+    for x in (s1, s2, b1, o1, b2, o2, q2):
+        x.close()
+
+
 # ----------------------------------------------------------------------------
 # floating-point scans: the exclusive offset of a thread is never `inclusive - own`
 # ----------------------------------------------------------------------------
