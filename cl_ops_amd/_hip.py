@@ -39,6 +39,7 @@ _sig("clo_hip_set_device", ci, ci)
 _sig("clo_hip_get_device", ci, C.POINTER(ci))
 _sig("clo_hip_get_device_props", ci, ci, C.POINTER(DeviceProps))
 _sig("clo_hip_stream_create", ci, C.POINTER(vp))
+_sig("clo_hip_stream_create_high_priority", ci, C.POINTER(vp))
 _sig("clo_hip_stream_destroy", ci, vp)
 _sig("clo_hip_stream_synchronize", ci, vp)
 _sig("clo_hip_malloc", ci, C.POINTER(vp), sz)

@@ -457,7 +457,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 		evt = clo_sort_with_device_data(ss->sorter, cq_exec, NULL, ss->recv, NULL, total, 0, err);
 		if (!evt) { shard_abort(ss); return NULL; }
 	} else {
-		if (!ss->comm_stream && (st = clo_hip_stream_create(&ss->comm_stream)) != 0) {
+		if (!ss->comm_stream && (st = clo_hip_stream_create_high_priority(&ss->comm_stream)) != 0) {
 			clo_hip_failed(st, err, "hipStreamCreate"); shard_abort(ss); return NULL;
 		}
 		st = record(&ss->ev_part, stream);

@@ -114,6 +114,16 @@ int clo_hip_stream_create(void** stream) {
 	*stream = (e == hipSuccess) ? (void*) s : nullptr;
 	return (int) e;
 }
+int clo_hip_stream_create_high_priority(void** stream) {
+	if (!stream) return CLO_HIP_EARGS;
+	int least = 0, greatest = 0;   // (numerically lower = higher priority)
+	hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+	if (e != hipSuccess) return (int) e;
+	hipStream_t s;
+	e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest);
+	*stream = (e == hipSuccess) ? (void*) s : nullptr;
+	return (int) e;
+}
 int clo_hip_stream_destroy(void* stream) { return (int) hipStreamDestroy((hipStream_t) stream); }
 int clo_hip_stream_synchronize(void* stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
 

@@ -48,6 +48,9 @@ int clo_hip_get_device(int* device);
 int clo_hip_get_device_props(int device, clo_hip_device_props* props);
 
 int clo_hip_stream_create(void** stream);
+/* The same with the device's highest stream priority: for the transfer stream of the sharded sort, whose (few)
+ * work-groups should be dispatched ahead of the sort kernels' that fill the device beside them. */
+int clo_hip_stream_create_high_priority(void** stream);
 int clo_hip_stream_destroy(void* stream);
 int clo_hip_stream_synchronize(void* stream);
 
