@@ -99,7 +99,9 @@ def test_sweep_ticket_pools(gpu, monkeypatch, pools, kind, logn):
 
 @pytest.mark.parametrize("kind,n,opts", [("uint", (1 << 22) + 12345, None), ("uint", (1 << 26) + 999, None), ("ulong", (1 << 23) + 5, None),
                                          ("uint", 8192 * 2 + 1, None), ("uint", 8192 * 129 + 3, None), ("uint", (1 << 23) + 1, "radix=4"),
-                                         ("ulong", (1 << 22) + 7, "radix=256")])
+                                         ("ulong", (1 << 22) + 7, "radix=256"), ("uint", 8192 * 300 + 11, "radix=2"),
+                                         ("uint", 8192 * 700 + 5, "radix=8"), ("uint", 8192 * 300 + 1, "radix=32"),
+                                         ("ulong", 4096 * 520 + 3, "radix=64"), ("uint", 8192 * 260 + 9, "radix=128")])
 def test_counter_scan_in_one_launch(gpu, monkeypatch, kind, n, opts):
     """The chain-free passes' counter scan (ticketed chunks, published chunk sums, digit bases in
     a row of their own): 2, 3, 129+ tiles, many chunks, both tile shapes, radix 4 / 16 / 256."""
