@@ -795,6 +795,7 @@ int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_s
 // ---------------------------------------------------------------------------
 constexpr int GSEL_THREADS = 256;
 constexpr int GSEL_STAGE = 2048;   // a multiple of GSEL_THREADS: a work-group's elements lie in ONE stage
+static_assert(GSEL_STAGE % GSEL_THREADS == 0 && GSEL_THREADS % 4 == 0, "a work-group's elements lie in one stage, at a 16-byte boundary of its keys");
 
 template <typename E>
 __device__ __forceinline__ unsigned long long gsel_key(E e, const key_desc& kd) {
