@@ -328,7 +328,9 @@ inline size_t clo_big_tile_bytes(int elem_size) {   // CLO_RADIX_BIG_MIB: one th
 inline bool clo_radix_big_tiles(size_t n, int elem_size) { return elem_size >= 4 && n * (size_t) elem_size >= clo_big_tile_bytes(elem_size); }
 // The digit stream (one byte per element between two passes) goes with the
 // big tiles: on 8 192-element tiles (arrays that sit in the last-level cache) its extra
-// writes cost more than the histogram's shorter read saves (2^25 uint32: 0.471 vs 0.421 ms).
+// writes cost more than the histogram's shorter read saves (2^25 uint32: 0.471 vs 0.421 ms in round 2;
+// re-measured in round 3 after the counter scan became one launch: 2^22 0.113 vs 0.108, 2^24 0.224 vs 0.222,
+// 2^25 0.440 vs 0.389 — runs of 32 digit bytes per digit pair and tile are sub-line writes).
 inline bool clo_radix_digit_stream(size_t n, int elem_size) { return clo_radix_big_tiles(n, elem_size); }
 __host__ __device__ inline size_t clo_pair_tile_elems(int elem_size, bool big) {
 	return (size_t) ((big && elem_size >= 4) ? 1024 : 512) * (elem_size == 8 ? 8 : 16);
