@@ -91,6 +91,8 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="both", choices=["weak", "strong", "both"],
                     help="N > 1: which legs to run (both = weak + strong + the uint64 leg of config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1: the headline line only, without the short legs of the other BASELINE configs (profiler runs)")
     ap.add_argument("--cpu-sample-log2n", type=int, default=None)
     ap.add_argument("--exchange", default="c", choices=["torch", "c"],
                     help="N > 1: the sort through the library's own C API over RCCL (include/clo_shard.h: "
@@ -210,7 +212,8 @@ def load_traffic(workload):
     fams = dict(d.get("families") or {})
     if not fams and d.get("hbm_bytes_per_launch"):           # round-1 file: the dominant kernel only
         fams = {DOMINANT_KERNEL[workload]: {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"]}}
-    return fams, {"log2n": d.get("log2n"), "source": d.get("source")}
+    return fams, {"log2n": d.get("log2n"), "source": d.get("source"), "kernels_sha16": d.get("kernels_sha16"),
+                  "source_head": d.get("source_head")}
 
 
 def cpu_baseline(workload, host_input, radix, sample_log2n):
@@ -368,33 +371,69 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
                     name="leg"):
     """K timed distributed sorts of n_local keys per rank; returns the leg's record
     (on every rank; only rank 0's is printed)."""
+    wd = _Watchdog(watchdog, "rank %d, leg %s" % (rank, name))
+    try:
+        return _run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix, exchange, slices, watchdog, name)
+    finally:
+        wd.done()
+
+
+def _run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_rank, radix, exchange, slices, watchdog, name):
     torch, dist = be.torch, be.dist
     from cl_ops_amd.multigpu import ShardedSorter
-    wd = _Watchdog(watchdog, "rank %d, leg %s" % (rank, name))
     es = 4 if etype == "uint" else 8
     workload = "satradix_u32" if es == 4 else "satradix_u64"
     host = make_input(workload, n_local, seed + rank)
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to(be.device)
     sharded, fallback = None, None
     if exchange == "c" and not be.dry:
-        # The C driver over RCCL (the product path). Should it not come up on this node — it has never run on more than
-        # one RCCL rank before the first multi-GPU run — every rank falls back to the Python driver TOGETHER (an all-reduce
-        # of "I have it") and the line says so: a scaling curve on the second path beats no curve.
+        # The C driver over RCCL (the product path). It has never run on more than one RCCL rank before the first
+        # multi-GPU run, so it has to prove itself before the legs depend on it: construction, then ONE small probe sort
+        # (2^22 keys per rank, the smallest size that travels in slices: count all-gather + sliced send/recv on the second stream + slice sorts)
+        # under a short watchdog of its own, then an all-reduce(MIN) of "mine worked". Any rank that failed takes every
+        # rank to the Python driver TOGETHER, and the line says so: a scaling curve on the second path beats no curve.
+        # A probe that hangs inside RCCL cannot be agreed upon: its watchdog ends the rank (exit 3, a plain exit).
         from cl_ops_amd.multigpu import CShardedSorter
+        probe_wd = _Watchdog(min(watchdog, 120.0) if watchdog and watchdog > 0 else 0.0, "rank %d, C-driver probe sort of leg %s" % (rank, name))
         try:
             sharded = CShardedSorter(etype, local_rank, options="radix=%d%s" % (radix, ",slices=%d" % slices if slices else ""))
+            if os.environ.get("CLO_BENCH_FAIL_PROBE") == str(rank):      # (tests/test_bench_launch.py: the fallback itself)
+                raise RuntimeError("probe failure injected on rank %d" % rank)
+            pn = 1 << 22
+            ph = make_input(workload, pn, seed + 977 + rank)
+            pt = torch.from_numpy(ph.view(np.int32 if es == 4 else np.int64)).to(be.device)
+            probe = CShardedSorter(etype, local_rank, options="radix=%d,slices=2" % radix, transport=sharded.transport)
+            try:
+                po, pm = probe.sort(pt, pn)
+                probe.check()
+                be.sync()
+                pg = po[:pm].cpu().numpy().view(ph.dtype)
+                if pm > 1 and not bool(np.all(pg[:-1] <= pg[1:])):
+                    raise RuntimeError("the probe sort's bucket is not sorted")
+            finally:
+                probe.close()
         except Exception as e:      # noqa: BLE001
             fallback = "%s: %s" % (type(e).__name__, e)
+            if sharded is not None:
+                try:
+                    sharded.close()
+                except Exception:   # noqa: BLE001
+                    pass
+                sharded = None
+        finally:
+            probe_wd.done()
         have = torch.tensor([0 if sharded is None else 1], dtype=torch.int64, device=be.device)
         dist.all_reduce(have, op=dist.ReduceOp.MIN)
         if int(have.item()) == 0:
             if sharded is not None:
                 sharded.close()
                 sharded = None
-            fallback = fallback or "another rank could not create the C driver"
+            fallback = fallback or "another rank's C driver failed its probe sort"
             exchange = "torch (fallback from c: %s)" % fallback[:200]
     if sharded is None:
         sharded = ShardedSorter(be.ops(etype, local_rank))
+        if be.dry:
+            exchange = "torch over gloo (dry-run)"
 
     def step():
         return sharded.sort(src, n_local)      # the shard is only read: partition into the send buffer
@@ -456,7 +495,6 @@ def run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local_
     elif hasattr(sharded.ops, "close"):
         sharded.ops.close()
     del src
-    wd.done()
     ls_bytes = local_sort_bytes(int(a[:, 2].max()), es, radix)          # the fullest rank's bucket
     ls_s = phases.get("local_sort", 0.0)
     return {"value": round(n_local * world * steps / t_max / 1e6, 1), "unit": "Mkeys/s",
@@ -510,10 +548,10 @@ def main_sharded(args, world, rank, local_rank):
                                    % (world, int(np.log2(head["elements_per_gpu"])), "uint32" if etype == "uint" else "uint64",
                                       world, args.radix),
                        "elements_per_gpu": head["elements_per_gpu"], "radix": args.radix,
-                       "parallelism": "msd-bucket-exchange x%d (RCCL send/recv all-to-all, %d slice(s)) + local satradix"
-                                      % (world, head["exchange_stats"]["slices"]),
-                       "api": "clo_shard_sort_with_device_data (C API over RCCL)" if args.exchange == "c" else
-                              "cl_ops_amd.multigpu.ShardedSorter over clo_hip_msd_partition + clo_sort_with_device_data"},
+                       "parallelism": "msd-bucket-exchange x%d (%s send/recv all-to-all, %d slice(s)) + local satradix"
+                                      % (world, "gloo" if args.dry_run else "RCCL", head["exchange_stats"]["slices"]),
+                       "api": "clo_shard_sort_with_device_data (C API over RCCL)" if head["exchange"] == "c" else
+                              "cl_ops_amd.multigpu.ShardedSorter over clo_hip_msd_partition + clo_sort_with_device_data (%s)" % head["exchange"]},
             "correct": ok, "ranks_seen": head["ranks_seen"], "phases_ms": head["phases_ms"],
             "exchange_stats": head["exchange_stats"], "roofline": head["local_sort_roofline"],
         }
@@ -530,26 +568,34 @@ def main_sharded(args, world, rank, local_rank):
 # one GPU
 # ----------------------------------------------------------------------------
 
-def main_single(args):
-    # The library loads its kernels at sorter creation with two small dummy sorts;
-    # this script has untimed steps of its own for that, and the dummy launches
-    # would dilute the per-kernel averages of a rocprofv3 run of this command.
-    os.environ.setdefault("CLO_NO_WARMUP", "1")
+def kernel_sources_sha16():
+    """Content hash of the kernel sources (cl_ops_amd/csrc/hip/*): the GPU box has no .git, so this is how a line
+    says which kernels it ran and whether profiles/traffic_*.json was collected on the same ones."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cl_ops_amd", "csrc", "hip", "*"))):
+        if f.endswith((".hip", ".h")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=None, with_cpu=True):
+    """One workload on cuda:0 through the C API: PREWARM + warmup untimed steps, exactly `steps` timed ones between
+    fences, then the same number again with every kernel bracketed by HIP events (roofline + live guard), a
+    size-independent correctness check of what was timed, and the CPU oracle on a bounded sample. Returns the
+    full line as a dict."""
     import torch
     import cl_ops_amd as clo
     from cl_ops_amd import _hip
     from cl_ops_amd._hip import lib
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(0)
-    workload = args.workload
-    log2n = args.log2n or WORKLOADS[workload][0]
     n = 1 << log2n
     etype = WORKLOADS[workload][1]
     es = 4 if etype == "uint" else 8
 
-    host = make_input(workload, n, args.seed)
+    host = make_input(workload, n, seed)
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to("cuda")
     dst = torch.empty_like(src)
     torch.cuda.synchronize()
@@ -564,7 +610,7 @@ def main_single(args):
         kw = {}
         if workload == "satradix_pairs":
             kw = dict(key_type="uint", get_key="(uint) ((x) >> 32)")
-        op = clo.Sorter("satradix", ctx, etype, options="radix=%d" % args.radix, **kw)
+        op = clo.Sorter("satradix", ctx, etype, options="radix=%d" % radix, **kw)
     elif workload == "scan":
         op = clo.Scanner("blelloch", ctx, "uint", "uint")
     else:
@@ -579,7 +625,7 @@ def main_single(args):
 
     # PREWARM untimed steps first (allocations of the cached aux buffers, clock
     # ramp), then the W warm-up steps the caller asked for
-    for _ in range(PREWARM + args.warmup):
+    for _ in range(PREWARM + warmup):
         step()
     fence()
 
@@ -587,7 +633,7 @@ def main_single(args):
     timer = clo.HipEventTimer(q)
     t0 = time.perf_counter()
     timer.start()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     timer.stop()
     fence()
@@ -600,7 +646,7 @@ def main_single(args):
     # a few microseconds of pipeline bubble (~4 % of a 5 ms sort). ----
     lib.clo_hip_timing_reset()
     lib.clo_hip_timing_enable(1)
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     lib.clo_hip_timing_enable(0)
@@ -618,22 +664,25 @@ def main_single(args):
         ok = bool(np.all(got[:-1] <= got[1:]))
         ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
         ok = ok and int(got.sum(dtype=np.uint64)) == int(host.sum(dtype=np.uint64))
+    del got
 
     # ---- the line ----
     group = "satradix" if workload.startswith("satradix") else workload
     traffic, tmeta = load_traffic(workload)
     if tmeta and tmeta.get("log2n") not in (None, log2n):
-        traffic = {}                                   # measured at another size: not comparable
+        traffic, tmeta = {}, None                      # measured at another size: not comparable
+    sha_now = kernel_sources_sha16()
+    stale = bool(traffic) and (tmeta or {}).get("kernels_sha16") != sha_now
     kernels = []
     for label in FAMILIES[group]:
         cnt, tot_ms = _hip.timing_read(label)
         if not cnt:
             continue
         avg_ms = tot_ms / cnt
-        floor_b = min_moved_bytes(label, n, es, args.radix, 32 if workload == "satradix_pairs" else None)
+        floor_b = min_moved_bytes(label, n, es, radix, 32 if workload == "satradix_pairs" else None)
         pmc_b = (traffic.get(label) or {}).get("hbm_bytes_per_launch")
         moved = max(floor_b, pmc_b or 0)
-        kernels.append({"name": label, "launches_per_step": round(cnt / args.steps, 3), "avg_launch_ms": round(avg_ms, 5),
+        kernels.append({"name": label, "launches_per_step": round(cnt / steps, 3), "avg_launch_ms": round(avg_ms, 5),
                         "bytes_per_launch": int(moved), "traffic_pmc": pmc_b, "min_moved_bytes": int(floor_b),
                         "GBps": round(moved / (avg_ms * 1e-3) / 1e9, 1),
                         "frac": round(moved / (avg_ms * 1e-3) / HBM_PEAK, 4)})
@@ -643,9 +692,9 @@ def main_single(args):
     dom = next((k for k in kernels if k["name"] == label), None)
     step_bytes = sum(k["bytes_per_launch"] * k["launches_per_step"] for k in kernels)
     kernel_ms = sum(k["avg_launch_ms"] * k["launches_per_step"] for k in kernels)
-    contract_B = contract_bytes_per_elem(workload, args.radix, log2n) * n
+    contract_B = contract_bytes_per_elem(workload, radix, log2n) * n
     unit = "MValues/s" if workload == "scan" else "Mkeys/s"
-    ms_step = wall / args.steps * 1e3
+    ms_step = wall / steps * 1e3
     roof = {"bound": "hbm", "kernel": label, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
     if workload in ("abitonic", "sbitonic") and n * es <= (256 << 20):
         # every pass re-reads what the pass before wrote, and the whole array fits the 256 MiB last-level cache:
@@ -657,41 +706,168 @@ def main_single(args):
         assert dom["frac"] <= 1.0, "a physical fraction above 1: %r" % (dom,)
         roof.update({
             "achieved": dom["GBps"], "frac": dom["frac"], "traffic": dom["traffic_pmc"],
-            "launches": int(round(dom["launches_per_step"] * args.steps)), "avg_launch_ms": dom["avg_launch_ms"],
+            "launches": int(round(dom["launches_per_step"] * steps)), "avg_launch_ms": dom["avg_launch_ms"],
             "bytes_per_launch": dom["bytes_per_launch"],
-            "basis": "PMC traffic (profiles/traffic_%s.json)" % workload if dom["traffic_pmc"] else
+            "basis": ("stale PMC" if stale else "PMC traffic") + " (profiles/traffic_%s.json)" % workload if dom["traffic_pmc"] else
                      "minimum moved bytes (no PMC summary for this size in profiles/)",
         })
+    # ---- live guard: what a stale PMC file cannot vouch for is checked against THIS run: the launches a step
+    # makes per kernel family against the ones the PMC collection saw, and the kernels' summed durations against
+    # the step (a kernel family that appeared, vanished or doubled, or time spent outside the listed kernels) ----
+    seen = {k["name"]: k["launches_per_step"] for k in kernels}
+    expected = {f: v["launches_per_step"] for f, v in traffic.items() if v.get("launches_per_step")}
+    counts_ok = None if not expected else bool(set(expected) == set(seen) and all(abs(seen[f] - expected[f]) < 1e-6 for f in expected))
+    ratio = kernel_ms / ms_step if ms_step > 0 else 0.0
+    tol = 0.05 if ms_step >= 0.5 else 0.35              # (launch-bound steps: the event pairs themselves are a share of the step)
+    guard = {"launches_per_step": seen, "expected_launches_per_step": expected or None, "launch_counts_ok": counts_ok,
+             "kernel_ms_per_step": round(kernel_ms, 4), "kernel_ms_over_step_ms": round(ratio, 4), "tolerance": tol,
+             "timing_ok": bool(abs(ratio - 1.0) <= tol),
+             "kernels_sha16": sha_now, "traffic_kernels_sha16": (tmeta or {}).get("kernels_sha16"),
+             "traffic_source_head": (tmeta or {}).get("source_head"), "traffic_stale": stale if traffic else None}
+    guard["ok"] = bool(guard["timing_ok"] and counts_ok is not False)
     roof.update({
         "kernels": kernels,
         "kernel_ms_per_step": round(kernel_ms, 4),                # sum over the list: what is left of ms_per_step is launch gaps
         "traffic_step_bytes": int(step_bytes),
         "step_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
         "step_frac": round(step_bytes / (ms_step * 1e-3) / HBM_PEAK, 4),   # whole step, physical
-        "contract_A_bytes_per_step": int(contract_B),              # SURVEY.md §8d's accounting
+        "contract_A_bytes_per_step": int(contract_B),              # SURVEY.md §8d's accounting: a LABEL (it prices 4-bit trips; the sort makes 8-bit ones), not a roofline
         "contract_A_GBps": round(contract_B / (ms_step * 1e-3) / 1e9, 1),
         "contract_A_frac": round(contract_B / (ms_step * 1e-3) / HBM_PEAK, 4),
         "note": "per-launch durations from HIP events on the kernel's stream over %d extra steps run right after the "
-                "timed region; frac = bytes really moved / duration / 8 TB/s" % args.steps,
+                "timed region; frac = bytes really moved / duration / 8 TB/s" % steps,
     })
     out = {
         "metric": "Mkeys/s sorting 2^28 uint32 (satradix, 4-bit digits); achieved % of HBM roofline"
                   if workload == "satradix_u32" else WORKLOADS[workload][2],
-        "value": round(n * args.steps / wall / 1e6, 1), "unit": unit, "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "prewarm": PREWARM, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+        "value": round(n * steps / wall / 1e6, 1), "unit": unit, "n_gpus": 1, "steps": steps,
+        "warmup": warmup, "prewarm": PREWARM, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u32" if es == 4 else "u64", "data": "synthetic",
         "config": {"workload": WORKLOADS[workload][2] if log2n == WORKLOADS[workload][0] else
                    WORKLOADS[workload][2].replace("2^%d" % WORKLOADS[workload][0], "2^%d" % log2n),
-                   "elements_per_gpu": n, "radix": args.radix, "parallelism": "single GPU",
+                   "elements_per_gpu": n, "radix": radix, "parallelism": "single GPU",
                    "api": "clo_sort_with_device_data" if workload != "scan" else "clo_scan_with_device_data"},
-        "correct": ok, "device_ms_per_step": round(dev_ms / args.steps, 4), "roofline": roof,
+        "correct": ok, "device_ms_per_step": round(dev_ms / steps, 4), "roofline": roof, "live_guard": guard,
     }
-    if not args.no_cpu_baseline:
+    for x in (op, bsrc, bdst, q, ctx):
+        x.close()
+    del src, dst
+    torch.cuda.empty_cache()
+    if with_cpu:
         # sized for about 10-30 core-seconds of CPU work
         default_sample = {"satradix_u32": 28, "satradix_pairs": 27, "satradix_u64": 26, "scan": 26,
                           "abitonic": 20, "sbitonic": 16}[workload]
-        out["cpu_baseline"] = cpu_baseline(workload, host, args.radix, args.cpu_sample_log2n or default_sample)
+        out["cpu_baseline"] = cpu_baseline(workload, host, radix, min(cpu_sample_log2n or default_sample, log2n))
+    return out
+
+
+def shard_world1_leg(etype, log2n, steps, warmup, radix, seed, slices=0):
+    """BASELINE config 5's code path on the one GPU there is: clo_shard_sort_with_device_data (include/clo_shard.h) on
+    a one-rank RCCL communicator with `loopback=1` — partition, count all-gather, the slices' grouped
+    ncclSend/ncclRecv (this rank to itself) on the transfer stream, the local sorts beside them. What a node adds is
+    xGMI in place of a device copy."""
+    import torch
+    from cl_ops_amd.multigpu import CShardedSorter
+    es = 4 if etype == "uint" else 8
+    n = 1 << log2n
+    workload = "satradix_u32" if es == 4 else "satradix_u64"
+    host = make_input(workload, n, seed)
+    src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to("cuda")
+    s = CShardedSorter(etype, 0, options="radix=%d,loopback=1%s" % (radix, ",slices=%d" % slices if slices else ""))
+    try:
+        for _ in range(PREWARM + warmup):
+            s.sort(src)
+        s.check()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out_t, m = s.sort(src)
+        s.check()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        s.phase_times = {}
+        for _ in range(steps):
+            s.sort(src)
+        torch.cuda.synchronize()
+        phases = {k: v / steps for k, v in s.collect_phase_times().items()}
+        x = s.ss.exchange()
+        got = out_t[:m].cpu().numpy().view(host.dtype)
+        ok = m == n and bool(np.all(got[:-1] <= got[1:]))
+        ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
+        ok = ok and int(got.sum(dtype=np.uint64)) == int(host.sum(dtype=np.uint64))
+        ok = ok and bool(np.array_equal(src.cpu().numpy().view(host.dtype), host))      # the shard is only read
+    finally:
+        s.close()
+    del src
+    torch.cuda.empty_cache()
+    ms_step = wall / steps * 1e3
+    ls_bytes = local_sort_bytes(n, es, radix)
+    ls_s = phases.get("local_sort", 0.0)
+    return {"value": round(n * steps / wall / 1e6, 1), "unit": "Mkeys/s", "ms_per_step": round(ms_step, 4), "correct": ok,
+            "steps": steps, "warmup": warmup, "dtype": "u32" if es == 4 else "u64",
+            "config": {"workload": "satradix of 2^%d %s keys through clo_shard_sort_with_device_data on ONE rank over RCCL "
+                                   "(loopback: the rank sends every sub-bucket to itself)" % (log2n, "uint32" if es == 4 else "uint64"),
+                       "api": "clo_shard_sort_with_device_data (C API over RCCL)", "radix": radix},
+            "slices": x["slices"], "exchange_device_ms": round(x["ms"], 4),
+            "phases_ms": {k: round(v * 1e3, 4) for k, v in sorted(phases.items())},
+            "local_sort_roofline": {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "bytes": ls_bytes,
+                                    "frac": round(ls_bytes / ls_s / HBM_PEAK, 4) if ls_s > 0 else None,
+                                    "basis": "minimum bytes a plain local sort of the same keys moves / the local_sort phase"},
+            "step_frac": round((ls_bytes + 2 * n * es) / (ms_step * 1e-3) / HBM_PEAK, 4)}
+
+
+# the BASELINE.json configs beside the headline, in its order: (key, workload, steps, warmup)
+CONFIG_LEGS = (("1_sbitonic_2p16", "sbitonic", 50, 5), ("2_scan_2p26", "scan", 30, 5), ("3_abitonic_2p26", "abitonic", 10, 2),
+               ("4_satradix_pairs_2p28", "satradix_pairs", 8, 2), ("5_satradix_u64_2p28_one_shard", "satradix_u64", 5, 2))
+
+
+def leg_summary(full):
+    r = full["roofline"]
+    out = {"value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "correct": full["correct"],
+           "steps": full["steps"], "warmup": full["warmup"], "dtype": full["dtype"], "config": full["config"],
+           "kernel": r.get("kernel"), "frac": r.get("frac"), "bound": r.get("bound"), "basis": r.get("basis"),
+           "avg_launch_ms": r.get("avg_launch_ms"), "step_frac": r.get("step_frac"),
+           "kernels": {k["name"]: [k["launches_per_step"], k["avg_launch_ms"]] for k in r.get("kernels", [])},
+           "live_guard_ok": full["live_guard"]["ok"], "kernel_ms_over_step_ms": full["live_guard"]["kernel_ms_over_step_ms"]}
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = full["cpu_baseline"]
+    return out
+
+
+def main_single(args):
+    # The library loads its kernels at sorter creation with two small dummy sorts;
+    # this script has untimed steps of its own for that, and the dummy launches
+    # would dilute the per-kernel averages of a rocprofv3 run of this command.
+    os.environ.setdefault("CLO_NO_WARMUP", "1")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(0)
+    workload = args.workload
+    log2n = args.log2n or WORKLOADS[workload][0]
+    out = single_leg(workload, log2n, args.steps, args.warmup, args.radix, args.seed, args.cpu_sample_log2n, not args.no_cpu_baseline)
+    ok = out["correct"]
+    if not out["live_guard"]["ok"]:
+        sys.stderr.write("bench.py: live guard: %r\n" % (out["live_guard"],))
+    # ---- every other BASELINE config, one short leg each, in this process (no re-exec, no child after HIP is up) ----
+    if workload == "satradix_u32" and args.log2n is None and not args.no_configs:
+        t0 = time.perf_counter()
+        configs = {}
+        for key, w, k, wu in CONFIG_LEGS:
+            try:
+                configs[key] = leg_summary(single_leg(w, WORKLOADS[w][0], k, wu, args.radix, args.seed, None, not args.no_cpu_baseline))
+            except Exception as e:      # noqa: BLE001 (a leg that fails says so; the headline stands)
+                configs[key] = {"correct": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        try:
+            configs["5_sharded_c_path_world1_rccl_u64_2p28"] = shard_world1_leg("ulong", 28, 5, 2, args.radix, args.seed, args.slices)
+        except Exception as e:          # noqa: BLE001
+            configs["5_sharded_c_path_world1_rccl_u64_2p28"] = {"correct": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        out["configs"] = configs
+        out["configs_wall_s"] = round(time.perf_counter() - t0, 1)
+        ok = ok and all(c.get("correct") for c in configs.values())
     print(json.dumps(out), flush=True)
+    if out["live_guard"]["launch_counts_ok"] is False:
+        return 1
     return 0 if ok else 1
 
 

@@ -139,8 +139,9 @@ size_t clo_shard_plan_slice(const uint64_t* counts, size_t row, int world, int s
 /* ---------------- the object ---------------- */
 
 /* "slices=S" is ours, the rest goes to satradix. Returns a malloc'd copy of the rest, or NULL on a bad value. */
-static char* shard_options(const char* options, int* slices, GError** err) {
+static char* shard_options(const char* options, int* slices, int* loopback, GError** err) {
 	*slices = 0;
+	*loopback = 0;
 	const size_t len = options ? strlen(options) : 0;
 	char* rest = (char*) calloc(len + 1, 1);
 	if (!rest) return NULL;
@@ -156,6 +157,8 @@ static char* shard_options(const char* options, int* slices, GError** err) {
 				return NULL;
 			}
 			*slices = v;
+		} else if (n > 9 && strncmp(p, "loopback=", 9) == 0) {
+			*loopback = atoi(p + 9) != 0;
 		} else if (n > 0) {
 			if (rest[0]) strcat(rest, ",");
 			strncat(rest, p, n);
@@ -181,13 +184,13 @@ CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, 
 		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "the world size must be 1, 2, 4 or 8 (got %d)", world);
 		return NULL;
 	}
-	int slices = 0;
-	char* sort_options = shard_options(options, &slices, err);
+	int slices = 0, loopback = 0;
+	char* sort_options = shard_options(options, &slices, &loopback, err);
 	if (!sort_options) return NULL;
 	if (slices == 0) slices = 4;
-	/* (one rank has nothing to exchange; CLO_SHARD_TEST_EXCHANGE_ALONE keeps the slices and sends the rank's keys
-	 * to itself through the whole protocol: the only way to run the exchange over RCCL on a one-GPU box) */
-	if (world == 1 && !getenv("CLO_SHARD_TEST_EXCHANGE_ALONE")) slices = 1;
+	/* (one rank has nothing to exchange; `loopback=1` keeps the slices and sends the rank's keys to itself
+	 * through the whole protocol: a rehearsal of the exchange over the transport on a one-GPU box) */
+	if (world == 1 && !loopback) slices = 1;
 	int sbits = 0;
 	while ((1 << sbits) < slices) ++sbits;
 	CloShardSort* ss = (CloShardSort*) calloc(1, sizeof(*ss));

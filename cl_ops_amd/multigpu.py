@@ -443,8 +443,8 @@ class CShardedSorter:
         finally:
             if buf is not None:
                 buf.close()
-        if self.phase_times is not None and self.world > 1:
-            for k, v in self.ss.phase_ms().items():      # (synchronises: phase legs only)
+        if self.phase_times is not None:
+            for k, v in self.ss.phase_ms().items():      # (synchronises: phase legs only; zeros when the call had no exchange)
                 self.phase_times[k] = self.phase_times.get(k, 0.0) + v * 1e-3
         if m == 0:
             return self.torch.empty(0, dtype=local.dtype, device=local.device), 0

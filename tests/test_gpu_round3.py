@@ -333,12 +333,11 @@ def test_c_shard_sort_slices_over_real_rccl_world_one(gpu, monkeypatch, etype, o
     transport above.)"""
     import torch
     from cl_ops_amd.multigpu import CShardedSorter
-    monkeypatch.setenv("CLO_SHARD_TEST_EXCHANGE_ALONE", "1")      # (one rank alone would skip the exchange)
     dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
     n = (1 << 23) + 4099
     a = np.random.default_rng(17).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
     t = torch.from_numpy(a.view(tdt).copy()).cuda()
-    s = CShardedSorter(etype, 0, options=options)
+    s = CShardedSorter(etype, 0, options=(options + "," if options else "") + "loopback=1")   # (one rank alone would skip the exchange)
     for rep in range(2):                                   # (the second call reuses every buffer and event)
         out, m = s.sort(t)
         s.check()

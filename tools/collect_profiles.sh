@@ -10,34 +10,34 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic sbitonic; do
-	python3 "$ROOT/bench.py" --workload $w --steps 30 --warmup 3 > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
+	python3 "$ROOT/bench.py" --workload $w --steps 30 --warmup 3 --no-configs > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || exit 1
 	echo "bench $w done"
 done
 # the other path at the headline sizes (the library's choice there: chain-free pair passes): single-sweep passes forced on
 for w in satradix_u32 satradix_u64 satradix_pairs; do
-	CLO_RADIX_SWEEP=1 python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_${w}_sweep.json" 2> "$OUT/bench_${w}_sweep.err" || exit 1
+	CLO_RADIX_SWEEP=1 python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-configs > "$OUT/bench_${w}_sweep.json" 2> "$OUT/bench_${w}_sweep.err" || exit 1
 done
 [ "$2" = "benchonly" ] && { echo "bench lines done"; exit 0; }
 echo "bench sweep done"
 export CLO_RADIX_SWEEP=1
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_satradix_u32_sweep" --output-format csv -- \
-	python3 "$ROOT/bench.py" --workload satradix_u32 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_satradix_u32_sweep.json" 2> "$OUT/trace_satradix_u32_sweep.log" || exit 1
+	python3 "$ROOT/bench.py" --workload satradix_u32 --steps 10 --warmup 2 --no-cpu-baseline --no-configs > "$OUT/trace_satradix_u32_sweep.json" 2> "$OUT/trace_satradix_u32_sweep.log" || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
 	rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_satradix_u32_sweep" --output-format csv -- \
-		python3 "$ROOT/bench.py" --workload satradix_u32 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${c}_satradix_u32_sweep.json" 2> "$OUT/pmc_${c}_satradix_u32_sweep.log" || exit 1
+		python3 "$ROOT/bench.py" --workload satradix_u32 --steps 2 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/pmc_${c}_satradix_u32_sweep.json" 2> "$OUT/pmc_${c}_satradix_u32_sweep.log" || exit 1
 done
 unset CLO_RADIX_SWEEP
 echo "trace + pmc sweep done"
 for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic; do
 	rocprofv3 --kernel-trace --stats -d "$OUT/trace_$w" --output-format csv -- \
-		python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/trace_$w.json" 2> "$OUT/trace_$w.log" || exit 1
+		python3 "$ROOT/bench.py" --workload $w --steps 10 --warmup 2 --no-cpu-baseline --no-configs > "$OUT/trace_$w.json" 2> "$OUT/trace_$w.log" || exit 1
 	echo "trace $w done"
 done
 # HBM traffic (headline workload first): one counter per run, kernel trace only
 for w in satradix_u32 satradix_pairs satradix_u64 scan abitonic; do
 	for c in FETCH_SIZE WRITE_SIZE; do
 		rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_$w" --output-format csv -- \
-			python3 "$ROOT/bench.py" --workload $w --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${c}_$w.json" 2> "$OUT/pmc_${c}_$w.log" || exit 1
+			python3 "$ROOT/bench.py" --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/pmc_${c}_$w.json" 2> "$OUT/pmc_${c}_$w.log" || exit 1
 	done
 	echo "pmc $w done"
 done

@@ -6,7 +6,7 @@ mkdir -p "$out"
 for wl in satradix_u32 satradix_u64; do
   for v in "$@"; do
     tag=$(echo "$v" | tr ' =/' '___')
-    env $v python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline > "$out/${wl}_${tag}.json" 2> "$out/${wl}_${tag}.err" || { echo "FAILED $wl $v"; tail -5 "$out/${wl}_${tag}.err"; exit 1; }
+    env $v python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-configs > "$out/${wl}_${tag}.json" 2> "$out/${wl}_${tag}.err" || { echo "FAILED $wl $v"; tail -5 "$out/${wl}_${tag}.err"; exit 1; }
     python - "$out/${wl}_${tag}.json" "$wl" "$v" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -17,7 +17,7 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" \
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS_ATOMIC"; do
 	i=$((i + 1))
 	rocprofv3 --pmc $set --kernel-trace -d "$OUT/set$i" --output-format csv -- \
-		python3 "$ROOT/bench.py" --workload "$WL" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/set$i.json" 2> "$OUT/set$i.log" || { echo "set $i failed"; tail -3 "$OUT/set$i.log"; exit 1; }
+		python3 "$ROOT/bench.py" --workload "$WL" --steps 2 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/set$i.json" 2> "$OUT/set$i.log" || { echo "set $i failed"; tail -3 "$OUT/set$i.log"; exit 1; }
 	echo "set $i done: $set"
 done
 python3 - "$OUT" <<'PY'

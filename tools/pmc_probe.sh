@@ -11,7 +11,7 @@ i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"; do
 	i=$((i+1))
 	rocprofv3 --pmc $set --kernel-trace -d "$OUT/p$i" --output-format csv -- \
-		python3 "$ROOT/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/p$i.json" 2> "$OUT/p$i.log" || exit 1
+		python3 "$ROOT/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/p$i.json" 2> "$OUT/p$i.log" || exit 1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -196,3 +196,28 @@ for alg, cmd in NOTES.items():
                 "numbers, below bench.py's back-to-back steps). The scan pipelines chunks of 2^22..2^24 elements from 2^24 elements on: "
                 "its device time is the sum of the chunk scans.\n" % cmd)
         o.write(open(f).read())
+
+# ---- what bench.py's live guard compares a later run with: the kernel sources the PMC passes ran (content hash printed by
+# bench.py itself on the GPU box), the commit this summary was made at, and the launches per step of every kernel family
+# as bench.py's own timing leg counted them in the PMC run ----
+import subprocess
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    head = None
+for workload in ("satradix_u32", "satradix_pairs", "satradix_u64", "scan", "abitonic"):
+    tj = os.path.join(dst, "traffic_%s.json" % workload)
+    bj = os.path.join(src, "pmc_FETCH_SIZE_%s.json" % workload)
+    if not (os.path.exists(tj) and os.path.exists(bj)):
+        continue
+    lines = [l for l in open(bj).read().splitlines() if l.startswith("{")]
+    if not lines:
+        continue
+    b = json.loads(lines[-1])
+    d = json.load(open(tj))
+    d["kernels_sha16"] = (b.get("live_guard") or {}).get("kernels_sha16")
+    d["source_head"] = head
+    for k in (b.get("roofline") or {}).get("kernels", []):
+        if k["name"] in d["families"]:
+            d["families"][k["name"]]["launches_per_step"] = k["launches_per_step"]
+    json.dump(d, open(tj, "w"), indent=1)
