@@ -80,6 +80,9 @@ _sig("clo_hip_radix_polls", ci, sz, ci, ci)
 _sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_radix_takes_first_digits", ci, sz, ci, ci, ci)
 _sig("clo_hip_radix_sort_fed", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, vp, sz, vp)
+_sig("clo_hip_radix_seg_workspace_bytes", sz, sz, ci, ci, ci)
+_sig("clo_hip_radix_sort_segmented", ci, vp, vp, sz, C.POINTER(sz), ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(ci), ci,
+     ci, ci, ci, ci, vp, sz, vp, C.POINTER(ci))
 _sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)
 _sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, vp, sz, vp)
 _sig("clo_hip_msd_workspace_bytes", sz, sz, ci, ci)

@@ -102,8 +102,43 @@ int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
 	return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, first_digits, workspace, s);
 }
 
+size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, int digit_bits) {
+	return clo_radix4_seg_workspace_bytes(numel, nseg, elem_size, digit_bits);
+}
+
+int clo_hip_radix_sort_segmented(void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
+	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream, int* result_in_b) {
+	if (!result_in_b) return CLO_HIP_EARGS;
+	*result_in_b = 0;
+	if (numel == 0) return 0;
+	if (!a || !b || a == b || !workspace || !seg_counts || nseg < 1 || nseg > CLO_SEG_MAX) return CLO_HIP_EARGS;
+	if (npieces < 0 || npieces > CLO_SEG_MAX || (npieces > 0 && (!piece_counts || !piece_offsets || !piece_segment))) return CLO_HIP_EARGS;
+	if (elem_size != 4 && elem_size != 8) return CLO_HIP_EUNSUPPORTED;
+	if (digit_bits != 4 && digit_bits != 8) return CLO_HIP_EUNSUPPORTED;
+	if (key_bits < 1 || key_shift < 0 || key_shift + key_bits > 8 * elem_size) return CLO_HIP_EARGS;
+	if (numel > 0xffffffffull) return CLO_HIP_EARGS;
+	size_t total = 0;
+	for (int i = 0; i < nseg; ++i) total += seg_counts[i];
+	if (total != numel) return CLO_HIP_EARGS;
+	if (npieces > 0) {   // the pieces of a segment add up to it, every piece lies inside the source
+		size_t per[CLO_SEG_MAX];
+		for (int k = 0; k < nseg; ++k) per[k] = 0;
+		for (int i = 0; i < npieces; ++i) {
+			if (piece_segment[i] < 0 || piece_segment[i] >= nseg || piece_offsets[i] > numel || piece_counts[i] > numel - piece_offsets[i]) return CLO_HIP_EARGS;
+			per[piece_segment[i]] += piece_counts[i];
+		}
+		for (int k = 0; k < nseg; ++k) if (per[k] != seg_counts[k]) return CLO_HIP_EARGS;
+	}
+	const size_t need = clo_radix4_seg_workspace_bytes(numel, nseg, elem_size, digit_bits);
+	if (need == 0) return CLO_HIP_EUNSUPPORTED;
+	if (workspace_bytes < need) return CLO_HIP_EWORKSPACE;
+	return clo_radix4_sort_segmented(a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
+		elem_size, key_shift, key_bits, digit_bits, workspace, (hipStream_t) stream, result_in_b);
+}
+
 size_t clo_hip_msd_workspace_bytes(size_t numel, int elem_size, int bucket_bits) {
-	if (bucket_bits < 1 || bucket_bits > 6) return 0;
+	if (bucket_bits < 1 || bucket_bits > 8) return 0;
 	return clo_radix4_partition_workspace_bytes(numel, elem_size, bucket_bits);
 }
 
@@ -127,7 +162,7 @@ int clo_hip_msd_partition(const void* src, void* dst, size_t numel, int elem_siz
 	int key_shift, int key_bits, int bucket_bits, uint64_t* counts_dev,
 	void* workspace, size_t workspace_bytes, void* stream) {
 	hipStream_t s = (hipStream_t) stream;
-	if (bucket_bits < 1 || bucket_bits > 6 || bucket_bits > key_bits) return CLO_HIP_EARGS;
+	if (bucket_bits < 1 || bucket_bits > 8 || bucket_bits > key_bits) return CLO_HIP_EARGS;
 	if (numel == 0) {
 		if (counts_dev) return (int) hipMemsetAsync(counts_dev, 0, sizeof(uint64_t) << bucket_bits, s);
 		return 0;

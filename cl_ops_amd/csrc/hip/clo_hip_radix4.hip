@@ -51,13 +51,16 @@ namespace {
 // DIG: every element's NEXT combined digit (8 bits at next_shift) also goes out, one
 // byte per element in output order: the next pass's histogram then reads n bytes
 // instead of n elements (clo_radixw_launch_tilehist_bytes).
-template <typename E, int LB, int HB, bool BIG, bool DIG = false>
+// SEG: a segmented launch (clo_hip_radix_sort_segmented): `n` is the number of TILES of the launch, `tdesc` says which
+// segment a tile belongs to and where it lies; positions, offsets and the row of digit bases are the segment's own.
+template <typename E, int LB, int HB, bool BIG, bool DIG = false, bool SEG = false>
 __global__ __launch_bounds__((pair_shape<E, BIG>::THREADS), (pair_shape<E, BIG>::THREADS >= 1024 ? 8 : 6))   // 3 work-groups per CU (LDS): 6 waves per SIMD, <= 80 VGPRs (59 used); BIG: 2 x 16 waves, <= 64
 void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_t n,
 	unsigned shift, unsigned mask_lo, unsigned mask_hi,
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, const unsigned* __restrict__ dbase,
 	const unsigned* __restrict__ tinfo, int aligned,
-	clo_keyx kx_in, clo_keyx kx_out, unsigned char* __restrict__ dig_out = nullptr, unsigned next_shift = 0) {
+	clo_keyx kx_in, clo_keyx kx_out, unsigned char* __restrict__ dig_out = nullptr, unsigned next_shift = 0,
+	const clo_seg_tile* __restrict__ tdesc = nullptr) {
 
 	constexpr int THREADS = pair_shape<E, BIG>::THREADS;
 	constexpr int ITEMS = pair_shape<E, BIG>::ITEMS;
@@ -77,15 +80,27 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 
 	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 	// neighbouring tiles behind the same L2 (see above)
-	const unsigned per_xcd = (unsigned) ((n + (size_t) TILE * 8 - 1) / ((size_t) TILE * 8));
+	const unsigned per_xcd = SEG ? (unsigned) ((n + 7) / 8) : (unsigned) ((n + (size_t) TILE * 8 - 1) / ((size_t) TILE * 8));
 	const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-	const size_t base = (size_t) tile * TILE;
-	if (base >= n) return;
-	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	size_t base = (size_t) tile * TILE;
+	unsigned count, n32;
+	if constexpr (SEG) {
+		if (tile >= (unsigned) n) return;
+		const clo_seg_tile td = tdesc[tile];   // (one 16-byte load, the same for the whole work-group)
+		base = (size_t) td.in_base;
+		count = td.count_seg & 0xffffu;
+		n32 = td.seg_n;
+		out += td.out_base;
+		if constexpr (DIG) dig_out += td.out_base;
+		dbase += (size_t) (td.count_seg >> 16) * R2;
+	} else {
+		if (base >= n) return;
+		count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+		n32 = n > 0xffffffffull ? 0xffffffffu : (unsigned) n;   // global indices are 32-bit here
+	}
 	const bool full = count == (unsigned) TILE;
 	const unsigned tbase = tid * ITEMS;
 	const unsigned mask2 = (mask_hi << LB) | mask_lo;
-	const unsigned n32 = n > 0xffffffffull ? 0xffffffffu : (unsigned) n;   // global indices are 32-bit here
 
 	// the tile's counters (upstream's counters / counters_sum), requested before the keys
 	unsigned h2 = 0, goff = 0;
@@ -96,7 +111,8 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	}
 	E key[ITEMS];
 	if (full) {
-		load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
+		if constexpr (SEG) load_blocked_unaligned<E, ITEMS>(in + base + tbase, key);   // (a segment starts at any element)
+		else load_blocked<E, ITEMS>(in + base + tbase, key, aligned != 0);
 	} else {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
@@ -429,9 +445,9 @@ void clo_radix4_counts_kernel(const unsigned* __restrict__ thist, unsigned tiles
 }
 
 // One stable pass on `BITS` bits at `shift`: the MSD bucket split of the
-// multi-GPU exchange. Up to 3 bits: the pair kernel with no high digit; 4 .. 6 bits
-// (the buckets of the ranks times the sub-buckets of a rank, include/clo_shard.h): both
-// local splits, LB + HB = BITS. counts (optional) receives the 1 << BITS bucket sizes.
+// multi-GPU exchange. Up to 3 bits: the pair kernel with no high digit; 4 .. 8 bits
+// (the buckets of the ranks times the sub-buckets of a rank, include/clo_shard.h: 8 since
+// round 4 — the split then replaces one of the sort's own passes): both local splits, LB + HB = BITS. counts (optional) receives the 1 << BITS bucket sizes.
 template <typename E, int BITS, int LB, int HB>
 int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned long long* counts, void* ws, hipStream_t s) {
 	constexpr unsigned R = 1u << BITS;
@@ -465,6 +481,129 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, false>::THREADS), 0, s,
 			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo,
 			(int) ((uintptr_t) src % 16 == 0), kx_none, kx_none, nullptr, 0u);
+	return (int) hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Segmented sort: `nseg` consecutive segments of one array, each sorted on its own by the key bits
+// [key_shift, key_shift + key_bits), in SHARED launches — the passes above with one table lookup per tile
+// (which segment, where) and per counter-scan chunk. What it is for: the sub-buckets a rank of the sharded sort
+// receives (clo_shard.c) share their top key bits, so sorting them one by one on the remaining bits is right
+// but launch-bound (32 sorts of 2^23 keys: 12 launches each, every one too small for the chip), while one
+// segmented sort of all of them runs launches of the whole slice. The radix-16 / 256 schedule only (LB = HB = 4),
+// unsigned keys. The two buffers take turns: the result is in `b` after an odd number of passes, in `a` after an
+// even one (*result_in_b); `a` (the source) is overwritten either way.
+// ---------------------------------------------------------------------------
+struct rp_seg_layout { size_t thist, toff, partial, tinfo, tdesc, cdesc, dig, total, tile, max_tiles, max_chunks; bool big; };
+
+rp_seg_layout rp_make_seg_layout(size_t n, int nseg, int elem_size) {
+	rp_seg_layout L;
+	const size_t R2 = 256;
+	L.big = clo_radix_big_tiles(n, elem_size);
+	L.tile = clo_pair_tile_elems(elem_size, L.big);
+	clo_radixw_seg_bounds(n, CLO_SEG_MAX, nseg, L.tile, &L.max_tiles, &L.max_chunks);   // (room for any number of pieces)
+	const size_t per = L.max_tiles * R2 * sizeof(unsigned);
+	const auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+	L.thist = CLO_WS_HEADER_BYTES;
+	L.toff = L.thist + per;
+	L.partial = L.toff + per;
+	L.tinfo = L.partial + up(clo_radixw_partial_rows_seg(L.max_chunks, (size_t) nseg) * R2 * sizeof(unsigned));
+	// two pairs of tables: the first pass reads the pieces, the later ones the gathered segments
+	L.tdesc = L.tinfo + up(L.max_tiles * sizeof(unsigned));
+	L.cdesc = L.tdesc + 2 * up(L.max_tiles * sizeof(clo_seg_tile));
+	L.total = L.cdesc + 2 * up(L.max_chunks * sizeof(clo_seg_chunk));
+	L.dig = 0;
+	if (clo_radix_digit_stream(n, elem_size)) {
+		L.dig = L.total;
+		L.total += up(n);
+	}
+	return L;
+}
+
+template <typename E>
+int rp_sort_seg_impl(E* a, E* b, size_t n, const size_t* seg_counts, int nseg,
+	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int key_shift, int key_bits, void* ws,
+	hipStream_t s, int* result_in_b) {
+	constexpr int LB = 4, HB = 4, PB = 8;
+	const int passes = (key_bits + PB - 1) / PB;
+	const rp_seg_layout L = rp_make_seg_layout(n, nseg, (int) sizeof(E));
+	unsigned* thist = (unsigned*) ((char*) ws + L.thist);
+	unsigned* toff = (unsigned*) ((char*) ws + L.toff);
+	unsigned* partial = (unsigned*) ((char*) ws + L.partial);
+	unsigned* tinfo = (unsigned*) ((char*) ws + L.tinfo);
+	const auto up = [](size_t x) { return (x + 255) & ~(size_t) 255; };
+	// the segments as they lie after the first pass: back to back, in order
+	size_t seg_base[CLO_SEG_MAX];
+	int seg_id[CLO_SEG_MAX];
+	{
+		size_t at = 0;
+		for (int k = 0; k < nseg; ++k) { seg_base[k] = at; seg_id[k] = k; at += seg_counts[k]; }
+	}
+	clo_seg_tables sg0, sg;   // first pass (pieces) / later passes (segments)
+	sg.tiles = (const clo_seg_tile*) ((char*) ws + L.tdesc);
+	sg.chunks = (const clo_seg_chunk*) ((char*) ws + L.cdesc);
+	sg.nseg = (unsigned) nseg;
+	{
+		clo_timing_scope timing("radix_seg_tables", s);
+		int st = clo_radixw_seg_build(seg_counts, seg_base, seg_id, nseg, nseg, L.tile, (clo_seg_tile*) sg.tiles, (clo_seg_chunk*) sg.chunks, &sg.ntiles, &sg.nchunks, s);
+		if (st != 0) return st;
+		sg0 = sg;
+		if (npieces > 0) {
+			sg0.tiles = (const clo_seg_tile*) ((char*) ws + L.tdesc + up(L.max_tiles * sizeof(clo_seg_tile)));
+			sg0.chunks = (const clo_seg_chunk*) ((char*) ws + L.cdesc + up(L.max_chunks * sizeof(clo_seg_chunk)));
+			st = clo_radixw_seg_build(piece_n, piece_base, piece_seg, npieces, nseg, L.tile, (clo_seg_tile*) sg0.tiles, (clo_seg_chunk*) sg0.chunks, &sg0.ntiles, &sg0.nchunks, s);
+			if (st != 0) return st;
+		}
+	}
+	*result_in_b = passes % 2;
+	if (sg.ntiles == 0) return 0;
+	if (sg.ntiles > L.max_tiles || sg.nchunks > L.max_chunks || sg0.ntiles > L.max_tiles || sg0.nchunks > L.max_chunks)
+		return CLO_HIP_EWORKSPACE;   // (cannot happen: the bounds hold for any split of n)
+	unsigned char* dig = (L.dig != 0 && passes > 1) ? (unsigned char*) ws + L.dig : nullptr;
+	const clo_keyx kx_none = { 0, 0, 0 };
+	E* cur_in = a;
+	for (int p = 0; p < passes; ++p) {
+		const clo_seg_tables& sgp = p == 0 ? sg0 : sg;
+		const unsigned grid = (sgp.ntiles + 7u) / 8u * 8u;
+		E* cur_out = cur_in == a ? b : a;
+		const int rem = key_bits - p * PB;
+		const int bits = rem < PB ? rem : PB;
+		const int lo_bits = bits < LB ? bits : LB, hi_bits = bits - lo_bits;
+		const unsigned shift = (unsigned) (key_shift + p * PB);
+		const unsigned mask_lo = (1u << lo_bits) - 1u, mask_hi = (1u << hi_bits) - 1u;
+		{
+			clo_timing_scope timing("radix_hist", s);
+			const int st = (dig && p > 0)
+				? clo_radixw_launch_tilehist_bytes_seg(dig, sgp, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, partial, L.big, s)
+				: clo_radixw_launch_tilehist_seg(cur_in, sgp, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo, thist, tinfo, partial, L.big, s);
+			if (st != 0) return st;
+		}
+		const unsigned* dbase = nullptr;
+		{
+			clo_timing_scope timing("radix_offsets", s);
+			const int st = clo_radixw_launch_offsets_seg(PB, thist, sgp, partial, toff, &dbase, s);
+			if (st != 0) return st;
+		}
+		{
+			clo_timing_scope timing("radix_pass", s);
+			const unsigned next_shift = (unsigned) (key_shift + (p + 1) * PB);
+			if (L.big) {
+				if (dig && p + 1 < passes)
+					hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true, true>), dim3(grid), dim3(pair_shape<E, true>::THREADS), 0, s,
+						(const E*) cur_in, cur_out, (size_t) sgp.ntiles, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, 0,
+						kx_none, kx_none, dig, next_shift, sgp.tiles);
+				else
+					hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false, true>), dim3(grid), dim3(pair_shape<E, true>::THREADS), 0, s,
+						(const E*) cur_in, cur_out, (size_t) sgp.ntiles, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, 0,
+						kx_none, kx_none, nullptr, 0u, sgp.tiles);
+			} else {
+				hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false, true>), dim3(grid), dim3(pair_shape<E, false>::THREADS), 0, s,
+					(const E*) cur_in, cur_out, (size_t) sgp.ntiles, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, 0,
+					kx_none, kx_none, nullptr, 0u, sgp.tiles);
+			}
+		}
+		cur_in = cur_out;
+	}
 	return (int) hipGetLastError();
 }
 
@@ -503,6 +642,20 @@ size_t clo_radix4_workspace_bytes(size_t n, int elem_size, int digit_bits, int k
 	return b;
 }
 
+size_t clo_radix4_seg_workspace_bytes(size_t n, int nseg, int elem_size, int digit_bits) {
+	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || nseg < 1 || nseg > CLO_SEG_MAX) return 0;
+	return rp_make_seg_layout(n, nseg, elem_size).total;
+}
+
+int clo_radix4_sort_segmented(void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
+	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int elem_size, int key_shift,
+	int key_bits, int digit_bits, void* ws, hipStream_t s, int* result_in_b) {
+	if (digit_bits != 4 && digit_bits != 8) return CLO_HIP_EUNSUPPORTED;
+	if (elem_size == 4) return rp_sort_seg_impl<uint32_t>((uint32_t*) a, (uint32_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
+	if (elem_size == 8) return rp_sort_seg_impl<uint64_t>((uint64_t*) a, (uint64_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
+	return CLO_HIP_EUNSUPPORTED;
+}
+
 size_t clo_radix4_partition_workspace_bytes(size_t n, int elem_size, int bits) {
 	return rp_make_layout(n, elem_size, bits <= 3 ? 2 * bits : bits, false).total;
 }
@@ -517,6 +670,8 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 		if (bits == 4) CLO_R4P(uint32_t, 4, 2, 2);
 		if (bits == 5) CLO_R4P(uint32_t, 5, 3, 2);
 		if (bits == 6) CLO_R4P(uint32_t, 6, 3, 3);
+		if (bits == 7) CLO_R4P(uint32_t, 7, 4, 3);
+		if (bits == 8) CLO_R4P(uint32_t, 8, 4, 4);
 	} else if (elem_size == 8) {
 		if (bits == 1) CLO_R4P(uint64_t, 1, 1, 1);
 		if (bits == 2) CLO_R4P(uint64_t, 2, 2, 2);
@@ -524,6 +679,8 @@ int clo_radix4_partition(const void* src, void* dst, size_t n, int elem_size, un
 		if (bits == 4) CLO_R4P(uint64_t, 4, 2, 2);
 		if (bits == 5) CLO_R4P(uint64_t, 5, 3, 2);
 		if (bits == 6) CLO_R4P(uint64_t, 6, 3, 3);
+		if (bits == 7) CLO_R4P(uint64_t, 7, 4, 3);
+		if (bits == 8) CLO_R4P(uint64_t, 8, 4, 4);
 	}
 	#undef CLO_R4P
 	return CLO_HIP_EUNSUPPORTED;

@@ -59,6 +59,20 @@ __device__ __forceinline__ void load_blocked(const E* __restrict__ p, E (&key)[I
 	}
 }
 
+// The same slice at an address that is only element-aligned: 16-byte loads all the same (the hardware takes them;
+// the type says so to the compiler).
+template <typename E, int ITEMS>
+__device__ __forceinline__ void load_blocked_unaligned(const E* __restrict__ p, E (&key)[ITEMS]) {
+	constexpr int PER = 16 / (int) sizeof(E);
+	typedef E vecU __attribute__((ext_vector_type(PER), aligned(sizeof(E))));
+	#pragma unroll
+	for (int k = 0; k < ITEMS / PER; ++k) {
+		const vecU v = reinterpret_cast<const vecU*>(p)[k];
+		#pragma unroll
+		for (int q = 0; q < PER; ++q) key[k * PER + q] = v[q];
+	}
+}
+
 // The thread-private 4-bit counters first widen to 8-bit fields only (4
 // digits per VGPR: even digits in one word, odd digits in the next): an
 // inclusive scan inside a row of 16 lanes cannot exceed 16 * 15 = 240. Only

@@ -13,6 +13,8 @@
 // 6 counter streams). No kernel waits on another work-group.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
 #include "clo_hip_radix_rank.h"
@@ -49,14 +51,24 @@ __device__ __forceinline__ void rw_tile_info(unsigned h, unsigned count, unsigne
 	else if (h != 0u) tinfo[blockIdx.x] = 0u;
 }
 
+// Where a tile of a segmented launch lies (clo_hip_internal.h): one 16-byte load, the same for the whole work-group.
+__device__ __forceinline__ void rw_seg_tile(const clo_seg_tile* __restrict__ tdesc, size_t& base, unsigned& count, unsigned tile_elems) {
+	const clo_seg_tile td = tdesc[blockIdx.x];
+	base = (size_t) td.in_base;
+	count = td.count_seg & 0xffffu;
+	(void) tile_elems;
+}
+
 // ---------------------------------------------------------------------------
 // per-tile digit histogram (upstream's satradix_histogram job)
 // ---------------------------------------------------------------------------
-template <typename E, int BITS, bool BIG>
+// SEG: a segmented launch — `tdesc` says where the tile lies (n is unused); a segment starts at any element, so the
+// vector loads are only element-aligned.
+template <typename E, int BITS, bool BIG, bool SEG = false>
 __global__ __launch_bounds__((rw_shape<E, BIG>::THREADS))
 void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
 	unsigned* __restrict__ thist, unsigned* __restrict__ tinfo, int aligned, clo_keyx kx,
-	unsigned* __restrict__ clear, unsigned clear_words) {
+	unsigned* __restrict__ clear, unsigned clear_words, const clo_seg_tile* __restrict__ tdesc = nullptr) {
 	constexpr int R = 1 << BITS;
 	constexpr int ITEMS = rw_shape<E, BIG>::ITEMS;
 	constexpr int TILE = rw_shape<E, BIG>::TILE;
@@ -71,8 +83,9 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	constexpr int COPIES = 32;
 	__shared__ __attribute__((aligned(16))) unsigned s_cnt[R * COPIES];
 	const unsigned tid = threadIdx.x, lane = tid & 63u;
-	const size_t base = (size_t) blockIdx.x * TILE;
-	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	size_t base = (size_t) blockIdx.x * TILE;
+	unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	if constexpr (SEG) rw_seg_tile(tdesc, base, count, (unsigned) TILE);
 	{   // (16-byte stores: a quarter of the LDS instructions of a dword loop)
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
 		const vec4u z = { 0u, 0u, 0u, 0u };
@@ -81,8 +94,10 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	__syncthreads();
 	const unsigned tbase = tid * ITEMS;
 	const unsigned cp = lane & (COPIES - 1);
-	if (count == (unsigned) TILE && aligned) {
-		typedef E vecE __attribute__((ext_vector_type(PER)));   // (`aligned`: the source is 16-byte aligned)
+	if (count == (unsigned) TILE && (aligned || SEG)) {
+		typedef E vecA __attribute__((ext_vector_type(PER)));   // (`aligned`: the source is 16-byte aligned)
+		typedef E vecU __attribute__((ext_vector_type(PER), aligned(sizeof(E))));
+		typedef typename std::conditional<SEG, vecU, vecA>::type vecE;
 		const vecE* p = reinterpret_cast<const vecE*>(in + base + tbase);
 		vecE v[VECS];
 		#pragma unroll
@@ -112,23 +127,25 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 		thist[(size_t) blockIdx.x * R + d] = h;
 		rw_tile_info(h, count, tinfo);
 		rw_clear(clear, clear_words, blockIdx.x * R + d);
+		if constexpr (SEG) rw_clear(clear, clear_words, (gridDim.x + blockIdx.x) * R + d);   // (up to one chunk per tile, and the ticket's row)
 	}
 }
 
 // The same histogram out of the digit bytes the pass before wrote (one byte per
 // element, in the order of the elements; clo_radix4_pair_kernel<..., DIG>): a quarter
 // (uint32) or an eighth (8-byte elements) of the bytes to read.
-template <int BITS, int ITEMS, int THREADS>   // ITEMS bytes per thread: 16 (4-byte elements) or 8; THREADS of the tile's shape
+template <int BITS, int ITEMS, int THREADS, bool SEG = false>   // ITEMS bytes per thread: 16 (4-byte elements) or 8; THREADS of the tile's shape
 __global__ __launch_bounds__(THREADS)
 void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist,
-	unsigned* __restrict__ tinfo, unsigned* __restrict__ clear, unsigned clear_words) {
+	unsigned* __restrict__ tinfo, unsigned* __restrict__ clear, unsigned clear_words, const clo_seg_tile* __restrict__ tdesc = nullptr) {
 	constexpr int R = 1 << BITS;
 	constexpr int TILE = THREADS * ITEMS;
 	constexpr int COPIES = 32;
 	__shared__ __attribute__((aligned(16))) unsigned s_cnt[R * COPIES];
 	const unsigned tid = threadIdx.x, lane = tid & 63u;
-	const size_t base = (size_t) blockIdx.x * TILE;
-	const unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	size_t base = (size_t) blockIdx.x * TILE;
+	unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	if constexpr (SEG) rw_seg_tile(tdesc, base, count, (unsigned) TILE);
 	{
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
 		const vec4u z = { 0u, 0u, 0u, 0u };
@@ -138,7 +155,9 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 	const unsigned tbase = tid * ITEMS;
 	const unsigned cp = lane & (COPIES - 1);
 	if (count == (unsigned) TILE) {
-		typedef unsigned vecw __attribute__((ext_vector_type(ITEMS / 4)));   // (the stream starts 256-byte aligned, a tile is a multiple of 16 bytes)
+		typedef unsigned vecA __attribute__((ext_vector_type(ITEMS / 4)));   // (the stream starts 256-byte aligned, a tile is a multiple of 16 bytes)
+		typedef unsigned vecU __attribute__((ext_vector_type(ITEMS / 4), aligned(1)));   // (a segment starts at any byte of it)
+		typedef typename std::conditional<SEG, vecU, vecA>::type vecw;
 		const vecw v = *reinterpret_cast<const vecw*>(dig + base + tbase);
 		#pragma unroll
 		for (int k = 0; k < ITEMS / 4; ++k) {
@@ -164,6 +183,7 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 		thist[(size_t) blockIdx.x * R + d] = h;
 		rw_tile_info(h, count, tinfo);
 		rw_clear(clear, clear_words, blockIdx.x * R + d);
+		if constexpr (SEG) rw_clear(clear, clear_words, (gridDim.x + blockIdx.x) * R + d);
 	}
 }
 
@@ -205,10 +225,13 @@ template <int R> struct rw_cs {
 };
 
 constexpr unsigned RW_WRITTEN = 0x80000000u;
-template <int R>
+// SEG: the chunks of a segmented launch (cdesc): a chunk's tiles belong to ONE segment, it adds up the published sums of
+// the earlier chunks of ITS segment only (they hold earlier tickets, as before), and the last chunk of every segment
+// leaves that segment's digit bases in row chunks + 1 + segment.
+template <int R, bool SEG = false>
 __global__ __launch_bounds__(RW_CS_THREADS)
 void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned chunks,
-	unsigned* __restrict__ partial, unsigned* __restrict__ toff) {
+	unsigned* __restrict__ partial, unsigned* __restrict__ toff, const clo_seg_chunk* __restrict__ cdesc = nullptr) {
 	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
 	constexpr int GA = RW_CS_THREADS / R;   // thread groups of the look-back (all threads)
 	constexpr int LB = 8;                   // published rows a thread asks for at once
@@ -220,8 +243,16 @@ void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned t
 	// start in the order of their numbers often enough.)
 	__syncthreads();
 	const unsigned c = s_c;
-	const unsigned t0 = c * RW_CHUNK;
-	const unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
+	unsigned t0 = c * RW_CHUNK;
+	unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
+	unsigned c_first = 0u, dbase_row = chunks + 1u;
+	bool last = c + 1u == chunks;
+	if constexpr (SEG) {
+		const clo_seg_chunk cd = cdesc[c];
+		t0 = cd.t0; tend = cd.tend; c_first = cd.c_first;
+		last = (cd.seg_last >> 31) != 0u;
+		dbase_row = chunks + 1u + (cd.seg_last & 0x7fffffffu);
+	}
 	const bool active = g < (unsigned) G;
 	unsigned v[SUB];
 	if (active) {
@@ -244,7 +275,7 @@ void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned t
 	}
 	// the chunks before this one
 	unsigned acc = 0;
-	for (unsigned b = g; b < c; b += (unsigned) (GA * LB)) {
+	for (unsigned b = c_first + g; b < c; b += (unsigned) (GA * LB)) {
 		unsigned x[LB];
 		bool ok;
 		do {
@@ -266,7 +297,7 @@ void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned t
 	unsigned before = 0;
 	#pragma unroll 8
 	for (int k = 0; k < GA; ++k) before += s_lb[k * R + d];
-	if (c + 1u == chunks) {   // (the same for the whole work-group) the digit bases: exclusive scan of the totals over the digits
+	if (last) {   // (the same for the whole work-group) the digit bases: exclusive scan of the totals over the digits
 		const unsigned t = tid < (unsigned) R ? before + tot : 0u;
 		const unsigned incl = clo_wave_scan_inclusive<unsigned>(t, lane);
 		if (lane == 63 && wave < 4) s_w[wave] = incl;   // R <= 256: the digits sit in the first four waves
@@ -275,7 +306,7 @@ void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned t
 			unsigned dbase = incl - t;
 			#pragma unroll
 			for (unsigned w = 0; w < 4; ++w) if (w < wave) dbase += s_w[w];
-			partial[(size_t) (chunks + 1u) * R + tid] = dbase;
+			partial[(size_t) dbase_row * R + tid] = dbase;
 		}
 	}
 	if (!active) return;
@@ -331,7 +362,151 @@ void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned til
 	}
 }
 
+// ---------------------------------------------------------------------------
+// Segmented sorts: the two tables of a launch (clo_hip_internal.h), from the segments' lengths. Every work-group
+// scans the (at most 256) lengths itself — a few hundred LDS operations — and then describes one tile and one chunk
+// per thread: one launch per sort, whatever the number of tiles.
+// ---------------------------------------------------------------------------
+constexpr int SEG_BUILD_THREADS = 1024;
+__global__ __launch_bounds__(SEG_BUILD_THREADS)
+void clo_radix_seg_build_kernel(clo_seg_pieces pc, unsigned npieces, unsigned tile, unsigned ntiles, unsigned nchunks,
+	clo_seg_tile* __restrict__ tdesc, clo_seg_chunk* __restrict__ cdesc) {
+	// per piece: first tile (s_pt); per segment: length (s_sn), first element in the output (s_ob), first tile (s_st), first chunk (s_sc)
+	__shared__ unsigned s_pt[CLO_SEG_MAX + 1], s_sn[CLO_SEG_MAX], s_stl[CLO_SEG_MAX], s_ob[CLO_SEG_MAX + 1], s_st[CLO_SEG_MAX + 1], s_sc[CLO_SEG_MAX + 1], s_w[4][4];
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	if (tid < (unsigned) CLO_SEG_MAX) { s_sn[tid] = 0u; s_stl[tid] = 0u; }
+	__syncthreads();
+	unsigned pn = 0, ptl = 0;
+	if (tid < npieces) {
+		pn = pc.n[tid];
+		ptl = (pn + tile - 1u) / tile;
+		atomicAdd(&s_sn[pc.seg[tid]], pn);
+		atomicAdd(&s_stl[pc.seg[tid]], ptl);
+	}
+	__syncthreads();
+	if (tid < (unsigned) CLO_SEG_MAX) {
+		const unsigned sn = s_sn[tid], stl = s_stl[tid], sch = (stl + (unsigned) RW_CHUNK - 1u) / (unsigned) RW_CHUNK;
+		const unsigned i0 = clo_wave_scan_inclusive<unsigned>(ptl, lane), i1 = clo_wave_scan_inclusive<unsigned>(sn, lane),
+			i2 = clo_wave_scan_inclusive<unsigned>(stl, lane), i3 = clo_wave_scan_inclusive<unsigned>(sch, lane);
+		if (lane == 63u) { s_w[0][wave] = i0; s_w[1][wave] = i1; s_w[2][wave] = i2; s_w[3][wave] = i3; }
+		s_pt[tid + 1] = i0; s_ob[tid + 1] = i1; s_st[tid + 1] = i2; s_sc[tid + 1] = i3;
+	}
+	__syncthreads();
+	if (tid < (unsigned) CLO_SEG_MAX) {
+		unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+		for (unsigned w = 0; w < wave; ++w) { b0 += s_w[0][w]; b1 += s_w[1][w]; b2 += s_w[2][w]; b3 += s_w[3][w]; }
+		s_pt[tid + 1] += b0; s_ob[tid + 1] += b1; s_st[tid + 1] += b2; s_sc[tid + 1] += b3;
+		if (tid == 0) s_pt[0] = s_ob[0] = s_st[0] = s_sc[0] = 0u;
+	}
+	__syncthreads();
+	const unsigned i = blockIdx.x * SEG_BUILD_THREADS + tid;
+	if (i < ntiles) {   // the piece p with s_pt[p] <= i < s_pt[p + 1] (empty pieces have empty ranges)
+		unsigned lo = 0, hi = CLO_SEG_MAX;
+		while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (s_pt[mid] <= i) lo = mid; else hi = mid; }
+		const unsigned off = (i - s_pt[lo]) * tile, left = pc.n[lo] - off, sg = pc.seg[lo];
+		clo_seg_tile td;
+		td.in_base = pc.in_base[lo] + off;
+		td.count_seg = (left < tile ? left : tile) | (sg << 16);
+		td.out_base = s_ob[sg];
+		td.seg_n = s_sn[sg];
+		tdesc[i] = td;
+	}
+	if (i < nchunks) {
+		unsigned lo = 0, hi = CLO_SEG_MAX;
+		while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (s_sc[mid] <= i) lo = mid; else hi = mid; }
+		clo_seg_chunk cd;
+		cd.t0 = s_st[lo] + (i - s_sc[lo]) * (unsigned) RW_CHUNK;
+		cd.tend = cd.t0 + (unsigned) RW_CHUNK < s_st[lo + 1] ? cd.t0 + (unsigned) RW_CHUNK : s_st[lo + 1];
+		cd.c_first = s_sc[lo];
+		cd.seg_last = lo | (i + 1u == s_sc[lo + 1] ? 0x80000000u : 0u);
+		cdesc[i] = cd;
+	}
+}
+
 }  // namespace
+
+// ---- segmented launches ----
+void clo_radixw_seg_bounds(size_t numel, int npieces, int nseg, size_t tile, size_t* max_tiles, size_t* max_chunks) {
+	// every piece may end in a partial tile, and a segment's tiles in a partial chunk
+	*max_tiles = numel / tile + (size_t) npieces;
+	*max_chunks = *max_tiles / RW_CHUNK + (size_t) nseg;
+}
+
+int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int nseg, size_t tile,
+	clo_seg_tile* tiles, clo_seg_chunk* chunks, unsigned* ntiles, unsigned* nchunks, hipStream_t s) {
+	if (nseg < 1 || nseg > CLO_SEG_MAX || npieces < 1 || npieces > CLO_SEG_MAX) return CLO_HIP_EARGS;
+	clo_seg_pieces c;
+	size_t seg_tiles[CLO_SEG_MAX];
+	for (int k = 0; k < CLO_SEG_MAX; ++k) seg_tiles[k] = 0;
+	size_t nt = 0, nc = 0, total = 0;
+	int prev = 0;
+	for (int i = 0; i < CLO_SEG_MAX; ++i) {
+		const size_t n = i < npieces ? piece_n[i] : 0;
+		const int sg = i < npieces ? piece_seg[i] : prev;
+		if (n > 0xffffffffull || sg < prev || sg >= nseg) return CLO_HIP_EARGS;   // (pieces come in segment order)
+		prev = sg;
+		c.n[i] = (unsigned) n;
+		c.in_base[i] = i < npieces ? (unsigned) piece_base[i] : 0u;
+		c.seg[i] = (unsigned short) sg;
+		const size_t t = (n + tile - 1) / tile;
+		seg_tiles[sg] += t;
+		nt += t;
+		total += n;
+	}
+	for (int k = 0; k < nseg; ++k) nc += (seg_tiles[k] + RW_CHUNK - 1) / RW_CHUNK;
+	if (total > 0xffffffffull) return CLO_HIP_EARGS;
+	*ntiles = (unsigned) nt;
+	*nchunks = (unsigned) nc;
+	if (nt == 0) return 0;
+	hipLaunchKernelGGL(clo_radix_seg_build_kernel, dim3((unsigned) ((nt + SEG_BUILD_THREADS - 1) / SEG_BUILD_THREADS)), dim3(SEG_BUILD_THREADS), 0, s,
+		c, (unsigned) npieces, (unsigned) tile, (unsigned) nt, (unsigned) nc, tiles, chunks);
+	return (int) hipGetLastError();
+}
+
+size_t clo_radixw_partial_rows_seg(size_t chunks, size_t nseg) { return chunks + 1 + nseg; }
+
+template <typename E>
+static int rw_launch_tilehist_seg(const void* in, const clo_seg_tables& sg, int bits, unsigned shift, unsigned mask, unsigned* thist,
+	unsigned* tinfo, unsigned* partial, bool big, hipStream_t s) {
+	const unsigned clear_words = (sg.nchunks + 1u) << bits;
+	const clo_keyx kx_none = { 0, 0, 0 };
+	if (bits != 8) return CLO_HIP_EUNSUPPORTED;   // (the segmented sorts run the radix-16 / 256 schedule only)
+	if (big) hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, 8, true, true>), dim3(sg.ntiles), dim3(rw_shape<E, true>::THREADS), 0, s,
+		(const E*) in, (size_t) 0, shift, mask, thist, tinfo, 0, kx_none, partial, clear_words, sg.tiles);
+	else hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, 8, false, true>), dim3(sg.ntiles), dim3(rw_shape<E, false>::THREADS), 0, s,
+		(const E*) in, (size_t) 0, shift, mask, thist, tinfo, 0, kx_none, partial, clear_words, sg.tiles);
+	return (int) hipGetLastError();
+}
+
+int clo_radixw_launch_tilehist_seg(const void* in, const clo_seg_tables& sg, int elem_size, int bits, unsigned shift, unsigned mask,
+	unsigned* thist, unsigned* tinfo, unsigned* partial, bool big, hipStream_t s) {
+	switch (elem_size) {
+		case 4: return rw_launch_tilehist_seg<uint32_t>(in, sg, bits, shift, mask, thist, tinfo, partial, big, s);
+		case 8: return rw_launch_tilehist_seg<uint64_t>(in, sg, bits, shift, mask, thist, tinfo, partial, big, s);
+		default: return CLO_HIP_EUNSUPPORTED;
+	}
+}
+
+int clo_radixw_launch_tilehist_bytes_seg(const unsigned char* dig, const clo_seg_tables& sg, int elem_size, int bits, unsigned mask,
+	unsigned* thist, unsigned* tinfo, unsigned* partial, bool big, hipStream_t s) {
+	const unsigned clear_words = (sg.nchunks + 1u) << bits;
+	if (bits != 8 || !big) return CLO_HIP_EUNSUPPORTED;
+	if (elem_size == 8) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<8, 8, 1024, true>), dim3(sg.ntiles), dim3(1024), 0, s,
+		dig, (size_t) 0, mask, thist, tinfo, partial, clear_words, sg.tiles);
+	else if (elem_size == 4) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<8, 16, 1024, true>), dim3(sg.ntiles), dim3(1024), 0, s,
+		dig, (size_t) 0, mask, thist, tinfo, partial, clear_words, sg.tiles);
+	else return CLO_HIP_EUNSUPPORTED;
+	return (int) hipGetLastError();
+}
+
+int clo_radixw_launch_offsets_seg(int bits, const unsigned* thist, const clo_seg_tables& sg, unsigned* partial, unsigned* toff,
+	const unsigned** dbase, hipStream_t s) {
+	if (bits != 8) return CLO_HIP_EUNSUPPORTED;
+	hipLaunchKernelGGL((clo_radixw_offsets_lb_kernel<256, true>), dim3(sg.nchunks), dim3(RW_CS_THREADS), 0, s,
+		thist, sg.ntiles, sg.nchunks, partial, toff, sg.chunks);
+	*dbase = partial + ((size_t) (sg.nchunks + 1u) << bits);
+	return (int) hipGetLastError();
+}
 
 // ---- the histogram / counter-scan steps for any digit width 1..8 (used by
 // the digit-pair passes of clo_hip_radix4.hip) ----

@@ -187,14 +187,34 @@ int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
 	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits, const unsigned char* first_digits,
 	void* workspace, size_t workspace_bytes, void* stream);
 
+/* Segmented sort (new functionality, the local step of the sharded sort): `nseg` (1..256) segments of ONE array —
+ * seg_counts[i] elements each, host memory, summing to numel — are sorted independently, each stably by the key
+ * field [key_shift, key_shift + key_bits), in SHARED launches: a launch's tiles and counter-scan chunks are
+ * numbered through all segments and one small table lookup tells a work-group which segment it works for.
+ * Sub-buckets that share their top key bits (what an MSD partition leaves) are thereby sorted on the REMAINING
+ * bits at the rate of one large sort, where sorting them one by one would be launch-bound.
+ * Where the segments lie: the RESULT holds them back to back in order (segment k at the sum of the counts before
+ * it). The SOURCE `a` either holds them the same way (npieces = 0) or in up to 256 PIECES anywhere inside
+ * a[0 .. numel): piece i = piece_counts[i] elements from piece_offsets[i], belonging to segment piece_segment[i],
+ * pieces listed in segment order (what a rank of the sharded sort receives: one piece per source rank and
+ * sub-bucket); the first pass then gathers a segment's pieces, in the order listed, as a by-product.
+ * The two buffers take turns: the result is in `b` when *result_in_b comes back 1 (an odd number of 8-bit
+ * passes), else in `a`; `a` is overwritten either way. digit_bits 4 or 8 (radix 16 / 256), elem_size 4 or 8,
+ * unsigned keys. Asynchronous; the host arrays are read before the call returns. */
+size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, int digit_bits);
+int clo_hip_radix_sort_segmented(void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
+	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream,
+	int* result_in_b);
+
 /* MSD bucket partition used by the multi-GPU exchange (new
  * functionality): stable split of src into 1<<bucket_bits buckets by the top
  * bucket_bits of the key field; dst gets the buckets back to back in bucket
  * order. counts_dev (device, 1<<bucket_bits uint64; may be NULL for the
  * partition) receives the bucket sizes — the partition produces them as a
- * by-product, clo_hip_msd_histogram computes them alone. bucket_bits: 1..6 for
- * the partition (up to 8 ranks x 8 sub-buckets per rank, include/clo_shard.h),
- * 1..3 for the histogram alone. */
+ * by-product, clo_hip_msd_histogram computes them alone. bucket_bits: 1..8 for
+ * the partition (the sharded sort splits on 8: ranks x sub-buckets per rank = 256,
+ * include/clo_shard.h), 1..3 for the histogram alone. */
 int clo_hip_msd_histogram(const void* src, size_t numel, int elem_size,
 	int key_shift, int key_bits, int bucket_bits,
 	uint64_t* counts_dev, void* stream);

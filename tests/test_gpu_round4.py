@@ -1,0 +1,145 @@
+"""Round-4 GPU parity tests: the segmented sort (clo_hip_radix_sort_segmented, the local step of the sharded sort
+since round 4) and the 8-bit MSD partition, through the C-ABI, bit-exact against numpy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import cl_ops_amd  # noqa: F401
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _seg_sort(torch, a, seg_counts, key_shift, key_bits, digit_bits=4, pieces=None):
+    """Runs clo_hip_radix_sort_segmented on the array `a` (numpy, uint32 / uint64); returns the result (numpy)."""
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    es = a.dtype.itemsize
+    n = a.size
+    tdt = np.int32 if es == 4 else np.int64
+    ta = torch.from_numpy(a.view(tdt).copy()).cuda()
+    tb = torch.full_like(ta, -1)
+    nseg = len(seg_counts)
+    need = lib.clo_hip_radix_seg_workspace_bytes(n, nseg, es, digit_bits)
+    assert need > 0
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    sc = (C.c_size_t * nseg)(*[int(x) for x in seg_counts])
+    if pieces is not None:
+        pn, po, ps = pieces
+        npc = len(pn)
+        args = ((C.c_size_t * npc)(*[int(x) for x in pn]), (C.c_size_t * npc)(*[int(x) for x in po]), (C.c_int * npc)(*[int(x) for x in ps]), npc)
+    else:
+        args = (None, None, None, 0)
+    in_b = C.c_int(-1)
+    st = lib.clo_hip_radix_sort_segmented(ta.data_ptr(), tb.data_ptr(), n, sc, nseg, *args, es, key_shift, key_bits, digit_bits,
+                                          ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream, C.byref(in_b))
+    _hip.check(st, "clo_hip_radix_sort_segmented")
+    torch.cuda.synchronize()
+    assert in_b.value == (-(-key_bits // 8)) % 2
+    return (tb if in_b.value else ta).cpu().numpy().view(a.dtype)
+
+
+def _expect(a, seg_counts, key_shift, key_bits):
+    out = np.empty_like(a)
+    at = 0
+    mask = a.dtype.type((1 << key_bits) - 1)
+    for c in seg_counts:
+        seg = a[at:at + c]
+        k = (seg >> a.dtype.type(key_shift)) & mask
+        out[at:at + c] = seg[np.argsort(k, kind="stable")]
+        at += c
+    return out
+
+
+@pytest.mark.parametrize("dt,n,nseg,key_bits", [
+    (np.uint32, 1 << 20, 16, 24), (np.uint32, (1 << 22) + 12345, 64, 24), (np.uint32, 70001, 5, 24),
+    (np.uint64, (1 << 20) + 77, 32, 56), (np.uint32, 1 << 18, 256, 24), (np.uint32, (1 << 21) + 3, 7, 20),
+    (np.uint32, 1 << 16, 3, 8), (np.uint64, 1 << 19, 9, 16), (np.uint32, 5000, 256, 24)])
+def test_segmented_sort_contiguous(gpu, dt, n, nseg, key_bits):
+    rng = np.random.default_rng(n + nseg)
+    a = rng.integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    cuts = np.sort(rng.integers(0, n + 1, nseg - 1))
+    if nseg >= 5:
+        cuts[1] = cuts[0]                         # an empty segment
+    seg_counts = np.diff(np.concatenate(([0], cuts, [n])))
+    got = _seg_sort(gpu, a, seg_counts, 0, key_bits)
+    assert np.array_equal(got, _expect(a, seg_counts, 0, key_bits))
+
+
+@pytest.mark.parametrize("dt,logn", [(np.uint32, 26), (np.uint64, 24)])
+def test_segmented_sort_big_tiles_and_digit_stream(gpu, dt, logn):
+    """>= 256 MiB (32 MiB of 8-byte elements): 16 384-element tiles, the digit bytes between the passes."""
+    n = (1 << logn) + 4099
+    rng = np.random.default_rng(logn)
+    a = rng.integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    nseg = 64
+    seg_counts = np.full(nseg, n // nseg)
+    seg_counts[-1] += n - seg_counts.sum()
+    seg_counts[3] += 1000
+    seg_counts[4] -= 1000
+    kb = 8 * a.dtype.itemsize - 8
+    got = _seg_sort(gpu, a, seg_counts, 0, kb)
+    assert np.array_equal(got, _expect(a, seg_counts, 0, kb))
+
+
+def test_segmented_sort_one_huge_segment_among_small_ones(gpu):
+    """Skew: one segment of many counter-scan chunks between tiny ones."""
+    n = (1 << 23) + 17
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    seg_counts = np.array([3, 0, 100, n - 3 - 100 - 9000 - 1, 9000, 1])
+    got = _seg_sort(gpu, a, seg_counts, 0, 24)
+    assert np.array_equal(got, _expect(a, seg_counts, 0, 24))
+
+
+@pytest.mark.parametrize("dt,n,nseg,nsrc", [(np.uint32, (1 << 21) + 9, 8, 4), (np.uint64, 1 << 20, 32, 8), (np.uint32, (1 << 26) + 5, 8, 8)])
+def test_segmented_sort_gathers_pieces(gpu, dt, n, nseg, nsrc):
+    """The source holds every segment in `nsrc` pieces, laid out source-major (what a rank of the sharded sort
+    receives: for every source rank its sub-buckets back to back); the result holds the segments back to back."""
+    rng = np.random.default_rng(n % 1000 + nsrc)
+    sizes = rng.multinomial(n, np.ones(nseg * nsrc) / (nseg * nsrc)).reshape(nsrc, nseg)   # [source][segment]
+    sizes[1, 2] += sizes[0, 2]
+    sizes[0, 2] = 0                                   # an empty piece
+    a = rng.integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    off = np.concatenate(([0], np.cumsum(sizes.reshape(-1))[:-1])).reshape(nsrc, nseg)     # source-major layout
+    pn, po, ps = [], [], []
+    for k in range(nseg):
+        for p in range(nsrc):
+            pn.append(sizes[p, k]); po.append(off[p, k]); ps.append(k)
+    seg_counts = sizes.sum(axis=0)
+    kb = 8 * a.dtype.itemsize - 8
+    got = _seg_sort(gpu, a, seg_counts, 0, kb, pieces=(pn, po, ps))
+    # expected: segment k = its pieces in source order, stably sorted by the low bits
+    gathered = np.concatenate([a[off[p, k]:off[p, k] + sizes[p, k]] for k in range(nseg) for p in range(nsrc)])
+    assert np.array_equal(got, _expect(gathered, seg_counts, 0, kb))
+
+
+@pytest.mark.parametrize("dt,bits", [(np.uint32, 7), (np.uint32, 8), (np.uint64, 8)])
+def test_msd_partition_on_seven_and_eight_bits(gpu, dt, bits):
+    torch = gpu
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    n = (1 << 22) + 333
+    es = np.dtype(dt).itemsize
+    a = np.random.default_rng(bits).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    tdt = np.int32 if es == 4 else np.int64
+    src = torch.from_numpy(a.view(tdt).copy()).cuda()
+    dst = torch.empty_like(src)
+    counts = torch.zeros(1 << bits, dtype=torch.int64, device="cuda")
+    need = lib.clo_hip_msd_workspace_bytes(n, es, bits)
+    assert need > 0
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    _hip.check(lib.clo_hip_msd_partition(src.data_ptr(), dst.data_ptr(), n, es, 0, 8 * es, bits, counts.data_ptr(), ws.data_ptr(), need,
+                                         torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    top = a >> dt(8 * es - bits)
+    assert np.array_equal(dst.cpu().numpy().view(dt), a[np.argsort(top, kind="stable")])
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(top.astype(np.int64), minlength=1 << bits))
