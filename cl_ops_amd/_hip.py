@@ -60,6 +60,7 @@ _sig("clo_hip_event_create", ci, C.POINTER(vp))
 _sig("clo_hip_event_destroy", ci, vp)
 _sig("clo_hip_event_record", ci, vp, vp)
 _sig("clo_hip_event_synchronize", ci, vp)
+_sig("clo_hip_event_query", ci, vp)
 _sig("clo_hip_event_elapsed_ms", ci, vp, vp, C.POINTER(C.c_float))
 _sig("clo_hip_stream_wait_event", ci, vp, vp)
 _sig("clo_hip_error_string", C.c_char_p, ci)

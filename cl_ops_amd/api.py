@@ -139,11 +139,13 @@ _sig("clo_scan_get_localmem_usage", sz, vp, _u32, sz, sz, _E)
 SHARD_AG = C.CFUNCTYPE(ci, vp, vp, vp, sz, vp)
 SHARD_A2A = C.CFUNCTYPE(ci, vp, vp, C.POINTER(sz), C.POINTER(sz), vp, C.POINTER(sz), C.POINTER(sz), vp)
 SHARD_DESTROY = C.CFUNCTYPE(None, vp)
+SHARD_ALLOC = C.CFUNCTYPE(vp, vp, sz)
+SHARD_FREE = C.CFUNCTYPE(None, vp, vp)
 
 
 class ShardTransportStruct(C.Structure):
     _fields_ = [("user", vp), ("rank", ci), ("world", ci), ("all_gather_u64", SHARD_AG), ("all_to_all_v", SHARD_A2A),
-                ("destroy", SHARD_DESTROY), ("abort", SHARD_DESTROY)]
+                ("destroy", SHARD_DESTROY), ("abort", SHARD_DESTROY), ("recv_alloc", SHARD_ALLOC), ("recv_free", SHARD_FREE)]
 
 
 _sig("clo_shard_rccl_unique_id", _u32, vp, _E)
@@ -154,7 +156,7 @@ _sig("clo_shard_sort_destroy", None, vp)
 _sig("clo_shard_sort_with_device_data", vp, vp, vp, vp, sz, C.POINTER(vp), C.POINTER(sz), _E)
 _sig("clo_shard_sort_get_phase_ms", None, vp, C.POINTER(C.c_double * 4))
 _sig("clo_shard_plan", None, C.POINTER(C.c_uint64), ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
-_sig("clo_shard_plan_slice", sz, C.POINTER(C.c_uint64), sz, ci, ci, ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
+_sig("clo_shard_plan_slice", sz, C.POINTER(C.c_uint64), sz, ci, ci, ci, ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
      C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
 _sig("clo_shard_sort_get_exchange", None, vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_double), C.POINTER(ci))
 
@@ -480,10 +482,11 @@ class ShardTransport:
         return cls(p)
 
     @classmethod
-    def custom(cls, rank, world, all_gather_u64, all_to_all_v):
+    def custom(cls, rank, world, all_gather_u64, all_to_all_v, recv_alloc=None, recv_free=None):
         """all_gather_u64(send_ptr, recv_ptr, count, stream) -> status;
         all_to_all_v(send_ptr, send_bytes, send_off, recv_ptr, recv_bytes, recv_off, stream) -> status
-        (the four arrays as Python lists of `world` ints)."""
+        (the four arrays as Python lists of `world` ints); optional recv_alloc(bytes) -> device pointer or None,
+        recv_free(ptr): the transport's own memory for the receive buffers."""
         def ag(user, s, r, count, stream):
             return int(all_gather_u64(s, r, count, stream) or 0)
 
@@ -494,8 +497,14 @@ class ShardTransport:
 
         def ab(user):
             aborted.append(True)
-        st = ShardTransportStruct(None, rank, world, SHARD_AG(ag), SHARD_A2A(a2a), SHARD_DESTROY(), SHARD_DESTROY(ab))
-        t = cls(C.pointer(st), keep=(st, ag, a2a, ab), owned=False)
+        def ra(user, nbytes):
+            return recv_alloc(nbytes) or None
+
+        def rf(user, ptr):
+            recv_free(ptr)
+        st = ShardTransportStruct(None, rank, world, SHARD_AG(ag), SHARD_A2A(a2a), SHARD_DESTROY(), SHARD_DESTROY(ab),
+                                  SHARD_ALLOC(ra) if recv_alloc else SHARD_ALLOC(), SHARD_FREE(rf) if recv_free else SHARD_FREE())
+        t = cls(C.pointer(st), keep=(st, ag, a2a, ab, ra, rf), owned=False)
         t.aborted = aborted          # non-empty once the C driver has asked for an abort
         return t
 

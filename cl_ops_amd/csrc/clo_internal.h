@@ -120,6 +120,15 @@ typedef struct {
 	 * first: growing a buffer between two of them would free memory the earlier one is still using — hipFree
 	 * waits for the device, and the overlap the slices exist for is gone. */
 	cl_bool (*reserve)(struct clo_sort* sorter, CCLQueue* cq_exec, size_t numel, GError** err);
+	/* sort_segments: `nseg` segments of one device range of `numel` elements, each sorted on its own by the key bits
+	 * [key_shift, key_shift + key_bits), in shared launches (clo_hip_radix_sort_segmented, include/clo_hip.h: where the
+	 * segments and the optional pieces lie; the result is in b_dev when *result_in_b, else in a_dev; a_dev is overwritten).
+	 * *handled = 0 and nothing enqueued when this sorter cannot (another radix than 16 / 256, element size, key kind) —
+	 * the caller then sorts the range some other way. reserve_segments grows the buffers it needs for that size NOW. */
+	CCLEvent* (*sort_segments)(struct clo_sort* sorter, CCLQueue* cq_exec, void* a_dev, void* b_dev, size_t numel,
+		const size_t* seg_counts, int nseg, const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
+		int key_shift, int key_bits, int* result_in_b, int* handled, GError** err);
+	cl_bool (*reserve_segments)(struct clo_sort* sorter, CCLQueue* cq_exec, size_t numel, int nseg, int* handled, GError** err);
 } clo_sort_impl_ext;
 const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name);
 extern const clo_sort_impl_ext clo_sort_satradix_ext;

@@ -38,6 +38,7 @@ typedef struct {
 	clo_devbuf tmp;       /* ping-pong partner of the array being sorted */
 	clo_devbuf workspace; /* per-tile histograms, offsets, chunk sums */
 	clo_devbuf pairs;     /* (ordered key, index) pairs of a run-time compiled get_key */
+	clo_devbuf seg_ws;    /* workspace of the segmented sorts (sort_segments: the sharded sort's local step) */
 	clo_status_cell* status;  /* the workspace's status word, for the sorts whose kernels poll (clo_hip_radix_polls) */
 	void* ws_ready;           /* the allocation whose header (status word) has been cleared */
 	size_t ws_ready_bytes;
@@ -461,8 +462,70 @@ static cl_bool clo_sort_satradix_reserve(CloSort* sorter, CCLQueue* cq_exec, siz
 	return (numel == 0 || satradix_reserve(sorter, cq_exec, numel, err)) ? CL_TRUE : CL_FALSE;
 }
 
+/* ---- segmented sorts (clo_internal.h: clo_sort_impl_ext.sort_segments) ---- */
+static int satradix_segments_apply(CloSort* sorter) {
+	clo_sort_satradix_data* data = (clo_sort_satradix_data*) clo_sort_get_data(sorter);
+	const CloSortKeySpec* ks = clo_sort_get_key_spec(sorter);
+	return (data->radix == 16 || data->radix == 256) && (ks->elem_size == 4 || ks->elem_size == 8) && ks->key_kind == 0
+		&& clo_sort_get_jit(sorter) == NULL;
+}
+
+static cl_bool clo_sort_satradix_reserve_segments(CloSort* sorter, CCLQueue* cq_exec, size_t numel, int nseg, int* handled, GError** err) {
+	clo_sort_satradix_data* data = (clo_sort_satradix_data*) clo_sort_get_data(sorter);
+	const CloSortKeySpec* ks = clo_sort_get_key_spec(sorter);
+	*handled = satradix_segments_apply(sorter);
+	if (!*handled || numel == 0) return CL_TRUE;
+	if (clo_hip_failed(clo_stream_guard_enter(&data->guard, cq_exec), err, "hipStreamWaitEvent")) return CL_FALSE;
+	const size_t need = clo_hip_radix_seg_workspace_bytes(numel, nseg, ks->elem_size, (int) clo_tzc((int) data->radix));
+	if (need == 0) { *handled = 0; return CL_TRUE; }
+	if (clo_hip_failed(clo_devbuf_reserve(&data->seg_ws, need), err, "hipMalloc(satradix segmented workspace)")) return CL_FALSE;
+	return CL_TRUE;
+}
+
+static CCLEvent* clo_sort_satradix_sort_segments(CloSort* sorter, CCLQueue* cq_exec, void* a_dev, void* b_dev, size_t numel,
+	const size_t* seg_counts, int nseg, const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
+	int key_shift, int key_bits, int* result_in_b, int* handled, GError** err) {
+	clo_sort_satradix_data* data = (clo_sort_satradix_data*) clo_sort_get_data(sorter);
+	const CloSortKeySpec* ks = clo_sort_get_key_spec(sorter);
+	*result_in_b = 0;
+	if (!clo_sort_satradix_reserve_segments(sorter, cq_exec, numel, nseg, handled, err)) return NULL;
+	if (!*handled) return NULL;
+	static const clo_kname knames[] = {
+		{ "radix_hist", CLO_SORT_SATRADIX_KNAME_HISTOGRAM }, { "radix_offsets", "clo_scan_blelloch_wgscan" },
+		{ "radix_pass", CLO_SORT_SATRADIX_KNAME_SCATTER }, { "radix_seg_tables", CLO_SORT_SATRADIX_KNAME_LOCALSORT }
+	};
+	const int per_kernel = ccl_queue_is_profiling(cq_exec) && numel > 0;
+	clo_kernel_events ke;
+	CCLEvent* evt = NULL;
+	if (per_kernel) {
+		clo_kernel_events_install(&ke, cq_exec, knames, sizeof(knames) / sizeof(knames[0]), CLO_SORT_SATRADIX_KNAME_SCATTER);
+	} else {
+		evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
+		if (!evt) return NULL;
+	}
+	if (numel > 0) {
+		const int st = clo_hip_radix_sort_segmented(a_dev, b_dev, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
+			ks->elem_size, key_shift, key_bits, (int) clo_tzc((int) data->radix), data->seg_ws.ptr, data->seg_ws.bytes,
+			ccl_queue_get_stream(cq_exec), result_in_b);
+		if (clo_hip_failed(st, err, "clo_hip_radix_sort_segmented")) {
+			if (per_kernel) clo_kernel_events_remove(&ke, NULL); else ccl_queue_abort_command(cq_exec, evt);
+			return NULL;
+		}
+	}
+	if (per_kernel) {
+		GError* e2 = NULL;
+		CCLEvent* last = clo_kernel_events_remove(&ke, &e2);
+		if (e2) { clo_gerror_propagate(err, e2); return NULL; }
+		if (last) return last;
+		evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
+		if (!evt) return NULL;
+	}
+	if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); return NULL; }
+	return evt;
+}
+
 const clo_sort_impl_ext clo_sort_satradix_ext = { "satradix", clo_sort_satradix_check_status, clo_sort_satradix_host_pipeline,
-	clo_sort_satradix_reserve };
+	clo_sort_satradix_reserve, clo_sort_satradix_sort_segments, clo_sort_satradix_reserve_segments };
 
 typedef struct {
 	clo_sort_satradix_data* data;
@@ -518,6 +581,7 @@ static void satradix_free(clo_sort_satradix_data* data) {
 	clo_devbuf_release(&data->tmp);
 	clo_devbuf_release(&data->workspace);
 	clo_devbuf_release(&data->pairs);
+	clo_devbuf_release(&data->seg_ws);
 	clo_stream_guard_release(&data->guard);
 	free(data);
 }

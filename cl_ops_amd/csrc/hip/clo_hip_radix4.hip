@@ -444,6 +444,17 @@ void clo_radix4_counts_kernel(const unsigned* __restrict__ thist, unsigned tiles
 	}
 }
 
+// The same sizes out of the counter scan's digit bases (an exclusive scan of them over the digits): a difference per
+// bucket. (Summing the per-tile histograms with ONE work-group — the kernel above, fine for the 2 .. 64 buckets of
+// rounds 1-3, whose threads split the tiles among 256 / R groups — walks every tile in every thread when R = 256:
+// 6.5 ms for 2^28 keys, ten times the partition itself.)
+template <int R, int R2>
+__global__ __launch_bounds__(256)
+void clo_radix4_counts_from_bases_kernel(const unsigned* __restrict__ dbase, unsigned n, unsigned long long* __restrict__ counts) {
+	const unsigned d = threadIdx.x;
+	if (d < (unsigned) R) counts[d] = (unsigned long long) ((d + 1u < (unsigned) R2 ? dbase[d + 1u] : n) - dbase[d]);
+}
+
 // One stable pass on `BITS` bits at `shift`: the MSD bucket split of the
 // multi-GPU exchange. Up to 3 bits: the pair kernel with no high digit; 4 .. 8 bits
 // (the buckets of the ranks times the sub-buckets of a rank, include/clo_shard.h: 8 since
@@ -468,11 +479,13 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 	const unsigned mask_lo = TWO ? (1u << LB) - 1u : R - 1u, mask_hi = TWO ? (1u << HB) - 1u : 0u;
 	int st = clo_radixw_launch_tilehist(src, n, (int) sizeof(E), PB, shift, R - 1u, thist, tinfo, partial, tiles, big, kx_none, s);
 	if (st != 0) return st;
-	if (counts)
-		hipLaunchKernelGGL((clo_radix4_counts_kernel<R, (1 << PB)>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);
 	const unsigned* dbase = nullptr;
 	st = clo_radixw_launch_offsets(PB, thist, tiles, partial, toff, &dbase, s);
 	if (st != 0) return st;
+	if (counts) {
+		if (dbase) hipLaunchKernelGGL((clo_radix4_counts_from_bases_kernel<R, (1 << PB)>), dim3(1), dim3(256), 0, s, dbase, (unsigned) n, counts);
+		else hipLaunchKernelGGL((clo_radix4_counts_kernel<R, (1 << PB)>), dim3(1), dim3(256), 0, s, (const unsigned*) thist, tiles, counts);   // (one tile)
+	}
 	if (big)
 		hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false>), dim3((tiles + 7u) / 8u * 8u), dim3(pair_shape<E, true>::THREADS), 0, s,
 			src, dst, n, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo,

@@ -367,6 +367,10 @@ void clo_radixw_offsets1_kernel(const unsigned* __restrict__ thist, unsigned til
 // scans the (at most 256) lengths itself — a few hundred LDS operations — and then describes one tile and one chunk
 // per thread: one launch per sort, whatever the number of tiles.
 // ---------------------------------------------------------------------------
+// (Tiles start wherever their piece starts: 16-byte loads at addresses that are only element-aligned measured no
+// slower — giving every misaligned piece a short first tile that ends on a 16-element boundary of memory, so that all
+// later tiles load aligned, changed nothing: 2^28 uint32 keys in 256 segments, 0.593 -> 0.608 ms per pass, the partial
+// tiles it adds cost more than the alignment buys.)
 constexpr int SEG_BUILD_THREADS = 1024;
 __global__ __launch_bounds__(SEG_BUILD_THREADS)
 void clo_radix_seg_build_kernel(clo_seg_pieces pc, unsigned npieces, unsigned tile, unsigned ntiles, unsigned nchunks,

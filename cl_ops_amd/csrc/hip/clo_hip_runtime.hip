@@ -166,6 +166,7 @@ int clo_hip_event_record(void* event, void* stream) {
 	return (int) hipEventRecord((hipEvent_t) event, (hipStream_t) stream);
 }
 int clo_hip_event_synchronize(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }
+int clo_hip_event_query(void* event) { return event ? (int) hipEventQuery((hipEvent_t) event) : CLO_HIP_EARGS; }
 int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
 	return ms ? (int) hipEventElapsedTime(ms, (hipEvent_t) start, (hipEvent_t) stop) : CLO_HIP_EARGS;
 }

@@ -70,6 +70,7 @@ int clo_hip_event_create(void** event);
 int clo_hip_event_destroy(void* event);
 int clo_hip_event_record(void* event, void* stream);
 int clo_hip_event_synchronize(void* event);
+int clo_hip_event_query(void* event);   /* 0 = the event has completed; anything else: not yet (or an error) */
 int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms);
 /* Make `stream` wait for `event` (cq_exec waiting on a cq_comm copy,
  * sort/clo_sort_sbitonic.c:86-95). */

@@ -9,36 +9,59 @@
  *
  * One process per GPU. With G = world size (a power of two), rank r ends up
  * holding bucket r — the keys whose top log2(G) bits equal r — sorted; the ranks'
- * results in rank order are the globally sorted array. Per sort:
- *   1. stable local partition into G buckets by the top log2(G) key bits; the
- *      bucket sizes are a by-product              (clo_hip_msd_partition)
- *   2. all-gather of the G counts                  (transport: all_gather_u64)
- *   3. all-to-all(v) of the buckets                (transport: all_to_all_v — over
- *      RCCL one group of ncclSend/ncclRecv pairs, every pair on its own xGMI link)
- *   4. local satradix of what arrived              (clo_sort_with_device_data)
+ * results in rank order are the globally sorted array. Per sort (round 4):
+ *   1. stable local partition by the top 8 key bits into 256 sub-buckets, 256 / G
+ *      per destination rank (ascending key ranges); their sizes are a by-product
+ *                                                  (clo_hip_msd_partition: ONE radix pass)
+ *   2. all-gather of the 256 counts + a status word + the receive capacity per rank
+ *                                                  (transport: all_gather_u64)
+ *   3. all-to-all(v) of the sub-buckets in S slices (S = 1, 2, 4 or 8; slice j = the
+ *      sub-buckets [j * 256 / (G S), (j + 1) * 256 / (G S)) of every rank: one contiguous
+ *      range per pair of ranks) on a stream of its own   (transport: all_to_all_v — over
+ *      RCCL one group of ncclSend/ncclRecv pairs per slice, every pair on its own xGMI link)
+ *   4. per slice, ONE segmented sort of its sub-buckets on the remaining key bits
+ *      (clo_hip_radix_sort_segmented: every sub-buckets sorted on its own, in launches
+ *      shared by all of them; its first pass gathers a sub-bucket's G pieces — one per
+ *      source rank — as a by-product), on cq_exec while slice j + 1 travels.
+ * The partition consumes 8 key bits, so the local sorts run one 8-bit pass fewer than a
+ * plain sort: partition + local sort together make exactly the passes a single-GPU sort
+ * of the same keys makes (4 for uint, 8 for ulong) — the exchange is what a sharded sort
+ * adds, not a pass. (Round 3 partitioned on log2(G S) <= 6 bits and sorted every slice
+ * on the full key width: one pass more, and S mid-size sorts instead of shared launches.)
+ * Arrays below 2^22 keys per rank (global mean) and sorters whose radix is neither 16 nor
+ * 256 use one exchange and one plain sort of the whole bucket.
  * The two exchanges go through a small table of functions (CloShardTransport):
  * RCCL in production (clo_shard_transport_new_rccl), anything else that moves the
  * same bytes in tests (two ranks on one GPU cannot use RCCL).
  *
- * Slices (round 3). The local sort of step 4 cannot start before the LAST key has
- * arrived, so with one exchange the links idle while the GPU sorts and the GPU idles
- * while the keys travel. With S = 2, 4 or 8 slices the partition of step 1 splits by
- * log2(G) + log2(S) top bits instead: every rank's bucket comes as S sub-buckets (key
- * ranges in ascending order). Sub-bucket j of every rank travels as one all-to-all(v)
- * on a stream of its own, and the local sort of sub-bucket j (in place, at its place in
- * the result) runs on cq_exec while sub-bucket j + 1 travels. Result and interface are
- * unchanged; `slices=1` in the options gives the single exchange.
+ * Slices. The local sort of a bucket cannot start before its LAST key has arrived, so
+ * with one exchange the links idle while the GPU sorts and the GPU idles while the keys
+ * travel. With S slices the sort of slice j runs while slice j + 1 travels. How many
+ * slices pay depends on the links' rate against the sort's, which only a run shows:
+ * `slices=auto` (the default) times every sliced call on the device, shares the times
+ * through the count exchange (so that every rank holds the same table and decides the
+ * same), tries 4, 2, 1 and 8 slices twice each for a size class and then keeps the
+ * fastest; `slices=1|2|4|8` fixes the number.
  *
  * Failing together. A rank that fails before a collective its peers enter would leave
  * them waiting inside RCCL for ever. So nothing that can fail on one rank alone sits
- * between "decided to communicate" and the collective: every rank ALWAYS joins the
- * count exchange and contributes a status word with its counts (0 = fine); after it
- * every rank knows of every failure and all return an error without touching the key
- * exchange; whatever is decided from the count matrix (bucket too large for one GPU,
- * who has to grow its receive buffer) is decided identically everywhere, and growing a
- * buffer — the one local step left — is followed by a second agreement round. A failure
- * that still strikes in between (the runtime refusing to enqueue the exchange) aborts the
- * transport (ncclCommAbort), which fails the peers' pending operations.
+ * between "decided to communicate" and the collective: buffers (for the rank's receive
+ * capacity, the sorter's included), events and the transfer stream are made BEFORE the
+ * count exchange, every rank ALWAYS joins it and contributes a status word with its counts
+ * (0 = fine); after it every rank knows of every failure and all return an error without
+ * touching the key exchange; whatever is decided from the count matrix (bucket too large
+ * for one GPU, who has to grow its receive buffer, how many slices) is decided identically
+ * everywhere, and growing buffers — the one local step left, only when a bucket exceeds
+ * the capacity — is followed by a second agreement round. After that nothing is allocated.
+ * What can still fail is the runtime refusing to enqueue: while the exchange is being
+ * enqueued that aborts the transport (ncclCommAbort: this rank's part of the collective
+ * can no longer happen); once all of this rank's transfers are enqueued, a later failure
+ * (a sort that cannot be launched) is this rank's alone and is only RETURNED — the
+ * exchange completes for the peers. An abort is local: it does not wake peers that are
+ * already blocked inside a transfer with the aborted rank. A deployment that must survive
+ * such a runtime failure polls ncclCommGetAsyncError or bounds its waits (bench.py: a
+ * watchdog per leg); the protocol above only guarantees that no LOCAL failure — arguments,
+ * memory — ever reaches that state.
  */
 #ifndef CLO_SHARD_H
 #define CLO_SHARD_H
@@ -62,9 +85,14 @@ typedef struct clo_shard_transport {
 	int (*all_to_all_v)(void* user, const void* send_dev, const size_t* send_bytes, const size_t* send_offset,
 		void* recv_dev, const size_t* recv_bytes, const size_t* recv_offset, void* stream);
 	void (*destroy)(void* user);   /* may be NULL */
-	/* Ends the transport at once so that operations of it pending on ANY rank fail instead of
-	 * waiting for this rank (RCCL: ncclCommAbort). May be NULL. After it only destroy is called. */
+	/* Ends this rank's side of the transport at once (RCCL: ncclCommAbort): its pending operations fail instead
+	 * of waiting. May be NULL. After it only destroy is called. */
 	void (*abort)(void* user);
+	/* Optional (both or neither): device memory for the receive buffers, for transports whose transfers want
+	 * memory of their own kind (registered with the communicator, say). NULL from recv_alloc = out of memory:
+	 * reported like any allocation failure (the ranks fail together). */
+	void* (*recv_alloc)(void* user, size_t bytes);
+	void (*recv_free)(void* user, void* ptr);
 } CloShardTransport;
 
 /* The 128-byte id one rank creates and every rank passes to
@@ -79,9 +107,11 @@ void clo_shard_transport_destroy(CloShardTransport* t);
 typedef struct clo_shard_sort CloShardSort;
 
 /* elem_type: CLO_UINT or CLO_ULONG (the key is the whole element); options: the
- * satradix options of the local sort ("radix=16" ...) and `slices=S` (1, 2, 4 or 8
- * sub-buckets per rank, log2(world) + log2(S) <= 6; default 4 above 2^22 elements per
- * rank, else 1). The transport stays the caller's. */
+ * satradix options of the local sort ("radix=16" ...), `slices=S` (1, 2, 4, 8 or auto —
+ * the default, see above) and `loopback=1`: with a world of ONE rank, run the whole
+ * protocol all the same, the rank sending every slice to itself through the transport
+ * (a rehearsal of config 5's code path on a one-GPU box; without it one rank takes a
+ * shortcut: copy + local sort). The transport stays the caller's. */
 CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, CloType elem_type,
 	const char* options, GError** err);
 void clo_shard_sort_destroy(CloShardSort* ss);
@@ -110,12 +140,13 @@ void clo_shard_sort_get_exchange(CloShardSort* ss, size_t* bytes_out, size_t* by
  * the four arrays of rank `rank` (elements): send counts / offsets, receive counts / offsets. */
 void clo_shard_plan(const uint64_t* counts, int world, int rank,
 	size_t* send_counts, size_t* send_offsets, size_t* recv_counts, size_t* recv_offsets);
-/* The same for a sliced sort: counts[src * row + bucket * slices + j] (row = the stride
- * of a rank's row, >= world * slices); the four arrays of slice j (`world` entries each,
- * elements; offsets into the partitioned shard and into the result). *slice_offset (may
- * be NULL) = where sub-bucket j starts in the result, *slice_total its size. Returns the
- * size of this rank's whole bucket. */
-size_t clo_shard_plan_slice(const uint64_t* counts, size_t row, int world, int slices, int rank, int j,
+/* The same for a sliced sort: counts[src * row + dest * subs + k] (row = the stride of a
+ * rank's row, >= world * subs; subs sub-buckets per destination, slices divides subs);
+ * the four arrays of slice j (`world` entries each, elements; offsets into the partitioned
+ * shard and into the receive buffer, where the slices lie one after the other and inside a
+ * slice one block per source rank). *slice_offset (may be NULL) = where slice j starts in
+ * the receive buffer, *slice_total its size. Returns the size of this rank's whole bucket. */
+size_t clo_shard_plan_slice(const uint64_t* counts, size_t row, int world, int subs, int slices, int rank, int j,
 	size_t* send_counts, size_t* send_offsets, size_t* recv_counts, size_t* recv_offsets,
 	size_t* slice_offset, size_t* slice_total);
 

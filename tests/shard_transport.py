@@ -5,7 +5,10 @@ any send / receive offsets (the slices of a sliced sort start anywhere in the bu
 import numpy as np
 
 
-def gloo_staged_transport(rank, world):
+def gloo_staged_transport(rank, world, own_memory=False):
+    """own_memory: the transport also provides the receive buffers (CloShardTransport.recv_alloc / recv_free) —
+    torch allocations here — and refuses to while `t.alloc_state["fail"]` is set: what running out of memory on ONE
+    rank looks like to the sharded sort (its ranks must then fail together)."""
     import torch
     import torch.distributed as dist
     import cl_ops_amd as clo
@@ -53,4 +56,19 @@ def gloo_staged_transport(rank, world):
                 h2d(recv + ro[x[1]], x[0].numpy(), stream)
         return 0
 
-    return clo.ShardTransport.custom(rank, world, all_gather, all_to_all_v)
+    allocs, state = {}, {"fail": False}
+
+    def recv_alloc(nbytes):
+        if state["fail"]:
+            return None
+        t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device="cuda")
+        allocs[t.data_ptr()] = t
+        return t.data_ptr()
+
+    def recv_free(ptr):
+        allocs.pop(ptr, None)
+
+    tr = clo.ShardTransport.custom(rank, world, all_gather, all_to_all_v, recv_alloc if own_memory else None,
+                                   recv_free if own_memory else None)
+    tr.alloc_state = state
+    return tr

@@ -254,7 +254,7 @@ def _shard_worker(rank, world, port, etype, n, options, fail, out_dir):
     try:
         dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
         bits = 8 * np.dtype(dt).itemsize
-        tr = gloo_staged_transport(rank, world)
+        tr = gloo_staged_transport(rank, world, own_memory=bool(fail))
         a = np.random.default_rng(90 + rank).integers(0, np.iinfo(dt).max, n + 4099 * rank, dtype=dt, endpoint=True)
         if fail and fail[1] == 2:      # everything into the failing rank's bucket: its receive buffer has to grow
             a = (a >> dt(1)) | dt(fail[0] << (bits - 1))
@@ -265,13 +265,28 @@ def _shard_worker(rank, world, port, etype, n, options, fail, out_dir):
         s = CShardedSorter(etype, 0, transport=tr, options=options)
         text = ""
         if fail:
-            os.environ["CLO_SHARD_TEST_FAIL"] = "%d:%d" % fail
+            # a failure of ONE rank's own: stage 1 — its arguments are wrong (numel beyond its buffer), found before the
+            # count exchange; stage 2 — its receive buffer has to grow after the plan and the memory is not there
             try:
-                s.sort(local)
+                if fail[1] == 1 and rank == fail[0]:
+                    small = clo.Buffer(s.ctx, 64, device_ptr=local.data_ptr())
+                    try:
+                        s.ss.with_device_data(s.queue, small, local.numel())
+                    finally:
+                        small.close()
+                else:
+                    if fail[1] == 2 and rank == fail[0]:
+                        s.sort(local[:1000])               # (first call: the usual capacity, for 1000 keys)
+                        torch.cuda.synchronize()
+                        tr.alloc_state["fail"] = True
+                    elif fail[1] == 2:
+                        s.sort(local[:1000])
+                        torch.cuda.synchronize()
+                    s.sort(local)
                 text = "NO ERROR"
             except clo.CloError as e:
                 text = e.message
-            del os.environ["CLO_SHARD_TEST_FAIL"]
+            tr.alloc_state["fail"] = False
             torch.cuda.synchronize()
         for _ in range(2):                                          # the second call reuses every buffer
             out, m = s.sort(local)

@@ -137,34 +137,36 @@ def test_ranks_fail_together(tmp_path, world, stage, bad_rank):
 
 
 def test_slice_plan_matches_a_numpy_model():
-    """clo_shard_plan_slice (pure host logic of the C driver): slice j of every rank's bucket
-    travels as one all-to-all; what rank r sends to p in slice j is what p expects from r, the
-    pieces tile the partitioned shard and the result without gaps, sub-buckets in key order."""
+    """clo_shard_plan_slice (pure host logic of the C driver): a rank's bucket comes as `subs` sub-buckets, slice j =
+    `subs / slices` consecutive ones of every rank, travelling as one all-to-all; what rank r sends to p in slice j is
+    what p expects from r, the pieces tile the partitioned shard and the receive buffer without gaps."""
     import ctypes as C
     from cl_ops_amd.api import lib
     rng = np.random.default_rng(3)
-    for world, slices in ((2, 4), (8, 8), (4, 2), (8, 1)):
-        row = world * slices + 2
+    for world, subs, slices in ((2, 128, 4), (8, 32, 8), (4, 64, 2), (8, 32, 1), (1, 256, 4), (2, 4, 4)):
+        row = world * subs + 5
         m = rng.integers(0, 1000, (world, row)).astype(np.uint64)
-        m[:, 3 % (world * slices)] = 0
+        m[:, 3 % (world * subs)] = 0
         flat = np.ascontiguousarray(m.reshape(-1))
         arr = lambda: (C.c_size_t * world)()      # noqa: E731
+        group = subs // slices
         plans = {}
         for r in range(world):
             for j in range(slices):
                 sc, so, rc, ro = arr(), arr(), arr(), arr()
                 at, tot = C.c_size_t(0), C.c_size_t(0)
-                total = lib.clo_shard_plan_slice(flat.ctypes.data_as(C.POINTER(C.c_uint64)), row, world, slices, r, j,
+                total = lib.clo_shard_plan_slice(flat.ctypes.data_as(C.POINTER(C.c_uint64)), row, world, subs, slices, r, j,
                                                  sc, so, rc, ro, C.byref(at), C.byref(tot))
                 plans[r, j] = (list(sc), list(so), list(rc), list(ro), at.value, tot.value, total)
         for r in range(world):
-            mine = m[r, :world * slices].reshape(world, slices)
-            starts = np.concatenate(([0], np.cumsum(mine.reshape(-1))[:-1])).reshape(world, slices)
+            mine = m[r, :world * subs].reshape(world, subs)
+            starts = np.concatenate(([0], np.cumsum(mine.reshape(-1))[:-1])).reshape(world, subs)
             covered = 0
             for j in range(slices):
                 sc, so, rc, ro, at, tot, total = plans[r, j]
-                assert sc == list(mine[:, j]) and so == list(starts[:, j])
-                assert total == int(m[:, r * slices:(r + 1) * slices].sum())
+                assert sc == [int(mine[p, j * group:(j + 1) * group].sum()) for p in range(world)]
+                assert so == list(starts[:, j * group])
+                assert total == int(m[:, r * subs:(r + 1) * subs].sum())
                 assert at == covered and tot == sum(rc)
                 assert ro == [at + int(sum(rc[:p])) for p in range(world)]
                 covered += tot
