@@ -92,7 +92,7 @@ _sig("clo_hip_bitonic_simple", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci)
 _sig("clo_hip_bitonic_tiled", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_bitonic_any", ci, vp, sz, ci, ci, ci, ci, ci, ci, C.POINTER(ci), vp)
 _sig("clo_hip_kernel_lds_bytes", sz, C.c_char_p, ci, ci)
-_sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
+_sig("clo_hip_bitonic_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
 _sig("clo_hip_bitonic_jit_destroy", None, vp)
 _sig("clo_hip_bitonic_jit_sort", ci, vp, vp, sz, ci, C.POINTER(ci), vp)
 _sig("clo_hip_bitonic_jit_gselect", ci, vp, vp, vp, sz, vp)
@@ -104,7 +104,7 @@ _sig("clo_hip_rccl_comm_abort", ci, vp)
 _sig("clo_hip_rccl_all_gather_u64", ci, vp, vp, vp, sz, vp)
 _sig("clo_hip_rccl_all_to_all_v", ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp)
 _sig("clo_hip_set_launch_observer", ci, vp, vp)
-_sig("clo_hip_radix_jit_create", ci, ci, ci, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
+_sig("clo_hip_radix_jit_create", ci, ci, ci, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_char_p))
 _sig("clo_hip_radix_jit_destroy", None, vp)
 _sig("clo_hip_radix_jit_sort", ci, vp, vp, vp, vp, vp, sz, ci, vp, sz, vp)
 _sig("clo_hip_timing_enable", ci, ci)

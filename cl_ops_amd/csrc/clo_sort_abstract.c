@@ -224,6 +224,31 @@ const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name) {
 	return NULL;
 }
 
+/* Does `text` use, as an identifier, a name that `compiler_opts` defines or undefines (-DNAME[=value], -D NAME, -UNAME)?
+ * Then the expression means what the COMPILER makes of it, not what the parser of the fixed family reads: it is
+ * pasted into the kernel source and built with those options, as upstream builds everything
+ * (sort/clo_sort_abstract.c:144-179). */
+static int is_ident_char(int c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; }
+static int opts_name_used(const char* compiler_opts, const char* text) {
+	if (!compiler_opts || !text) return 0;
+	const char* p = compiler_opts;
+	while (*p) {
+		while (*p == ' ' || *p == '\t' || *p == '\n') ++p;
+		if (p[0] == '-' && (p[1] == 'D' || p[1] == 'U')) {
+			p += 2;
+			while (*p == ' ' || *p == '\t') ++p;   /* "-D NAME" */
+			const char* name = p;
+			while (is_ident_char((unsigned char) *p)) ++p;
+			const size_t n = (size_t) (p - name);
+			for (const char* t = text; n > 0 && *t; ++t) {
+				if (strncmp(t, name, n) == 0 && !is_ident_char((unsigned char) t[n]) && (t == text || !is_ident_char((unsigned char) t[-1]))) return 1;
+			}
+		}
+		while (*p && *p != ' ' && *p != '\t' && *p != '\n') ++p;
+	}
+	return 0;
+}
+
 CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
 	const char* compiler_opts, GError** err) {
@@ -262,8 +287,9 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 			goto error_handler;
 		}
 		const int key_ok = parse_get_key(get_key, ks->elem_size, ks->key_size, &ks->key_shift, &ks->key_bits)
-			&& !(ks->key_kind == 2 && ks->key_bits != 8 * ks->key_size);   /* a float key is the whole key type */
-		int cmp_ok = parse_compare(compare, &ks->descending);
+			&& !(ks->key_kind == 2 && ks->key_bits != 8 * ks->key_size)   /* a float key is the whole key type */
+			&& !opts_name_used(compiler_opts, get_key);
+		int cmp_ok = parse_compare(compare, &ks->descending) && !opts_name_used(compiler_opts, compare);
 		const int is_satradix = strcmp(type, "satradix") == 0;
 		if (is_satradix && !cmp_ok) {
 			/* upstream's radix kernels never expand CLO_SORT_COMPARE (always ascending):
@@ -277,17 +303,18 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 			char* log = NULL;
 			int st;
 			if (is_satradix) {
-				st = clo_hip_radix_jit_create((int) sorter->elem_type, (int) sorter->key_type, get_key, &sorter->jit, &log);
+				st = clo_hip_radix_jit_create((int) sorter->elem_type, (int) sorter->key_type, get_key, compiler_opts, &sorter->jit, &log);
 				sorter->jit_is_radix = 1;
 			} else {
-				st = clo_hip_bitonic_jit_create((int) sorter->elem_type, (int) sorter->key_type, compare, get_key,
+				st = clo_hip_bitonic_jit_create((int) sorter->elem_type, (int) sorter->key_type, compare, get_key, compiler_opts,
 					&sorter->jit, &log);
 			}
 			if (st != 0) {
 				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS,
-					"Could not build kernels for compare '%s' / get_key '%s': %s%s%.300s",
-					compare ? compare : "((a) > (b))", get_key ? get_key : "(x)", clo_hip_error_string(st),
-					log ? "\n" : "", log ? log : "");
+					"Could not build kernels for compare '%s' / get_key '%s'%s%s%s: %s%s%.600s",
+					compare ? compare : "((a) > (b))", get_key ? get_key : "(x)",
+					compiler_opts ? " with options '" : "", compiler_opts ? compiler_opts : "", compiler_opts ? "'" : "",
+					clo_hip_error_string(st), log ? "\n" : "", log ? log : "");
 				free(log);
 				goto error_handler;
 			}

@@ -22,6 +22,7 @@
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
+#include "clo_hip_jit_opts.h"
 
 namespace {
 
@@ -220,7 +221,7 @@ int launch(hipFunction_t f, unsigned blocks, hipStream_t s, void** args) {
 
 extern "C" {
 
-int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare, const char* get_key,
+int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare, const char* get_key, const char* compiler_opts,
 	void** handle, char** log) {
 	if (log) *log = nullptr;
 	if (!handle) return CLO_HIP_EARGS;
@@ -244,8 +245,10 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 		set_log(log, "hiprtcCreateProgram failed");
 		return CLO_HIP_EUNSUPPORTED;
 	}
-	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17" };
-	const hiprtcResult cr = hiprtcCompileProgram(prog, 3, opts);
+	const std::vector<std::string> optv = clo_jit_options(compiler_opts);
+	std::vector<const char*> opts;
+	for (const std::string& o : optv) opts.push_back(o.c_str());
+	const hiprtcResult cr = hiprtcCompileProgram(prog, (int) opts.size(), opts.data());
 	if (cr != HIPRTC_SUCCESS) {
 		size_t n = 0;
 		hiprtcGetProgramLogSize(prog, &n);

@@ -25,6 +25,7 @@
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
+#include "clo_hip_jit_opts.h"
 
 namespace {
 
@@ -112,7 +113,7 @@ void set_log(char** log, const std::string& text) {
 
 extern "C" {
 
-int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, void** handle, char** log) {
+int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, const char* compiler_opts, void** handle, char** log) {
 	if (log) *log = nullptr;
 	if (!handle) return CLO_HIP_EARGS;
 	*handle = nullptr;
@@ -135,8 +136,10 @@ int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, v
 		set_log(log, "hiprtcCreateProgram failed");
 		return CLO_HIP_EUNSUPPORTED;
 	}
-	const char* opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17" };
-	if (hiprtcCompileProgram(prog, 3, opts) != HIPRTC_SUCCESS) {
+	const std::vector<std::string> optv = clo_jit_options(compiler_opts);
+	std::vector<const char*> opts;
+	for (const std::string& o : optv) opts.push_back(o.c_str());
+	if (hiprtcCompileProgram(prog, (int) opts.size(), opts.data()) != HIPRTC_SUCCESS) {
 		size_t n = 0;
 		hiprtcGetProgramLogSize(prog, &n);
 		std::string text(n ? n : 1, '\0');

@@ -281,10 +281,15 @@ int clo_hip_gselect(const void* src, void* dst, size_t numel, int elem_size,
  *      get_key expressions — what upstream does for every sorter by OpenCL JIT
  *      (sort/clo_sort_abstract.c:144-179). elem_type / key_type: CloType numbers.
  *      compare: body of CLO_SORT_COMPARE(a, b) (NULL: "((a) > (b))"); get_key:
- *      body of CLO_SORT_KEY_GET(x) (NULL: "(x)"). On a compile error returns
- *      CLO_HIP_EARGS and, if log != NULL, a malloc'd build log (caller frees). ----
+ *      body of CLO_SORT_KEY_GET(x) (NULL: "(x)"). compiler_opts (may be NULL): the
+ *      caller's options for the compiler, white-space separated, as upstream hands
+ *      them to the OpenCL JIT (sort/clo_sort_abstract.c:177-178) — -DNAME[=value] /
+ *      -UNAME / -Idir reach hiprtc (also spelled "-D NAME"), OpenCL's own -cl-...
+ *      switches are dropped, anything else is the compiler's to accept or refuse. On a
+ *      compile error returns CLO_HIP_EARGS and, if log != NULL, a malloc'd build log
+ *      (caller frees). ----
  */
-int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare, const char* get_key,
+int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare, const char* get_key, const char* compiler_opts,
 	void** handle, char** log);
 void clo_hip_bitonic_jit_destroy(void* handle);
 /* In place, numel a power of two. tiled: 0 = sbitonic schedule, 1 = abitonic. */
@@ -300,7 +305,7 @@ int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, 
  *      (low half of the key, then the high half in the first round's order).
  *      pairs / pairs_tmp: numel * 8 bytes each; workspace as for
  *      clo_hip_radix_workspace_bytes(numel, 8, 32, digit_bits). ---- */
-int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, void** handle, char** log);
+int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, const char* compiler_opts, void** handle, char** log);
 void clo_hip_radix_jit_destroy(void* handle);
 int clo_hip_radix_jit_sort(void* handle, const void* src, void* dst, void* pairs, void* pairs_tmp, size_t numel,
 	int digit_bits, void* workspace, size_t workspace_bytes, void* stream);

@@ -12,13 +12,22 @@
  *    are parsed into a fixed family: get_key = x, (x) >> N, ((x) >> N) & MASK,
  *    optional casts; compare = ((a) > (b)) or ((a) < (b)) select ahead-of-time
  *    kernels. Any other expression is compiled at run time with hiprtc (as
- *    upstream does with the OpenCL JIT): into the bitonic kernels themselves,
- *    or, for satradix, into a kernel that materialises the keys (key types of
- *    up to 4 bytes). gselect answers CLO_ERROR_ARGS.
+ *    upstream does with the OpenCL JIT): into the bitonic and gselect kernels
+ *    themselves, or, for satradix, into a kernel that materialises the keys
+ *    (any key type; 8-byte keys take two rounds).
  *  - data_out != NULL works (upstream sorts data_in regardless,
  *    clo_sort_satradix.c:276,305 / clo_sort_abitonic.c:388) and leaves data_in
  *    untouched; numel need not be a power of two.
- *  - `compiler_opts` is accepted and ignored (kernels are built ahead of time).
+ *  - `compiler_opts` reaches the run-time compiler whenever kernels are compiled at
+ *    run time, as upstream hands it to the OpenCL JIT (clo_sort_abstract.c:177-178):
+ *    -DNAME[=value], -UNAME, -Idir (OpenCL's -cl-... switches are dropped, anything
+ *    else is the compiler's to refuse). An expression that uses a name the options
+ *    define is always compiled, never parsed: compiler_opts = "-DSHIFT=12" with
+ *    get_key = "((x) >> SHIFT) & 0xfff" works as upstream. Sorters built from the
+ *    ahead-of-time kernels have nothing to compile and ignore the options.
+ *  - `lws_max` is accepted and ignored: a tile is a work-group's registers and LDS,
+ *    fixed at compile time (upstream caps the work-group size it asks for,
+ *    clo_sort_satradix.c:184-190); results never depend on it.
  */
 #ifndef CLO_SORT_H
 #define CLO_SORT_H

@@ -143,3 +143,60 @@ def test_msd_partition_on_seven_and_eight_bits(gpu, dt, bits):
     top = a >> dt(8 * es - bits)
     assert np.array_equal(dst.cpu().numpy().view(dt), a[np.argsort(top, kind="stable")])
     assert np.array_equal(counts.cpu().numpy(), np.bincount(top.astype(np.int64), minlength=1 << bits))
+
+
+# ----------------------------------------------------------------------------
+# compiler_opts reach the run-time compiler (sort/clo_sort_abstract.c:173-179)
+# ----------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def cq(gpu):
+    import cl_ops_amd as clo
+    ctx = clo.Context(0)
+    q = clo.Queue(ctx)
+    yield ctx, q
+    q.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("alg", ["sbitonic", "abitonic", "gselect", "satradix"])
+@pytest.mark.parametrize("opts", ["-DSHIFT=12", "-cl-fast-relaxed-math -D SHIFT=12 -DUNUSED"])
+def test_compiler_opts_define_a_macro_used_in_get_key(cq, alg, opts):
+    """Upstream hands compiler_opts to the OpenCL JIT with the kernel source, so a caller may define SHIFT there and
+    use it inside get_key; here the options reach hiprtc for all four sorters."""
+    import cl_ops_amd as clo
+    ctx, q = cq
+    n = 3000 if alg == "gselect" else (1 << 15) + (0 if alg != "satradix" else 77)
+    a = np.random.default_rng(12).integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    s = clo.Sorter(alg, ctx, "uint", get_key="((x) >> SHIFT) & 0xfff", compiler_opts=opts)
+    got = s.with_host_data(a, q)
+    s.close()
+    key = (a >> np.uint32(12)) & np.uint32(0xfff)
+    if alg in ("gselect", "satradix"):            # stable sorters: the result is unique
+        assert np.array_equal(got, a[np.argsort(key, kind="stable")])
+    else:                                          # bitonic networks: sorted by the key, the same multiset
+        gk = (got >> np.uint32(12)) & np.uint32(0xfff)
+        assert np.all(gk[:-1] <= gk[1:]) and np.array_equal(np.sort(got), np.sort(a))
+
+
+def test_compiler_opts_also_change_a_parseable_expression(cq):
+    """`(x) >> S` would be refused by the parser (S is not a number) — but `(x) & MASK`-style names that the options
+    define must never be PARSED as something else either: the define decides."""
+    import cl_ops_amd as clo
+    ctx, q = cq
+    a = np.random.default_rng(13).integers(0, 1 << 32, 1 << 16, dtype=np.uint64).astype(np.uint32)
+    s = clo.Sorter("satradix", ctx, "uint", get_key="(x) >> S", compiler_opts="-DS=20")
+    got = s.with_host_data(a, q)
+    s.close()
+    assert np.array_equal(got, a[np.argsort(a >> np.uint32(20), kind="stable")])
+
+
+@pytest.mark.parametrize("alg", ["abitonic", "satradix"])
+@pytest.mark.parametrize("opts,needle", [("-DSHIFT=(", "error"), ("-fno-such-flag-at-all -DSHIFT=3", "no-such-flag")])
+def test_bad_compiler_opts_give_a_gerror_with_the_build_log(cq, alg, opts, needle):
+    import cl_ops_amd as clo
+    ctx, q = cq
+    with pytest.raises(clo.CloError) as e:
+        clo.Sorter(alg, ctx, "uint", get_key="((x) >> SHIFT) & 0xfff", compiler_opts=opts)
+    assert e.value.code == 2                                   # CLO_ERROR_ARGS (clo_common.in.h:80-95)
+    assert "Could not build kernels" in e.value.message and needle in e.value.message.lower(), e.value.message
