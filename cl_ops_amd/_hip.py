@@ -61,6 +61,7 @@ _sig("clo_hip_event_destroy", ci, vp)
 _sig("clo_hip_event_record", ci, vp, vp)
 _sig("clo_hip_event_synchronize", ci, vp)
 _sig("clo_hip_event_query", ci, vp)
+_sig("clo_hip_env_refresh", None)
 _sig("clo_hip_event_elapsed_ms", ci, vp, vp, C.POINTER(C.c_float))
 _sig("clo_hip_stream_wait_event", ci, vp, vp)
 _sig("clo_hip_error_string", C.c_char_p, ci)
@@ -82,7 +83,7 @@ _sig("clo_hip_radix_sort", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, sz, vp)
 _sig("clo_hip_radix_takes_first_digits", ci, sz, ci, ci, ci)
 _sig("clo_hip_radix_sort_fed", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, vp, sz, vp)
 _sig("clo_hip_radix_seg_workspace_bytes", sz, sz, ci, ci, ci)
-_sig("clo_hip_radix_sort_segmented", ci, vp, vp, sz, C.POINTER(sz), ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(ci), ci,
+_sig("clo_hip_radix_sort_segmented", ci, vp, vp, vp, sz, C.POINTER(sz), ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(ci), ci,
      ci, ci, ci, ci, vp, sz, vp, C.POINTER(ci))
 _sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)
 _sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, vp, sz, vp)

@@ -12,6 +12,14 @@ int clo_debug_enabled(void) {
 	return cached;
 }
 
+/* The host drivers' environment switches, each read in one place and only when an object is made
+ * (INTEGRATION.md has the table): */
+int clo_env_no_warmup(void) { return getenv("CLO_NO_WARMUP") != NULL; }
+int clo_env_flag(const char* name) {   /* -1 unset, else 0 / 1 */
+	const char* x = getenv(name);
+	return x ? (atoi(x) != 0) : -1;
+}
+
 int clo_devbuf_reserve(clo_devbuf* b, size_t bytes) {
 	if (b->ptr && b->bytes >= bytes) return 0;
 	if (b->ptr) {

@@ -28,6 +28,13 @@
 int clo_debug_enabled(void);
 #define clo_debug(...) do { if (clo_debug_enabled()) { fprintf(stderr, "cl_ops-DEBUG: " __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
+/* Environment switches of the host drivers: read when an object is made, never per call. CLO_NO_WARMUP (no
+ * dummy sorts / scans at the first object of a kind), and the 0 / 1 switches CLO_SORT_HOST_PIPELINE (satradix's
+ * clo_sort_with_host_data: pipelined or blocking whatever the queue) and CLO_SBITONIC_STEPS (sbitonic with one
+ * launch per step). */
+int clo_env_no_warmup(void);
+int clo_env_flag(const char* name);
+
 /* A grow-only device allocation cached inside a sorter/scanner object, so the
  * hot path never calls hipMalloc after the first use (upstream allocates and
  * frees its aux buffers on every call: clo_sort_satradix.c:242-257,327-330). */

@@ -51,7 +51,7 @@ static void scan_pipe_res_free(scan_pipe_res* r);
  * the first timed scan (see sort_warmup in clo_sort_abstract.c). Best effort. */
 static void scan_warmup(CloScan* scanner) {
 	static int done;
-	if (done || getenv("CLO_NO_WARMUP")) return;
+	if (done || clo_env_no_warmup()) return;
 	done = 1;
 	const size_t n = 20000;
 	void* in = calloc(n, clo_type_sizeof(scanner->elem_type));
@@ -74,6 +74,7 @@ CloScan* clo_scan_new(const char* type, const char* options, CCLContext* ctx,
 	const CloScanImplDef* impls[] = { &clo_scan_blelloch_def, NULL };
 	CloScan* scanner = NULL;
 	GError* err_internal = NULL;
+	clo_hip_env_refresh();   /* the environment switches are read when an object is made, never per call */
 
 	for (unsigned i = 0; impls[i] != NULL; ++i) {
 		if (strcmp(type, impls[i]->name) != 0) continue;
@@ -170,8 +171,6 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
  * 6.2 ms with chunks of 2^22 or 2^23, 6.7 with 2^24; 2^28: 23.2-23.8 ms with 2^22
  * .. 2^24) is flat in the chunk size. */
 static size_t scan_pipe_chunk(size_t numel) {
-	const char* x = getenv("CLO_SCAN_PIPE_CHUNK_LOG2");   /* (A/B measurements only) */
-	if (x && atoi(x) >= 16 && atoi(x) <= 28) return (size_t) 1 << atoi(x);
 	(void) numel;
 	return CLO_SCAN_PIPE_CHUNK_MAX;   /* (a multiple of 16-KiB blocks: every chunk starts 16-byte aligned) */
 }
@@ -354,8 +353,7 @@ cl_bool clo_scan_with_host_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueue* c
 	}
 	if (cq_comm == NULL) cq_comm = cq_exec;
 
-	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && !clo_hip_scan_is_typed((int) scanner->elem_type, (int) scanner->sum_type) && numel >= CLO_SCAN_PIPE_MIN_NUMEL && ccl_queue_get_stream(cq_exec) != NULL
-		&& getenv("CLO_SCAN_NO_PIPELINE") == NULL) {   /* (the variable: A/B measurements only) */
+	if (scanner->ext != NULL && scanner->ext->scan_chunk != NULL && !clo_hip_scan_is_typed((int) scanner->elem_type, (int) scanner->sum_type) && numel >= CLO_SCAN_PIPE_MIN_NUMEL && ccl_queue_get_stream(cq_exec) != NULL) {
 		status = scan_with_host_data_pipelined(scanner, cq_exec, cq_comm, data_in, data_out, numel, &err_internal);
 		if (err_internal) goto error_handler;
 		goto finish;

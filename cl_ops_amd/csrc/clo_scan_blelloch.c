@@ -37,6 +37,12 @@ static int blelloch_workspace(CloScan* scanner, CCLQueue* cq_exec, size_t numel,
 	const int ss = (int) clo_scan_get_sum_size(scanner);
 	if (clo_hip_failed(clo_stream_guard_enter(&data->guard, cq_exec), err, "hipStreamWaitEvent")) return 0;
 	const size_t ws = clo_hip_scan_workspace_bytes(numel, es, ss);
+	if (data->workspace.ptr && data->workspace.bytes < ws) {
+		/* about to grow: the old range is freed, and the registry of prepared workspaces (clo_hip_scan_workspace_init)
+		 * must not go on vouching for whatever is allocated at that address next */
+		clo_hip_scan_workspace_forget(data->workspace.ptr);
+		data->ws_ready = NULL;
+	}
 	if (clo_hip_failed(clo_devbuf_reserve(&data->workspace, ws), err, "hipMalloc(scan workspace)")) return 0;
 	const int tripped = clo_status_cell_take_tripped(data->status);
 	if (data->ws_ready != data->workspace.ptr || data->ws_ready_bytes != data->workspace.bytes || tripped) {

@@ -195,7 +195,7 @@ static int parse_compare(const char* text, int* descending) {
 static void sort_warmup(CloSort* sorter, const char* type, size_t elem_size) {
 	static unsigned char done[4][4];
 	static const char* const kinds[4] = { "satradix", "abitonic", "sbitonic", "gselect" };
-	if (getenv("CLO_NO_WARMUP") || sorter->jit) return;
+	if (clo_env_no_warmup() || sorter->jit) return;
 	int k = -1, e = elem_size == 1 ? 0 : (elem_size == 2 ? 1 : (elem_size == 4 ? 2 : 3));
 	for (int i = 0; i < 4; ++i) if (strcmp(type, kinds[i]) == 0) k = i;
 	if (k < 0 || done[k][e]) return;
@@ -264,6 +264,7 @@ CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 
 	CloSort* sorter = NULL;
 	GError* err_internal = NULL;
+	clo_hip_env_refresh();   /* the environment switches are read when an object is made, never per call */
 
 	for (unsigned i = 0; impls[i] != NULL; ++i) {
 		if (type == NULL || strcmp(type, impls[i]->name) != 0) continue;

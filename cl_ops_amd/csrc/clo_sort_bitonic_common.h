@@ -13,6 +13,7 @@ typedef struct {
 	 * replayed from then on (sbitonic: 136 launches for 2^16 elements). */
 	clo_graph_cache graph;
 	int launches;
+	int steps;   /* sbitonic: CLO_SBITONIC_STEPS=1 when the sorter was made (one launch per step instead of the tiled schedule) */
 } clo_bitonic_state;
 
 void clo_bitonic_state_release(clo_bitonic_state* state);

@@ -39,6 +39,7 @@ typedef struct {
 	clo_devbuf workspace; /* per-tile histograms, offsets, chunk sums */
 	clo_devbuf pairs;     /* (ordered key, index) pairs of a run-time compiled get_key */
 	clo_devbuf seg_ws;    /* workspace of the segmented sorts (sort_segments: the sharded sort's local step) */
+	int host_pipeline;    /* CLO_SORT_HOST_PIPELINE as read when the sorter was made: -1 unset, 0, 1 */
 	clo_status_cell* status;  /* the workspace's status word, for the sorts whose kernels poll (clo_hip_radix_polls) */
 	void* ws_ready;           /* the allocation whose header (status word) has been cleared */
 	size_t ws_ready_bytes;
@@ -239,6 +240,13 @@ static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GEr
 #define SAT_PIPE_CHUNKS 8
 #define SAT_PIPE_BITS 4
 #define SAT_PIPE_BUCKETS (1 << SAT_PIPE_BITS)
+/* Round 4: where the sorter runs segmented sorts (radix 16 / 256) the split takes 8 key bits instead of 4 — 256
+ * sub-buckets, 16 to a bucket — and a bucket is ONE segmented sort of its 16 sub-buckets on the remaining bits
+ * (clo_hip_radix_sort_segmented), whose first pass gathers the sub-buckets' pieces out of the split chunks by itself:
+ * split + 3 passes for 32-bit keys, where the 4-bit split needed a gather copy and 4 passes per bucket (6 trips). */
+#define SAT_PIPE_SEG_BITS 8
+#define SAT_PIPE_SUBS (1 << SAT_PIPE_SEG_BITS)
+#define SAT_PIPE_KEEP_BYTES ((size_t) 512 << 20)   /* the two array-sized buffers stay cached in the sorter up to this size each */
 
 typedef struct sat_pipe_res_s {
 	clo_devbuf in, part, counts, msd_ws;   /* the array as it arrives / split chunk by chunk; bucket sizes; workspace of the splits */
@@ -258,6 +266,9 @@ typedef struct {
 	pthread_cond_t cv;
 	int posted, completed, abort, status;
 } sat_pipe;
+
+static int satradix_segments_apply(CloSort* sorter);
+static cl_bool clo_sort_satradix_reserve_segments(CloSort* sorter, CCLQueue* cq_exec, size_t numel, int nseg, int* handled, GError** err);
 
 static void sat_pipe_res_free(sat_pipe_res* r) {
 	if (!r) return;
@@ -301,11 +312,14 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 	const int es = ks->elem_size;
 	const int key_kind = (ks->key_kind == 1 && ks->key_bits < 8 * ks->key_size) ? 0 : ks->key_kind;
 	*handled = 0;
-	if (clo_sort_get_jit(sorter) != NULL || key_kind != 0 || (es != 4 && es != 8) || ks->key_bits <= SAT_PIPE_BITS) return CL_FALSE;
+	const int seg = satradix_segments_apply(sorter) && ks->key_bits > SAT_PIPE_SEG_BITS;
+	const int part_bits = seg ? SAT_PIPE_SEG_BITS : SAT_PIPE_BITS;
+	const int subs = 1 << part_bits, per = subs / SAT_PIPE_BUCKETS;   /* sub-buckets of the split; per bucket */
+	if (clo_sort_get_jit(sorter) != NULL || key_kind != 0 || (es != 4 && es != 8) || ks->key_bits <= part_bits) return CL_FALSE;
 	if (numel < SAT_PIPE_MIN_NUMEL || numel > 0xffffffffull) return CL_FALSE;
 	{   /* default: on, unless the caller profiles the exec queue (see above); CLO_SORT_HOST_PIPELINE=0 / 1 decides for both */
-		const char* x = getenv("CLO_SORT_HOST_PIPELINE");
-		const int want = x ? atoi(x) != 0 : !ccl_queue_is_profiling(cq_exec);
+		const int flag = ((clo_sort_satradix_data*) clo_sort_get_data(sorter))->host_pipeline;
+		const int want = flag >= 0 ? flag : !ccl_queue_is_profiling(cq_exec);
 		if (!want) return CL_FALSE;
 	}
 	*handled = 1;
@@ -315,7 +329,7 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 	size_t chunk = (numel + SAT_PIPE_CHUNKS - 1) / SAT_PIPE_CHUNKS;
 	chunk = (chunk + 4095) & ~(size_t) 4095;   /* every chunk starts 16-byte aligned */
 	const int nchunks = (int) ((numel + chunk - 1) / chunk);
-	uint64_t counts[SAT_PIPE_CHUNKS][SAT_PIPE_BUCKETS];
+	uint64_t counts[SAT_PIPE_CHUNKS][SAT_PIPE_SUBS];   /* [chunk][sub-bucket]: `subs` entries of a row are used */
 	sat_pipe p;
 	pthread_t helper;
 	int helper_started = 0, st = 0;
@@ -343,7 +357,7 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 	if (st == 0) st = clo_devbuf_reserve(&r->counts, sizeof(counts));
 	if (st == 0) {   /* (not monotone in the size — the tile shape changes with it: the last chunk may need more than a full one) */
 		const size_t last = numel - (size_t) (nchunks - 1) * chunk;
-		const size_t w_full = clo_hip_msd_workspace_bytes(chunk, es, SAT_PIPE_BITS), w_last = clo_hip_msd_workspace_bytes(last, es, SAT_PIPE_BITS);
+		const size_t w_full = clo_hip_msd_workspace_bytes(chunk, es, part_bits), w_last = clo_hip_msd_workspace_bytes(last, es, part_bits);
 		st = clo_devbuf_reserve(&r->msd_ws, w_full > w_last ? w_full : w_last);
 	}
 	if (st != 0) goto finish;
@@ -364,19 +378,20 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 		if (!evt) goto finish;
 		what = "clo_hip_msd_partition";
 		st = clo_hip_msd_partition((char*) r->in.ptr + off * es, (char*) r->part.ptr + off * es, cnt, es, ks->key_shift, ks->key_bits,
-			SAT_PIPE_BITS, (uint64_t*) r->counts.ptr + (size_t) c * SAT_PIPE_BUCKETS, r->msd_ws.ptr, r->msd_ws.bytes, s_exec);
+			part_bits, (uint64_t*) r->counts.ptr + (size_t) c * SAT_PIPE_SUBS, r->msd_ws.ptr, r->msd_ws.bytes, s_exec);
 		if (st != 0) { ccl_queue_abort_command(cq_exec, evt); goto finish; }
 		if (!ccl_queue_end_command(cq_exec, evt, err)) { ccl_queue_abort_command(cq_exec, evt); goto finish; }
 	}
 	/* ---- the bucket sizes (the one synchronisation of the call) ---- */
 	what = "bucket sizes";
-	st = clo_hip_memcpy_d2h_async(counts, r->counts.ptr, (size_t) nchunks * SAT_PIPE_BUCKETS * sizeof(uint64_t), s_exec);
+	st = clo_hip_memcpy_d2h_async(counts, r->counts.ptr, (size_t) nchunks * SAT_PIPE_SUBS * sizeof(uint64_t), s_exec);
 	if (st == 0) st = clo_hip_stream_synchronize(s_exec);
 	if (st != 0) goto finish;
 	size_t largest = 0, sum = 0;
 	for (int b = 0; b < SAT_PIPE_BUCKETS; ++b) {
 		size_t tot = 0;
-		for (int c = 0; c < nchunks; ++c) tot += (size_t) counts[c][b];
+		for (int c = 0; c < nchunks; ++c)
+			for (int k = b * per; k < (b + 1) * per; ++k) tot += (size_t) counts[c][k];
 		p.off[b] = sum;
 		sum += tot;
 		if (tot > largest) largest = tot;
@@ -386,17 +401,26 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "bucket sizes (%zu) do not add up to numel (%zu)", sum, numel);
 		goto finish;
 	}
-	{   /* the workspace a sort needs is not monotone in its size (the single-sweep passes of mid-sized buckets keep more state): the largest any bucket asks for */
+	int polls = 0;
+	if (!seg) {   /* the workspace a sort needs is not monotone in its size (the single-sweep passes of mid-sized buckets keep more state): the largest any bucket asks for */
 		size_t ws_max = 0;
 		for (int b = 0; b < SAT_PIPE_BUCKETS; ++b) {
 			const size_t tot = p.off[b + 1] - p.off[b];
 			const size_t w = tot ? clo_hip_radix_workspace_bytes(tot, es, ks->key_bits - SAT_PIPE_BITS, bits_in_digit) : 0;
 			if (w > ws_max) ws_max = w;
+			if (tot && clo_hip_radix_polls(tot, es, bits_in_digit)) polls = 1;
 		}
 		what = "hipMalloc(satradix workspace)";
 		if ((st = clo_devbuf_reserve(&data->workspace, ws_max)) != 0) goto finish;
 	}
 	if (largest > 0 && !satradix_reserve(sorter, cq_exec, largest, err)) goto finish;
+	/* (satradix_reserve arms the give-up watch when the LARGEST bucket's sort polls; the mid-sized ones are the
+	 * ones that take the polling passes: a caller's ccl_queue_finish must report their give-up too) */
+	if (polls) ccl_queue_watch_status(cq_exec, data->status);
+	if (seg && largest > 0) {
+		int h = 0;
+		if (!clo_sort_satradix_reserve_segments(sorter, cq_exec, largest, per, &h, err)) goto finish;
+	}
 	if (pthread_create(&helper, NULL, sat_pipe_copy_out, &p) != 0) { st = CLO_HIP_EARGS; what = "pthread_create"; goto finish; }
 	helper_started = 1;
 
@@ -406,15 +430,40 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 		evt = ccl_queue_begin_command(cq_exec, CLO_SORT_SATRADIX_KNAME_SCATTER, err);
 		if (!evt) goto finish;
 		size_t pos = p.off[b];
-		what = "hipMemcpyAsync(d2d)";
-		for (int c = 0; c < nchunks && st == 0; ++c) {
+		if (seg && tot > 0) {
+			/* the bucket's `per` sub-buckets = segments, each in one piece per chunk (in chunk order: stable); the first
+			 * pass gathers them. The passes go part -> X0 -> X1 ..., X alternating between the bucket's place in the
+			 * result and the scratch buffer such that the LAST one writes the result. */
+			size_t seg_counts[SAT_PIPE_SUBS / SAT_PIPE_BUCKETS], pn[SAT_PIPE_CHUNKS * SAT_PIPE_SUBS / SAT_PIPE_BUCKETS], po[SAT_PIPE_CHUNKS * SAT_PIPE_SUBS / SAT_PIPE_BUCKETS];
+			int ps[SAT_PIPE_CHUNKS * SAT_PIPE_SUBS / SAT_PIPE_BUCKETS], np = 0, in_b = 0;
+			for (int kk = 0; kk < per; ++kk) {
+				const int sub = b * per + kk;
+				seg_counts[kk] = 0;
+				for (int c = 0; c < nchunks; ++c) {
+					size_t before = 0;
+					for (int k = 0; k < sub; ++k) before += (size_t) counts[c][k];
+					pn[np] = (size_t) counts[c][sub];
+					po[np] = (size_t) c * chunk + before;
+					ps[np] = kk;
+					seg_counts[kk] += pn[np];
+					++np;
+				}
+			}
+			const int rest = ks->key_bits - SAT_PIPE_SEG_BITS, passes = (rest + 7) / 8;
+			void* final = (char*) r->in.ptr + p.off[b] * es;
+			what = "clo_hip_radix_sort_segmented";
+			st = clo_hip_radix_sort_segmented(r->part.ptr, passes % 2 ? data->tmp.ptr : final, passes % 2 ? final : data->tmp.ptr, tot, seg_counts, per,
+				pn, po, ps, np, es, ks->key_shift, rest, bits_in_digit, data->seg_ws.ptr, data->seg_ws.bytes, s_exec, &in_b);
+		}
+		what = seg ? what : "hipMemcpyAsync(d2d)";
+		for (int c = 0; c < nchunks && st == 0 && !seg; ++c) {
 			size_t before = 0;
 			for (int k = 0; k < b; ++k) before += (size_t) counts[c][k];
 			const size_t cnt = (size_t) counts[c][b];
 			if (cnt) st = clo_hip_memcpy_d2d_async((char*) r->in.ptr + pos * es, (const char*) r->part.ptr + ((size_t) c * chunk + before) * es, cnt * es, s_exec);
 			pos += cnt;
 		}
-		if (st == 0 && tot > 0) {
+		if (st == 0 && tot > 0 && !seg) {
 			what = "clo_hip_radix_sort";
 			void* at = (char*) r->in.ptr + p.off[b] * es;
 			/* (the top SAT_PIPE_BITS key bits are equal inside a bucket: the passes cover the rest) */
@@ -455,6 +504,11 @@ finish:
 	}
 	pthread_mutex_destroy(&p.mtx);
 	pthread_cond_destroy(&p.cv);
+	if (r && r->in.bytes > SAT_PIPE_KEEP_BYTES) {   /* large arrays: do not leave two more copies of them resident in the sorter */
+		clo_hip_stream_synchronize(s_exec);
+		clo_devbuf_release(&r->in);
+		clo_devbuf_release(&r->part);
+	}
 	return ok && (err == NULL || *err == NULL);
 }
 
@@ -504,7 +558,7 @@ static CCLEvent* clo_sort_satradix_sort_segments(CloSort* sorter, CCLQueue* cq_e
 		if (!evt) return NULL;
 	}
 	if (numel > 0) {
-		const int st = clo_hip_radix_sort_segmented(a_dev, b_dev, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
+		const int st = clo_hip_radix_sort_segmented(a_dev, a_dev, b_dev, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
 			ks->elem_size, key_shift, key_bits, (int) clo_tzc((int) data->radix), data->seg_ws.ptr, data->seg_ws.bytes,
 			ccl_queue_get_stream(cq_exec), result_in_b);
 		if (clo_hip_failed(st, err, "clo_hip_radix_sort_segmented")) {
@@ -592,6 +646,7 @@ static const char* clo_sort_satradix_init(CloSort* sorter, const char* options, 
 	clo_sort_satradix_data* data = (clo_sort_satradix_data*) calloc(1, sizeof(*data));
 	if (!data) return NULL;
 	data->radix = 16;
+	data->host_pipeline = clo_env_flag("CLO_SORT_HOST_PIPELINE");
 	data->status = clo_status_cell_new(NULL);
 	satradix_opt_ctx c = { data, NULL, 0 };
 	if (!clo_parse_options(options, satradix_option, &c, "satradix", err)) {

@@ -15,8 +15,8 @@ static CCLEvent* clo_sort_sbitonic_sort_with_device_data(CloSort* sorter, CCLQue
 	CCLQueue* cq_comm, CCLBuffer* data_in, CCLBuffer* data_out, size_t numel, size_t lws_max,
 	GError** err) {
 	(void) lws_max;
-	const int tiled = getenv("CLO_SBITONIC_STEPS") == NULL;   /* (read per call) */
-	return clo_bitonic_run(sorter, (clo_bitonic_state*) clo_sort_get_data(sorter), tiled, 1,
+	clo_bitonic_state* state = (clo_bitonic_state*) clo_sort_get_data(sorter);
+	return clo_bitonic_run(sorter, state, !state->steps, 1,
 		"sbitonic_ndrange", "sbitonic_copy", cq_exec, cq_comm, data_in, data_out, numel, err);
 }
 
@@ -26,6 +26,7 @@ static const char* clo_sort_sbitonic_init(CloSort* sorter, const char* options, 
 	(void) options;
 	clo_bitonic_state* state = (clo_bitonic_state*) calloc(1, sizeof(*state));
 	if (!state) return NULL;
+	state->steps = clo_env_flag("CLO_SBITONIC_STEPS") == 1;
 	clo_sort_set_data(sorter, state);
 	return "sbitonic:hip";
 }

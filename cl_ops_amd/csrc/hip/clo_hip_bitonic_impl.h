@@ -672,8 +672,6 @@ int any_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_siz
 	return (int) hipGetLastError();
 }
 
-inline bool g_no_strided2() { static const bool off = getenv("CLO_BITONIC_NO_STRIDED2") != nullptr; return off; }   // (A/B measurements only)
-
 template <typename E, int NS, int MODE>
 void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_desc& kd, hipStream_t s) {
 	const size_t threads = n >> NS;
@@ -729,7 +727,7 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 				// a two-level pass (up to 2Q steps) when it saves a pass over plain ones
 				const unsigned h = ns, n2 = h < 2u * Q ? h : 2u * Q;
 				const unsigned plain = (h + QS - 1) / QS, with2 = 1u + (h - n2 + QS - 1) / QS;
-				if (n2 > (unsigned) Q && with2 < plain && !g_no_strided2()) {
+				if (n2 > (unsigned) Q && with2 < plain) {
 					clo_timing_scope timing("bitonic_strided2", s);
 					hipLaunchKernelGGL((clo_bitonic_strided2_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, p, n2, kd);
 					++count;

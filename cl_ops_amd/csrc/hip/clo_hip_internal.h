@@ -17,6 +17,15 @@
 #define CLO_WS_MAX_PASSES    64
 #define CLO_WS_HEADER_BYTES  512
 
+// The environment switches of the HIP layer, read in ONE place (clo_hip_runtime.hip: clo_hip_env_refresh) and only
+// when an object is made (clo_sort_new / clo_scan_new / clo_shard_sort_new call it) or a test asks — never per call:
+//   CLO_MAX_SPINS        bound of every look-back poll loop (default CLO_MAX_SPINS below; tests force a give-up with 0)
+//   CLO_RADIX_SWEEP      0: never take the single-sweep radix passes, 1: whenever possible; unset: the library's choice
+//   CLO_R1_POOLS         8: the single-sweep passes draw tiles from one ticket pool per XCD (256-CU devices only)
+//   CLO_RADIX_NO_DIGITS  set: no digit stream between the chain-free passes (tests compare both)
+struct clo_hip_env_t { unsigned max_spins; int radix_sweep; int r1_pools; int no_digits; };
+const clo_hip_env_t* clo_hip_env();
+
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 
@@ -122,7 +131,7 @@ int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const 
 	clo_seg_tile* tiles, clo_seg_chunk* chunks, unsigned* ntiles, unsigned* nchunks, hipStream_t s);
 void clo_radixw_seg_bounds(size_t numel, int npieces, int nseg, size_t tile, size_t* max_tiles, size_t* max_chunks);
 size_t clo_radix4_seg_workspace_bytes(size_t n, int nseg, int elem_size, int digit_bits);
-int clo_radix4_sort_segmented(void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
+int clo_radix4_sort_segmented(const void* src, void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
 	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int elem_size, int key_shift,
 	int key_bits, int digit_bits, void* ws, hipStream_t s, int* result_in_b);
 

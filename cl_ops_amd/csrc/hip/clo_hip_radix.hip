@@ -106,13 +106,13 @@ size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, 
 	return clo_radix4_seg_workspace_bytes(numel, nseg, elem_size, digit_bits);
 }
 
-int clo_hip_radix_sort_segmented(void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
 	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
 	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream, int* result_in_b) {
 	if (!result_in_b) return CLO_HIP_EARGS;
 	*result_in_b = 0;
 	if (numel == 0) return 0;
-	if (!a || !b || a == b || !workspace || !seg_counts || nseg < 1 || nseg > CLO_SEG_MAX) return CLO_HIP_EARGS;
+	if (!src || !a || !b || a == b || src == b || !workspace || !seg_counts || nseg < 1 || nseg > CLO_SEG_MAX) return CLO_HIP_EARGS;
 	if (npieces < 0 || npieces > CLO_SEG_MAX || (npieces > 0 && (!piece_counts || !piece_offsets || !piece_segment))) return CLO_HIP_EARGS;
 	if (elem_size != 4 && elem_size != 8) return CLO_HIP_EUNSUPPORTED;
 	if (digit_bits != 4 && digit_bits != 8) return CLO_HIP_EUNSUPPORTED;
@@ -121,11 +121,11 @@ int clo_hip_radix_sort_segmented(void* a, void* b, size_t numel, const size_t* s
 	size_t total = 0;
 	for (int i = 0; i < nseg; ++i) total += seg_counts[i];
 	if (total != numel) return CLO_HIP_EARGS;
-	if (npieces > 0) {   // the pieces of a segment add up to it, every piece lies inside the source
+	if (npieces > 0) {   // the pieces of a segment add up to it (where they lie in `src` is the caller's business: 32-bit element offsets)
 		size_t per[CLO_SEG_MAX];
 		for (int k = 0; k < nseg; ++k) per[k] = 0;
 		for (int i = 0; i < npieces; ++i) {
-			if (piece_segment[i] < 0 || piece_segment[i] >= nseg || piece_offsets[i] > numel || piece_counts[i] > numel - piece_offsets[i]) return CLO_HIP_EARGS;
+			if (piece_segment[i] < 0 || piece_segment[i] >= nseg || piece_offsets[i] > 0xffffffffull || piece_counts[i] > numel) return CLO_HIP_EARGS;
 			per[piece_segment[i]] += piece_counts[i];
 		}
 		for (int k = 0; k < nseg; ++k) if (per[k] != seg_counts[k]) return CLO_HIP_EARGS;
@@ -133,7 +133,7 @@ int clo_hip_radix_sort_segmented(void* a, void* b, size_t numel, const size_t* s
 	const size_t need = clo_radix4_seg_workspace_bytes(numel, nseg, elem_size, digit_bits);
 	if (need == 0) return CLO_HIP_EUNSUPPORTED;
 	if (workspace_bytes < need) return CLO_HIP_EWORKSPACE;
-	return clo_radix4_sort_segmented(a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
+	return clo_radix4_sort_segmented(src, a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
 		elem_size, key_shift, key_bits, digit_bits, workspace, (hipStream_t) stream, result_in_b);
 }
 

@@ -61,7 +61,6 @@
 
 namespace {
 
-constexpr int R1_CHUNK_LOG_DEFAULT = 4;              // 16 tiles per chunk (a template parameter of the sweep kernel)
 constexpr int R1_PEEL = 4;                           // groups of equal digits a skewed wave counts by ballot, per element
 constexpr int R1_WINDOW = 8;                         // chunks a level-2 hop inspects
 constexpr unsigned R1_VALID = 0x80000000u;            // 32-bit entries: bit 31 = written, bits 30..0 = count
@@ -513,12 +512,6 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 // ---------------------------------------------------------------------------
 struct r1_layout { size_t ghist, gbase, tickets, done, pass0, per_pass, agg, cacc, cprefix, total, tiles, chunks; int passes; };
 
-int r1_chunk_log() {   // CLO_R1_CHUNK_LOG: 3 or 4 (A/B measurements)
-	const char* m = getenv("CLO_R1_CHUNK_LOG");
-	const int v = m ? atoi(m) : R1_CHUNK_LOG_DEFAULT;
-	return v == 3 ? 3 : 4;
-}
-
 r1_layout r1_make_layout(size_t n, int elem_size, int key_bits) {
 	r1_layout L;
 	const size_t tile = (size_t) 512 * (elem_size == 8 ? 8 : 16);
@@ -571,21 +564,15 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	const unsigned tiles = (unsigned) L.tiles;
 	const int passes = L.passes;
 	const clo_keyx kx_none = { 0, 0, 0 };
-	unsigned max_spins = CLO_MAX_SPINS;
-	if (const char* m = getenv("CLO_MAX_SPINS")) max_spins = (unsigned) strtoul(m, nullptr, 10);
-	const int chunk_log = r1_chunk_log();
-	int early = 8;   // (CLO_R1_EARLY: A/B measurements)
-	if (const char* m = getenv("CLO_R1_EARLY")) early = atoi(m);
+	const clo_hip_env_t* env = clo_hip_env();
+	const unsigned max_spins = env->max_spins;
 
-	// ticket pools: one counter unless the eight pools are safe (head of this file); CLO_R1_POOLS: A/B runs
+	// ticket pools: one counter unless the eight pools are safe (head of this file); CLO_R1_POOLS: tests of both
 	unsigned pools = (tiles > 1024u && r1_device_cus() >= 256) ? (unsigned) R1_POOLS : 1u;
-	if (const char* m = getenv("CLO_R1_POOLS")) pools = atoi(m) == R1_POOLS ? (unsigned) R1_POOLS : 1u;
+	if (env->r1_pools != 0) pools = env->r1_pools == R1_POOLS ? (unsigned) R1_POOLS : 1u;
 
-	const bool dbg = getenv("CLO_DEBUG") != nullptr;
-	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: n=%zu tiles=%u passes=%d ws=%p bytes=%zu stream=%p\n", n, tiles, passes, ws, L.total, (void*) s);
 	// everything the passes publish or count in starts from zero
 	hipError_t e = hipMemsetAsync(ws, 0, L.total, s);
-	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: memset -> %d\n", (int) e);
 	if (e != hipSuccess) return (int) e;
 	{
 		clo_timing_scope timing("radix_ghist", s);
@@ -596,11 +583,9 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 			default: return CLO_HIP_EUNSUPPORTED;
 		}
 	}
-	if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: ghist launched -> %d\n", (int) hipPeekAtLastError());
 	const bool inplace_odd = (dst == src) && (passes % 2 == 1);
 	const E* cur_in = src;
 	for (int p = 0; p < passes; ++p) {
-		if (dbg) fprintf(stderr, "cl_ops-DEBUG: radix1: pass %d\n", p);
 		E* cur_out;
 		if (inplace_odd) cur_out = (p % 2 == 0) ? tmp : dst;
 		else cur_out = ((passes - 1 - p) % 2 == 0) ? dst : tmp;
@@ -623,7 +608,7 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 		#define CLO_R1_SWEEP(CL, EARLY) hipLaunchKernelGGL((clo_radix1_sweep_kernel<E, 4, 4, CL, EARLY>), dim3(tiles), dim3(sweep_shape<E>::THREADS), 0, s, \
 			cur_in, cur_out, n, (unsigned) (key_shift + p * 8), (1u << lo_bits) - 1u, (1u << hi_bits) - 1u, P, \
 			(int) ((uintptr_t) cur_in % 16 == 0), p == 0 ? kx : kx_none, p + 1 == passes ? kx : kx_none)
-		if (chunk_log == 3) CLO_R1_SWEEP(3, 8); else if (early == 0) CLO_R1_SWEEP(4, 0); else CLO_R1_SWEEP(4, 8);
+		CLO_R1_SWEEP(4, 8);   // (16 tiles per chunk, 8 rows requested early: measured against 8 tiles / no early rows in round 2)
 		#undef CLO_R1_SWEEP
 		cur_in = cur_out;
 	}
@@ -642,9 +627,8 @@ int r1_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 // (clo_hip_radix4.hip). Digits of 4 or 8 bits only (radix 16: two digits per
 // sweep; radix 256: one), 4- and 8-byte elements, fewer than 2^31 of them.
 int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
-	// CLO_RADIX_SWEEP: 0 never, 1 whenever possible, unset: the library's choice (read per call: A/B runs)
-	const char* x = getenv("CLO_RADIX_SWEEP");
-	const int mode = x ? (atoi(x) != 0 ? 1 : 0) : 2;
+	// CLO_RADIX_SWEEP: 0 never, 1 whenever possible, unset: the library's choice
+	const int mode = clo_hip_env()->radix_sweep;
 	if (mode == 0) return 0;
 	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));

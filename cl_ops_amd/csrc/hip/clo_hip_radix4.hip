@@ -334,7 +334,7 @@ int rp_sort_impl(const E* src, E* dst, E* tmp, size_t n, int key_shift, int key_
 	unsigned* tinfo = (unsigned*) ((char*) ws + L.tinfo);
 	const unsigned tiles = (unsigned) L.tiles;
 	const bool big = clo_radix_big_tiles(n, (int) sizeof(E));
-	const bool no_dig = getenv("CLO_RADIX_NO_DIGITS") != nullptr;   // (A/B runs and tests: read at every call)
+	const bool no_dig = clo_hip_env()->no_digits != 0;   // (tests compare both)
 	// (the stream exists for the schedules of radix 16 and 256 only, LB = HB = 4: every other digit width
 	// would be another set of kernels to compile for sorts nobody times)
 	constexpr bool DIG_OK = LB == 4 && HB == 4 && sizeof(E) >= 4;
@@ -504,8 +504,9 @@ int r4_partition_impl(const E* src, E* dst, size_t n, unsigned shift, unsigned l
 // receives (clo_shard.c) share their top key bits, so sorting them one by one on the remaining bits is right
 // but launch-bound (32 sorts of 2^23 keys: 12 launches each, every one too small for the chip), while one
 // segmented sort of all of them runs launches of the whole slice. The radix-16 / 256 schedule only (LB = HB = 4),
-// unsigned keys. The two buffers take turns: the result is in `b` after an odd number of passes, in `a` after an
-// even one (*result_in_b); `a` (the source) is overwritten either way.
+// unsigned keys. The first pass reads `src` (the segments back to back, or their pieces anywhere in it) and writes
+// `b`; the later ones go b -> a -> b ...: the result is in `b` after an odd number of passes, in `a` after an even
+// one (*result_in_b). `src` may be `a` (it is read by the first pass only) and is otherwise left alone.
 // ---------------------------------------------------------------------------
 struct rp_seg_layout { size_t thist, toff, partial, tinfo, tdesc, cdesc, dig, total, tile, max_tiles, max_chunks; bool big; };
 
@@ -534,7 +535,7 @@ rp_seg_layout rp_make_seg_layout(size_t n, int nseg, int elem_size) {
 }
 
 template <typename E>
-int rp_sort_seg_impl(E* a, E* b, size_t n, const size_t* seg_counts, int nseg,
+int rp_sort_seg_impl(const E* src, E* a, E* b, size_t n, const size_t* seg_counts, int nseg,
 	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int key_shift, int key_bits, void* ws,
 	hipStream_t s, int* result_in_b) {
 	constexpr int LB = 4, HB = 4, PB = 8;
@@ -574,11 +575,11 @@ int rp_sort_seg_impl(E* a, E* b, size_t n, const size_t* seg_counts, int nseg,
 		return CLO_HIP_EWORKSPACE;   // (cannot happen: the bounds hold for any split of n)
 	unsigned char* dig = (L.dig != 0 && passes > 1) ? (unsigned char*) ws + L.dig : nullptr;
 	const clo_keyx kx_none = { 0, 0, 0 };
-	E* cur_in = a;
+	const E* cur_in = src;
 	for (int p = 0; p < passes; ++p) {
 		const clo_seg_tables& sgp = p == 0 ? sg0 : sg;
 		const unsigned grid = (sgp.ntiles + 7u) / 8u * 8u;
-		E* cur_out = cur_in == a ? b : a;
+		E* cur_out = p % 2 == 0 ? b : a;
 		const int rem = key_bits - p * PB;
 		const int bits = rem < PB ? rem : PB;
 		const int lo_bits = bits < LB ? bits : LB, hi_bits = bits - lo_bits;
@@ -660,12 +661,12 @@ size_t clo_radix4_seg_workspace_bytes(size_t n, int nseg, int elem_size, int dig
 	return rp_make_seg_layout(n, nseg, elem_size).total;
 }
 
-int clo_radix4_sort_segmented(void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
+int clo_radix4_sort_segmented(const void* src, void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
 	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int elem_size, int key_shift,
 	int key_bits, int digit_bits, void* ws, hipStream_t s, int* result_in_b) {
 	if (digit_bits != 4 && digit_bits != 8) return CLO_HIP_EUNSUPPORTED;
-	if (elem_size == 4) return rp_sort_seg_impl<uint32_t>((uint32_t*) a, (uint32_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
-	if (elem_size == 8) return rp_sort_seg_impl<uint64_t>((uint64_t*) a, (uint64_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
+	if (elem_size == 4) return rp_sort_seg_impl<uint32_t>((const uint32_t*) src, (uint32_t*) a, (uint32_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
+	if (elem_size == 8) return rp_sort_seg_impl<uint64_t>((const uint64_t*) src, (uint64_t*) a, (uint64_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
 	return CLO_HIP_EUNSUPPORTED;
 }
 
@@ -712,7 +713,7 @@ size_t clo_radix4_lds_bytes(int elem_size, int digit_bits) {
 
 // 1: a sort of this shape reads caller-provided first digits (the chain-free passes on big tiles, radix 16 / 256)
 int clo_radix4_takes_first_digits(size_t n, int elem_size, int digit_bits) {
-	if (elem_size < 4 || (digit_bits != 4 && digit_bits != 8) || getenv("CLO_RADIX_NO_DIGITS") != nullptr) return 0;
+	if (elem_size < 4 || (digit_bits != 4 && digit_bits != 8) || clo_hip_env()->no_digits) return 0;
 	if (clo_radix1_applies(n, elem_size, digit_bits)) return 0;
 	return clo_radix_big_tiles(n, elem_size) ? 1 : 0;
 }

@@ -165,6 +165,18 @@ int clo_hip_event_destroy(void* event) { return event ? (int) hipEventDestroy((h
 int clo_hip_event_record(void* event, void* stream) {
 	return (int) hipEventRecord((hipEvent_t) event, (hipStream_t) stream);
 }
+// ---- environment switches: one reader (clo_hip_internal.h has the list) ----
+static clo_hip_env_t g_env = { CLO_MAX_SPINS, 2, 0, 0 };
+static int g_env_read = 0;
+void clo_hip_env_refresh(void) {
+	clo_hip_env_t e = { CLO_MAX_SPINS, 2, 0, 0 };
+	if (const char* m = getenv("CLO_MAX_SPINS")) e.max_spins = (unsigned) strtoul(m, nullptr, 10);
+	if (const char* m = getenv("CLO_RADIX_SWEEP")) e.radix_sweep = atoi(m) != 0 ? 1 : 0;
+	if (const char* m = getenv("CLO_R1_POOLS")) e.r1_pools = atoi(m);
+	e.no_digits = getenv("CLO_RADIX_NO_DIGITS") != nullptr;
+	g_env = e;
+	g_env_read = 1;
+}
 int clo_hip_event_synchronize(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }
 int clo_hip_event_query(void* event) { return event ? (int) hipEventQuery((hipEvent_t) event) : CLO_HIP_EARGS; }
 int clo_hip_event_elapsed_ms(void* start, void* stop, float* ms) {
@@ -231,3 +243,9 @@ int clo_hip_check_status(void* workspace, void* stream) {
 }
 
 }  // extern "C"
+
+const clo_hip_env_t* clo_hip_env() {
+	if (!g_env_read) clo_hip_env_refresh();
+	return &g_env;
+}
+

@@ -371,7 +371,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	}
 }
 
-unsigned g_scan_xflags = 0;  // developer experiments (CLO_SCAN_XFLAGS), never set in production
+constexpr unsigned g_scan_xflags = 0;  // (the kernel's experiment switches — non-temporal loads / stores: no difference, DESIGN.md — stay off)
 unsigned g_scan_max_spins = CLO_MAX_SPINS;   // CLO_MAX_SPINS in the environment overrides (tests force a give-up with it)
 
 // Work-group shape by array size. Every work-group draws a ticket from one
@@ -589,12 +589,7 @@ int clo_hip_scan_exclusive_carry(const void* data_in, void* data_out, size_t num
 	}
 	if (!data_in || !data_out || !workspace) return CLO_HIP_EARGS;
 	if (sum_size < elem_size) return CLO_HIP_EUNSUPPORTED;
-	{
-		const char* x = getenv("CLO_SCAN_XFLAGS");
-		g_scan_xflags = x ? (unsigned) atoi(x) : 0u;
-		const char* m = getenv("CLO_MAX_SPINS");
-		g_scan_max_spins = m ? (unsigned) strtoul(m, nullptr, 10) : CLO_MAX_SPINS;
-	}
+	g_scan_max_spins = clo_hip_env()->max_spins;
 	if (workspace_bytes < clo_hip_scan_workspace_bytes(numel, elem_size, sum_size)) return CLO_HIP_EWORKSPACE;
 	// the place of the accumulators follows from the workspace's size, and nothing is cleared per call:
 	// this must be the range clo_hip_scan_workspace_init prepared, under the byte count it was given

@@ -66,6 +66,10 @@ int clo_hip_memset_async(void* dst, int value, size_t bytes, void* stream);
 int clo_hip_host_register(void* host_ptr, size_t bytes);
 int clo_hip_host_unregister(void* host_ptr);
 
+/* Re-reads the library's environment switches (CLO_MAX_SPINS, CLO_RADIX_SWEEP, CLO_R1_POOLS, CLO_RADIX_NO_DIGITS;
+ * INTEGRATION.md lists them all). The C API calls it whenever a sorter / scanner is made; calls in between use what
+ * was read then — nothing is read per call. */
+void clo_hip_env_refresh(void);
 int clo_hip_event_create(void** event);
 int clo_hip_event_destroy(void* event);
 int clo_hip_event_record(void* event, void* stream);
@@ -195,15 +199,17 @@ int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
  * Sub-buckets that share their top key bits (what an MSD partition leaves) are thereby sorted on the REMAINING
  * bits at the rate of one large sort, where sorting them one by one would be launch-bound.
  * Where the segments lie: the RESULT holds them back to back in order (segment k at the sum of the counts before
- * it). The SOURCE `a` either holds them the same way (npieces = 0) or in up to 256 PIECES anywhere inside
- * a[0 .. numel): piece i = piece_counts[i] elements from piece_offsets[i], belonging to segment piece_segment[i],
- * pieces listed in segment order (what a rank of the sharded sort receives: one piece per source rank and
- * sub-bucket); the first pass then gathers a segment's pieces, in the order listed, as a by-product.
- * The two buffers take turns: the result is in `b` when *result_in_b comes back 1 (an odd number of 8-bit
- * passes), else in `a`; `a` is overwritten either way. digit_bits 4 or 8 (radix 16 / 256), elem_size 4 or 8,
- * unsigned keys. Asynchronous; the host arrays are read before the call returns. */
+ * it). The SOURCE `src` either holds them the same way (npieces = 0) or in up to 256 PIECES anywhere in it
+ * (offsets below 2^32 elements): piece i = piece_counts[i] elements from piece_offsets[i], belonging to segment
+ * piece_segment[i], pieces listed in segment order (what a rank of the sharded sort receives: one piece per
+ * source rank and sub-bucket); the first pass then gathers a segment's pieces, in the order listed, as a
+ * by-product. The first pass reads `src` and writes `b` (numel elements), the later ones go b -> a -> b ...: the
+ * result is in `b` when *result_in_b comes back 1 (an odd number of 8-bit passes, ceil(key_bits / 8)), else in
+ * `a`. `src` may be `a` itself (the first pass is the only one to read it); otherwise it is left untouched.
+ * digit_bits 4 or 8 (radix 16 / 256), elem_size 4 or 8, unsigned keys. Asynchronous; the host arrays are read
+ * before the call returns. */
 size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, int digit_bits);
-int clo_hip_radix_sort_segmented(void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
 	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
 	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream,
 	int* result_in_b);

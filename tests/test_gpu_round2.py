@@ -85,7 +85,9 @@ def test_scan_lookback_timeout_is_reported(gpu, monkeypatch):
     a = np.random.default_rng(9).integers(0, 128, n, dtype=np.uint32)
     sc = clo.Scanner("blelloch", ctx, "uint", "uint")
     assert np.array_equal(sc.with_host_data(a, q), _excl(a, np.uint32))
+    from cl_ops_amd._hip import lib
     monkeypatch.setenv("CLO_MAX_SPINS", "0")
+    lib.clo_hip_env_refresh()                 # (the switches are read when an object is made — or on request)
     with pytest.raises(clo.CloError) as e:
         sc.with_host_data(a, q)
     assert e.value.code == clo.api.CLO_ERROR_LIBRARY and "look-back" in e.value.message
@@ -96,6 +98,7 @@ def test_scan_lookback_timeout_is_reported(gpu, monkeypatch):
         q.finish()
     assert e.value.code == clo.api.CLO_ERROR_LIBRARY
     monkeypatch.delenv("CLO_MAX_SPINS")
+    lib.clo_hip_env_refresh()
     sc.with_device_data(q, src, dst, n)
     q.finish()
     assert np.array_equal(dst.read(q, np.uint32, n), _excl(a, np.uint32))

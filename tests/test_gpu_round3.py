@@ -38,6 +38,7 @@ def test_sort_lookback_timeout_is_reported_on_every_queue_shape(gpu, monkeypatch
     assert np.array_equal(s.with_host_data(a, qx, qc), want)
 
     monkeypatch.setenv("CLO_MAX_SPINS", "0")
+    lib.clo_hip_env_refresh()                 # (the switches are read when an object is made — or on request)
     for queues in ((q, None), (qx, qc)):
         with pytest.raises(clo.CloError) as e:
             s.with_host_data(a, *queues)
@@ -55,6 +56,7 @@ def test_sort_lookback_timeout_is_reported_on_every_queue_shape(gpu, monkeypatch
         qc.finish()
     assert e.value.code == clo.api.CLO_ERROR_LIBRARY
     monkeypatch.setenv("CLO_MAX_SPINS", str(1 << 16))
+    lib.clo_hip_env_refresh()
     try:
         qx.finish()      # (the give-up above may still be pending on the exec queue: reported once more at most)
     except clo.CloError:
@@ -406,24 +408,30 @@ def test_sort_host_data_pipelined_equals_blocking(gpu, monkeypatch, kind, n, two
     if kind == "uint":
         a = rng.integers(0, 1 << 32, n, dtype=np.uint32)
         a[: n // 7] &= np.uint32(0x0fffffff)                       # uneven buckets
-        s = clo.Sorter("satradix", ctx, "uint")
+        make = lambda: clo.Sorter("satradix", ctx, "uint")         # noqa: E731
     elif kind == "ulong":
         a = rng.integers(0, np.iinfo(np.uint64).max, n, dtype=np.uint64, endpoint=True)
-        s = clo.Sorter("satradix", ctx, "ulong")
+        make = lambda: clo.Sorter("satradix", ctx, "ulong")        # noqa: E731
     else:   # few distinct keys: equal keys must keep their input order
         a = (rng.integers(0, 1000, n, dtype=np.uint64) << np.uint64(32 + 20)) | np.arange(n, dtype=np.uint64)
-        s = clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")
+        make = lambda: clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")   # noqa: E731
     qx = clo.Queue(ctx, profiling=True)
     qc = clo.Queue(ctx) if two_queues else None
+    # (the switch is read when a sorter is made)
     monkeypatch.setenv("CLO_SORT_HOST_PIPELINE", "0")
-    ref = s.with_host_data(a, qx, qc)
+    s0 = make()
+    ref = s0.with_host_data(a, qx, qc)
+    s0.close()
     monkeypatch.setenv("CLO_SORT_HOST_PIPELINE", "1")
+    s = make()
     got = s.with_host_data(a, qx, qc)
     assert np.array_equal(got, ref)
     monkeypatch.delenv("CLO_SORT_HOST_PIPELINE")                    # the default: pipelined on a queue without profiling
+    sd = make()
     qn = clo.Queue(ctx)
-    assert np.array_equal(s.with_host_data(a, qn, qc), ref)
+    assert np.array_equal(sd.with_host_data(a, qn, qc), ref)
     qn.close()
+    sd.close()
     if kind != "pairs":
         assert np.array_equal(got, np.sort(a))
     else:

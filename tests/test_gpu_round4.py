@@ -39,7 +39,7 @@ def _seg_sort(torch, a, seg_counts, key_shift, key_bits, digit_bits=4, pieces=No
     else:
         args = (None, None, None, 0)
     in_b = C.c_int(-1)
-    st = lib.clo_hip_radix_sort_segmented(ta.data_ptr(), tb.data_ptr(), n, sc, nseg, *args, es, key_shift, key_bits, digit_bits,
+    st = lib.clo_hip_radix_sort_segmented(ta.data_ptr(), ta.data_ptr(), tb.data_ptr(), n, sc, nseg, *args, es, key_shift, key_bits, digit_bits,
                                           ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream, C.byref(in_b))
     _hip.check(st, "clo_hip_radix_sort_segmented")
     torch.cuda.synchronize()
@@ -200,3 +200,42 @@ def test_bad_compiler_opts_give_a_gerror_with_the_build_log(cq, alg, opts, needl
         clo.Sorter(alg, ctx, "uint", get_key="((x) >> SHIFT) & 0xfff", compiler_opts=opts)
     assert e.value.code == 2                                   # CLO_ERROR_ARGS (clo_common.in.h:80-95)
     assert "Could not build kernels" in e.value.message and needle in e.value.message.lower(), e.value.message
+
+
+@pytest.mark.parametrize("dt,key_bits", [(np.uint32, 24), (np.uint32, 16), (np.uint64, 24)])
+def test_segmented_sort_from_a_larger_source(gpu, dt, key_bits):
+    """`src` is neither of the two working buffers: the pieces lie anywhere in a larger array (what the pipelined
+    clo_sort_with_host_data hands over: sub-buckets scattered over the split chunks), `src` stays untouched, and the
+    result lands in `b` after an odd number of passes, in `a` after an even one."""
+    torch = gpu
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    es = np.dtype(dt).itemsize
+    rng = np.random.default_rng(key_bits + es)
+    big = rng.integers(0, np.iinfo(dt).max, (1 << 22) + 333, dtype=dt, endpoint=True)
+    nseg, nchunk = 16, 8
+    sizes = rng.integers(0, 9000, (nseg, nchunk))
+    starts = np.sort(rng.choice(big.size // 16384, nseg * nchunk, replace=False)).reshape(nchunk, nseg).T * 16384 + 5   # disjoint, unaligned
+    pn, po, ps = [], [], []
+    for k in range(nseg):
+        for c in range(nchunk):
+            pn.append(int(sizes[k, c])); po.append(int(starts[k, c])); ps.append(k)
+    seg_counts = sizes.sum(axis=1)
+    n = int(seg_counts.sum())
+    tdt = np.int32 if es == 4 else np.int64
+    src = torch.from_numpy(big.view(tdt).copy()).cuda()
+    ta = torch.zeros(n, dtype=src.dtype, device="cuda")
+    tb = torch.zeros(n, dtype=src.dtype, device="cuda")
+    need = lib.clo_hip_radix_seg_workspace_bytes(n, nseg, es, 8)
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    npc = len(pn)
+    in_b = C.c_int(-1)
+    _hip.check(lib.clo_hip_radix_sort_segmented(src.data_ptr(), ta.data_ptr(), tb.data_ptr(), n, (C.c_size_t * nseg)(*[int(x) for x in seg_counts]), nseg,
+                                                (C.c_size_t * npc)(*pn), (C.c_size_t * npc)(*po), (C.c_int * npc)(*ps), npc, es, 3, key_bits, 8,
+                                                ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream, C.byref(in_b)))
+    torch.cuda.synchronize()
+    assert in_b.value == (-(-key_bits // 8)) % 2
+    got = (tb if in_b.value else ta).cpu().numpy().view(dt)
+    gathered = np.concatenate([big[starts[k, c]:starts[k, c] + sizes[k, c]] for k in range(nseg) for c in range(nchunk)])
+    assert np.array_equal(got, _expect(gathered, seg_counts, 3, key_bits))
+    assert np.array_equal(src.cpu().numpy().view(dt), big)

@@ -41,7 +41,7 @@ FAM = ("radix_seg_tables", "radix_hist", "radix_offsets", "radix_pass")
 
 def seg():
     ta.copy_(src)
-    _hip.check(lib.clo_hip_radix_sort_segmented(ta.data_ptr(), tb.data_ptr(), n, sc, nseg, None, None, None, 0, es, 0, kb, 4,
+    _hip.check(lib.clo_hip_radix_sort_segmented(ta.data_ptr(), ta.data_ptr(), tb.data_ptr(), n, sc, nseg, None, None, None, 0, es, 0, kb, 4,
                                                 ws.data_ptr(), need, stream, C.byref(in_b)))
 
 
@@ -53,7 +53,7 @@ tot = 0.0
 for _ in range(10):
     ta.copy_(src)
     e0.record()
-    _hip.check(lib.clo_hip_radix_sort_segmented(ta.data_ptr(), tb.data_ptr(), n, sc, nseg, None, None, None, 0, es, 0, kb, 4,
+    _hip.check(lib.clo_hip_radix_sort_segmented(ta.data_ptr(), ta.data_ptr(), tb.data_ptr(), n, sc, nseg, None, None, None, 0, es, 0, kb, 4,
                                                 ws.data_ptr(), need, stream, C.byref(in_b)))
     e1.record()
     torch.cuda.synchronize()
