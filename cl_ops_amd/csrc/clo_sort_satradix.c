@@ -246,7 +246,11 @@ static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GEr
  * split + 3 passes for 32-bit keys, where the 4-bit split needed a gather copy and 4 passes per bucket (6 trips). */
 #define SAT_PIPE_SEG_BITS 8
 #define SAT_PIPE_SUBS (1 << SAT_PIPE_SEG_BITS)
-#define SAT_PIPE_KEEP_BYTES ((size_t) 512 << 20)   /* the two array-sized buffers stay cached in the sorter up to this size each */
+/* The two array-sized buffers of the pipeline stay cached in the sorter up to this size each; larger ones are freed
+ * when the call ends (the sorter would otherwise keep three times the array resident until it is destroyed). Not lower:
+ * freeing and allocating 2 x 1 GiB per call cost 19 ms of a 39 ms sort of 2^28 keys (measured); at 8 GiB the array's own
+ * transfers take 300 ms. */
+#define SAT_PIPE_KEEP_BYTES ((size_t) 8 << 30)
 
 typedef struct sat_pipe_res_s {
 	clo_devbuf in, part, counts, msd_ws;   /* the array as it arrives / split chunk by chunk; bucket sizes; workspace of the splits */

@@ -18,7 +18,6 @@ for logn in [int(x) for x in sys.argv[1:]] or [24, 26, 28]:
         n = 1 << logn
         dt = np.uint32 if kind == "uint" else np.uint64
         a = np.random.default_rng(0).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
-        s = clo.Sorter("satradix", ctx, kind)
         buf = clo.Buffer(ctx, a.nbytes)
 
         def best(fn, reps=4):
@@ -47,9 +46,12 @@ for logn in [int(x) for x in sys.argv[1:]] or [24, 26, 28]:
             ok = lib.clo_sort_with_host_data(s.h, qx.h, qc.h, a.ctypes.data_as(vp), out.ctypes.data_as(vp), n, 0, err.ref)
             err.raise_if_set()
             assert ok
-        os.environ["CLO_SORT_HOST_PIPELINE"] = "0"
+        os.environ["CLO_SORT_HOST_PIPELINE"] = "0"           # (read when the sorter is made)
+        s = clo.Sorter("satradix", ctx, kind)
         t_block = best(run)
+        s.close()
         os.environ["CLO_SORT_HOST_PIPELINE"] = "1"
+        s = clo.Sorter("satradix", ctx, kind)
         t_pipe = best(run)
         del os.environ["CLO_SORT_HOST_PIPELINE"]
         assert np.array_equal(out[:1000], np.sort(a)[:1000])
