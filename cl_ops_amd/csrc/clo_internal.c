@@ -5,11 +5,13 @@
 
 int clo_debug_enabled(void) {
 	static int cached = -1;
-	if (cached < 0) {
+	int c = __atomic_load_n(&cached, __ATOMIC_RELAXED);
+	if (c < 0) {
 		const char* e = getenv("CLO_DEBUG");
-		cached = (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
+		c = (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
+		__atomic_store_n(&cached, c, __ATOMIC_RELAXED);
 	}
-	return cached;
+	return c;
 }
 
 /* The host drivers' environment switches, each read in one place and only when an object is made

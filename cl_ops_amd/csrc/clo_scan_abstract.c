@@ -51,8 +51,7 @@ static void scan_pipe_res_free(scan_pipe_res* r);
  * the first timed scan (see sort_warmup in clo_sort_abstract.c). Best effort. */
 static void scan_warmup(CloScan* scanner) {
 	static int done;
-	if (done || clo_env_no_warmup()) return;
-	done = 1;
+	if (clo_env_no_warmup() || __atomic_exchange_n(&done, 1, __ATOMIC_RELAXED)) return;   /* (scanners may be made on several threads at once) */
 	const size_t n = 20000;
 	void* in = calloc(n, clo_type_sizeof(scanner->elem_type));
 	void* out = malloc(n * clo_type_sizeof(scanner->sum_type));
@@ -152,8 +151,12 @@ CCLEvent* clo_scan_with_device_data(CloScan* scanner, CCLQueue* cq_exec, CCLQueu
  * out are issued by a helper thread; pinning the caller's memory instead
  * costs ~10 ms per GiB, more than the overlap gains.                     */
 /* ------------------------------------------------------------------ */
+#ifndef CLO_SCAN_PIPE_MIN_NUMEL   /* (the sanitizer build of tests/hoststub shrinks it) */
 #define CLO_SCAN_PIPE_MIN_NUMEL ((size_t) 1 << 25)   /* below this one copy in, one scan, one copy out */
+#endif
+#ifndef CLO_SCAN_PIPE_CHUNK_MAX   /* (the sanitizer build of tests/hoststub shrinks it) */
 #define CLO_SCAN_PIPE_CHUNK_MAX ((size_t) 1 << 24)
+#endif
 
 /* Chunks of the pipeline: chunks of 2^24 elements (the last one shorter), from 2^25
  * elements on. Never smaller (round 3): a chunk below 2^24 elements is scanned by the

@@ -198,8 +198,7 @@ static void sort_warmup(CloSort* sorter, const char* type, size_t elem_size) {
 	if (clo_env_no_warmup() || sorter->jit) return;
 	int k = -1, e = elem_size == 1 ? 0 : (elem_size == 2 ? 1 : (elem_size == 4 ? 2 : 3));
 	for (int i = 0; i < 4; ++i) if (strcmp(type, kinds[i]) == 0) k = i;
-	if (k < 0 || done[k][e]) return;
-	done[k][e] = 1;
+	if (k < 0 || __atomic_exchange_n(&done[k][e], 1, __ATOMIC_RELAXED)) return;   /* (sorters may be made on several threads at once) */
 	/* satradix has three families of kernels, each in a code object of its own:
 	 * the one-launch sort (<= 2^14 elements), the chain-free passes, and the
 	 * single-sweep passes the library uses from 128 tiles on (4 MiB of elements) */

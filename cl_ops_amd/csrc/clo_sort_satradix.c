@@ -236,7 +236,9 @@ static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GEr
  * --------------------------------------------------------------------------- */
 #include <pthread.h>
 
+#ifndef SAT_PIPE_MIN_NUMEL   /* (the sanitizer build of tests/hoststub shrinks it) */
 #define SAT_PIPE_MIN_NUMEL ((size_t) 1 << 24)
+#endif
 #define SAT_PIPE_CHUNKS 8
 #define SAT_PIPE_BITS 4
 #define SAT_PIPE_BUCKETS (1 << SAT_PIPE_BITS)
