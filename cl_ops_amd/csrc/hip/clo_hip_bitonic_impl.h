@@ -680,7 +680,7 @@ void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_des
 		data, n, stage, p, kd);
 }
 
-template <typename E, int MODE>
+template <typename E, int MODE, int TBF = 9>
 int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, hipStream_t s) {
 	// register bits per thread: 32 values of <= 4 bytes, 16 values of 8 bytes
@@ -688,9 +688,8 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	// Arrays of at least 2^KLF elements: 512-thread groups on tiles of 2^KLF
 	// (67 KiB of LDS, two groups per CU) with the compile-time schedule. Smaller
 	// ones are one tile, sorted by one launch of the run-time-schedule kernel.
-	constexpr int TBF = 9;
 	constexpr unsigned KLF = TBF + Q;
-	static_assert(KLF - 1 <= 8 + Q, "the run-time kernel covers every smaller array");
+	static_assert(TBF > 9 || KLF - 1 <= 8 + Q, "the run-time kernel covers every smaller array");
 	// strided passes need p - NS >= 6 so that a wave's 64 lanes read one
 	// contiguous row; KLF >= 13 guarantees it for every p > KLF.
 	E* data = (E*) vdata;
@@ -764,6 +763,9 @@ template <typename E>
 int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, hipStream_t s) {
 	const bool identity = key_shift == 0 && key_bits == 8 * (int) sizeof(E) && key_size == (int) sizeof(E);
+	// (TBF = 10 — 1024-thread groups on 2^15-element tiles, 132 KiB of LDS, one group per CU — was measured in round 4:
+	// 24 launches instead of 27 at 2^26 uint32, but the pre-sort takes 0.400 instead of 0.292 ms and a merge pass 0.102
+	// instead of 0.082: 2.562 against 2.557 ms per sort. One group per CU has nobody to run beside its barriers.)
 	if (identity && key_kind == 0)
 		return tiled_run<E, 1>(vdata, numel, key_shift, key_bits, key_size, key_kind, descending, launches, s);
 	if (identity && key_kind == 1)
