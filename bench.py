@@ -75,6 +75,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PREWARM = 3
+SHARD_SETTLE = 10   # untimed steps of a sharded leg before its warm-up (buffers, clocks, the adaptive slice count)
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy ceiling)
 
 
@@ -438,7 +439,9 @@ def _run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local
     def step():
         return sharded.sort(src, n_local)      # the shard is only read: partition into the send buffer
 
-    for _ in range(PREWARM + warmup):
+    # (the C driver's adaptive slice count tries 4, 2, 1 and 8 slices twice each before it settles, and learns a call's
+    # time two calls later: SHARD_SETTLE untimed steps in front of the W the caller asked for)
+    for _ in range(SHARD_SETTLE + warmup):
         step()
     be.fence()
     # ---- timed region: exactly K steps, fenced on both sides ----
@@ -541,7 +544,7 @@ def main_sharded(args, world, rank, local_rank):
         out = {
             "metric": "Mkeys/s sorting 2^28 uint32 (satradix, 4-bit digits) at 1/2/4/8 GPUs",
             "value": head["value"], "unit": "Mkeys/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "prewarm": PREWARM, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "prewarm": SHARD_SETTLE, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if "weak" in legs else "strong", "vs_baseline": None, "dtype": head["dtype"],
             "data": "synthetic" if not args.dry_run else "dry-run (no GPU: gloo + numpy stand-ins; NOT a measurement)",
             "config": {"workload": "satradix sort of %d x 2^%d %s keys sharded over %d GPUs, radix=%d"
@@ -775,7 +778,7 @@ def shard_world1_leg(etype, log2n, steps, warmup, radix, seed, slices=0):
     src = torch.from_numpy(host.view(np.int32 if es == 4 else np.int64)).to("cuda")
     s = CShardedSorter(etype, 0, options="radix=%d,loopback=1%s" % (radix, ",slices=%d" % slices if slices else ""))
     try:
-        for _ in range(PREWARM + warmup):
+        for _ in range(SHARD_SETTLE + warmup):
             s.sort(src)
         s.check()
         torch.cuda.synchronize()
