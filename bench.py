@@ -721,7 +721,7 @@ def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=Non
     expected = {f: v["launches_per_step"] for f, v in traffic.items() if v.get("launches_per_step")}
     counts_ok = None if not expected else bool(set(expected) == set(seen) and all(abs(seen[f] - expected[f]) < 1e-6 for f in expected))
     ratio = kernel_ms / ms_step if ms_step > 0 else 0.0
-    tol = 0.05 if ms_step >= 0.5 else 0.35              # (launch-bound steps: the event pairs themselves are a share of the step)
+    tol = 0.05 if ms_step >= 0.5 else (0.1 if ms_step >= 0.1 else 0.5)   # (launch-bound steps: the event pairs themselves are a share of the step)
     guard = {"launches_per_step": seen, "expected_launches_per_step": expected or None, "launch_counts_ok": counts_ok,
              "kernel_ms_per_step": round(kernel_ms, 4), "kernel_ms_over_step_ms": round(ratio, 4), "tolerance": tol,
              "timing_ok": bool(abs(ratio - 1.0) <= tol),
