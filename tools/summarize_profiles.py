@@ -152,10 +152,12 @@ for workload in ("satradix_pairs", "satradix_u64"):
 
 # ---- SQ counters of the kernels that ship (tools/pmc_busy.sh) and the other probes of the collection ----
 for extra in ("sq_counters_satradix_u32.txt", "sq_counters_satradix_u64.txt", "skew_probe.txt", "skew_probe_u64.txt",
-              "hostsort_pipeline.txt", "size_sweep.txt", "sweep_sizes_big.txt", "mid_probe.txt"):
+              "hostsort_pipeline.txt", "size_sweep.txt", "sweep_sizes_big.txt", "mid_probe.txt", "shard_alone_probe.txt", "seg_probe.txt",
+              "bench_headline_with_configs.json"):
     f = os.path.join(src, extra)
     if os.path.exists(f):
-        open(os.path.join(dst, "%s_%s" % (tag, extra)), "w").write("".join(l for l in open(f) if "amdgpu.ids" not in l))
+        open(os.path.join(dst, "%s_%s" % (tag, extra)), "w").write("".join(
+            l for l in open(f) if "amdgpu.ids" not in l and not l.startswith(("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl path"))))
 
 # ---- scan and abitonic: the dominant kernel of each ----
 for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_merge_kernel")):
