@@ -722,19 +722,35 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 			// costs more over a sort than the one pass it saves.
 			constexpr int QS = MODE == 0 ? Q + 1 : 6;
 			unsigned ns = p - kl;
+			// How the h = p - kl steps above the tile are cut into passes: plain passes of up to QS steps first (the top
+			// steps), then ONE two-level pass of Q + 2 .. 2Q steps on the steps right above the tile — whichever cut costs
+			// least by the passes' measured times (2^26 uint32, us per pass: plain 72 + k for k <= 5 steps, 81 for 6;
+			// two-level 77 / 78 / 82 for 7 / 8 / 9 steps and 124 for 10, whose rows are 64 bytes, half a cache line:
+			// profiles/r04_abitonic_strided_by_position.txt). Round 3 took the two-level pass first and as long as it
+			// could be: 11 steps = 10 + 1, 12 = 6 + 6; now 11 = 4 + 7, 12 = 5 + 7.
 			{
-				// a two-level pass (up to 2Q steps) when it saves a pass over plain ones
-				const unsigned h = ns, n2 = h < 2u * Q ? h : 2u * Q;
-				const unsigned plain = (h + QS - 1) / QS, with2 = 1u + (h - n2 + QS - 1) / QS;
-				if (n2 > (unsigned) Q && with2 < plain) {
+				const unsigned h = ns;
+				auto plain_cost = [&](unsigned k) { unsigned c = 0; while (k > 0) { const unsigned t = k > (unsigned) QS ? (k % QS ? k % QS : QS) : k; c += t >= 6 ? 81u : 72u + t; k -= t; } return c; };
+				// (a two-level pass of b2 steps reads rows of 2^(KLF - b2) elements: 77 us and 2 more per halving down to one
+				// cache line, 124 for half a line)
+				auto s2_cost = [&](unsigned b2) { const size_t row = ((size_t) 1 << (KLF - b2)) * sizeof(E); return row >= 128 ? 75u + 2u * (b2 - (unsigned) Q) : (row >= 64 ? 124u : 250u); };
+				unsigned best = plain_cost(h), best_b = 0;
+				for (unsigned b2 = Q + 2; b2 <= 2u * Q && b2 <= h; ++b2) {
+					const unsigned c = plain_cost(h - b2) + s2_cost(b2);
+					if (c < best) { best = c; best_b = b2; }
+				}
+				if (best_b == h) {   // this pass IS the two-level one
 					clo_timing_scope timing("bitonic_strided2", s);
-					hipLaunchKernelGGL((clo_bitonic_strided2_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, p, n2, kd);
+					hipLaunchKernelGGL((clo_bitonic_strided2_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, p, best_b, kd);
 					++count;
-					p -= n2;
+					p -= best_b;
 					continue;
 				}
+				ns = h - best_b;   // plain passes down to where the two-level pass (if any) starts
 			}
-			if (ns > (unsigned) QS) ns = QS;
+			// Several plain passes: the SHORT one first (the order decides the strides they run at; 64 values per thread
+			// 2 MiB apart — stage 25 of 2^26 uint32 as 6 + 5 steps — measured 143 us against 72 .. 86 for every other).
+			if (ns > (unsigned) QS) ns = ns % QS ? ns % QS : QS;
 			switch (ns) {
 				case 1: launch_strided<E, 1, MODE>(data, n, stage, p, kd, s); break;
 				case 2: launch_strided<E, 2, MODE>(data, n, stage, p, kd, s); break;
