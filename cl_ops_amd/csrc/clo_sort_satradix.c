@@ -209,7 +209,7 @@ static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GEr
  *
  * Upstream's path is blocking: copy in, sort, copy out (sort/clo_sort_abstract.c:348-395).
  * A sort's first output element depends on its last input element, so the two copies can
- * never overlap each other; what CAN disappear behind them is the sort:
+ * never overlap each other (docs/lab_notebook.md, "Measurement"); what CAN disappear behind them is the sort:
  *   copy in   the array arrives in SAT_PIPE_CHUNKS chunks on the transfer stream; as soon
  *             as chunk c is there, the exec stream splits it — stably — into 16 buckets by
  *             the top 4 key bits (clo_hip_msd_partition: the sort's own pass kernel), under

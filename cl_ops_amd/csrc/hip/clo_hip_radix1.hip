@@ -633,7 +633,7 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	if ((digit_bits != 4 && digit_bits != 8) || (elem_size != 4 && elem_size != 8) || n >= 0x80000000ull) return 0;
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
-	// The library's choice (measured; profiles/r03_sweep_sizes*.txt, r03_sweep_edge*.txt):
+	// The library's choice (measured, docs/lab_notebook.md; profiles/r03_sweep_sizes*.txt, r03_sweep_edge*.txt):
 	// 4 .. 256 tiles (2^15 .. 2^21 4-byte elements, 2^14 .. 2^20 8-byte ones): the sort is launch-bound and
 	// the sweeps need 6 launches instead of 12: 5-25 % less time (and half the events on a profiling
 	// queue). Above that the chain-free passes are ahead, and no work-group ever waits for another's

@@ -16,7 +16,7 @@
 // no spinning. The histogram and counter-scan kernels are in
 // clo_hip_radixw.hip.
 //
-// History of the pass, all measured on 2^28 uint32 keys, radix 16 (DESIGN.md
+// History of the pass, all measured on 2^28 uint32 keys, radix 16 (docs/lab_notebook.md
 // §4.1 has the numbers): chained look-back passes (latency-bound, 6.4 ms) ->
 // one digit per pass with the next digit's histogram fused into the scatter
 // (match-any ranking 5.3 ms, packed counters 3.94 ms) -> digit pairs with the

@@ -325,7 +325,7 @@ template <typename E> struct sweep_shape {
 // 1024 threads on twice the tile, the table inside the 64 KiB stage (ALIAS), 2
 // work-groups per CU — runs of 256 bytes per digit pair and tile instead of 128 in
 // the scatter, half the counters: pair kernel 0.475 -> 0.443 ms per pass at 2^28
-// uint32, uint64 0.887 -> 0.820.
+// uint32, uint64 0.887 -> 0.820 (docs/lab_notebook.md).
 template <typename E, bool BIG> struct pair_shape {
 	static constexpr int THREADS = (BIG && sizeof(E) >= 4) ? 1024 : 512;
 	static constexpr int ITEMS = sizeof(E) == 8 ? 8 : 16;
@@ -334,10 +334,10 @@ template <typename E, bool BIG> struct pair_shape {
 };
 // (8-byte elements gain from 32 MiB on — their digit stream is an eighth of the
 // array; 2^22 uint64 0.254 -> 0.234 ms, pairs 0.127 -> 0.119, profiles/r03_big_tile_threshold.txt —
-// 4-byte ones from 256 MiB: measured)
+// 4-byte ones from 256 MiB: measured, docs/lab_notebook.md)
 inline size_t clo_big_tile_bytes(int elem_size) { return (size_t) (elem_size == 8 ? 32 : 256) << 20; }
 inline bool clo_radix_big_tiles(size_t n, int elem_size) { return elem_size >= 4 && n * (size_t) elem_size >= clo_big_tile_bytes(elem_size); }
-// The digit stream (one byte per element between two passes, DESIGN.md 4.1) goes with the
+// The digit stream (one byte per element between two passes, DESIGN.md §4.1) goes with the
 // big tiles: on 8 192-element tiles (arrays that sit in the last-level cache) its extra
 // writes cost more than the histogram's shorter read saves (2^25 uint32: 0.471 vs 0.421 ms in round 2;
 // re-measured in round 3 after the counter scan became one launch: 2^22 0.113 vs 0.108, 2^24 0.224 vs 0.222,

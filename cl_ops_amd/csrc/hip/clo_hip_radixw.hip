@@ -210,7 +210,7 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 // reads — toff holds sum_{t' < t} cnt[t'][d] only. The hand-off words (sums, ticket) are zeroed by the histogram
 // kernel that precedes this one on the stream (rw_clear). 2^24 keys 0.240 -> 0.221 ms per sort, 2^25 0.409 ->
 // 0.385, 2^28 2.51 -> 2.46 (profiles/r03_counter_scan_one_launch.txt).
-// Tried and dropped on the way (profiles/r03_hist_chain_probe.txt): the chunk sums chained onto the
+// Tried and dropped on the way (profiles/r03_hist_chain_probe.txt, docs/lab_notebook.md): the chunk sums chained onto the
 // histogram kernel (write-through rows, arrival counters, the last arrival sums: the histogram kernel, bound by
 // its loads in flight, lost 0.07 ms per pass to the arrivals); the chunk scan folded into the offsets kernel
 // with every work-group re-deriving its chunk's start from ALL chunk sums, digit bases included (128 KiB of L2

@@ -371,7 +371,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	}
 }
 
-constexpr unsigned g_scan_xflags = 0;  // (the kernel's experiment switches — non-temporal loads / stores: no difference, DESIGN.md — stay off)
+constexpr unsigned g_scan_xflags = 0;  // (the kernel's experiment switches — non-temporal loads / stores: no difference, docs/lab_notebook.md — stay off)
 unsigned g_scan_max_spins = CLO_MAX_SPINS;   // CLO_MAX_SPINS in the environment overrides (tests force a give-up with it)
 
 // Work-group shape by array size. Every work-group draws a ticket from one

@@ -7,7 +7,7 @@
  * (clo_sort_sbitonic.in.h:36, clo_sort_abitonic.in.h:116, clo_sort_gselect.in.h:36,
  * clo_sort_satradix.in.h:55).
  *
- * Divergences from upstream, all deliberate (DESIGN.md §boundary):
+ * Divergences from upstream, all deliberate (DESIGN.md §1):
  *  - `compare` / `get_key` are OpenCL C macro bodies upstream (JIT). Here they
  *    are parsed into a fixed family: get_key = x, (x) >> N, ((x) >> N) & MASK,
  *    optional casts; compare = ((a) > (b)) or ((a) < (b)) select ahead-of-time
