@@ -120,3 +120,71 @@ def test_fuzz_key_fields(gpu, seed):
         got = s.with_host_data(a, q)
         s.close()
         assert np.array_equal(got, a[np.argsort(key, kind="stable")]), "%s n=%d %s radix=%d" % (et, n, get_key, radix)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_segmented_sort(gpu, seed):
+    """clo_hip_radix_sort_segmented (round 4): random segment counts and lengths (empty ones, one tile, many counter-scan
+    chunks), the source as the segments back to back or as up to 256 pieces scattered over a larger array, key fields at
+    any shift, both digit widths, both element sizes — against a stable numpy sort per segment."""
+    import ctypes as C
+    import torch
+    from cl_ops_amd import _hip
+    from cl_ops_amd._hip import lib
+    rng = np.random.default_rng(4000 + seed)
+    for case in range(10):
+        es = int(rng.choice([4, 8]))
+        dt, tdt = (np.uint32, np.int32) if es == 4 else (np.uint64, np.int64)
+        n = int(rng.choice([1, 37, 8192, 8193, 100000, (1 << 20) + 5, (1 << 22) + 12345]))
+        nseg = int(rng.choice([1, 2, 7, 64, 255, 256]))
+        cuts = np.sort(rng.integers(0, n + 1, nseg - 1)) if nseg > 1 else np.array([], dtype=np.int64)
+        seg_counts = np.diff(np.concatenate(([0], cuts, [n]))).astype(np.int64)
+        shift = int(rng.integers(0, 8 * es - 1))
+        bits = int(rng.integers(1, 8 * es - shift + 1))
+        digit_bits = int(rng.choice([4, 8]))
+        pieces = bool(rng.integers(0, 2)) and nseg <= 64
+        if pieces:          # every segment in up to 4 pieces, scattered over a source three times the size
+            per = 4
+            big = rng.integers(0, np.iinfo(dt).max, 3 * n + 5 * per * nseg + 64, dtype=dt, endpoint=True)
+            pn, ps = [], []
+            for k in range(nseg):
+                c = np.sort(rng.integers(0, seg_counts[k] + 1, per - 1))
+                for x in np.diff(np.concatenate(([0], c, [seg_counts[k]]))):
+                    pn.append(int(x)); ps.append(k)
+            order = rng.permutation(len(pn))                       # where the pieces lie has nothing to do with their order
+            po = np.zeros(len(pn), dtype=np.int64)
+            at = 3
+            for i in order:
+                po[i] = at
+                at += pn[i] + int(rng.integers(0, 5))
+            assert at <= big.size
+            src_np = big
+            gathered = np.concatenate([big[po[i]:po[i] + pn[i]] for i in range(len(pn))]) if n else big[:0]
+        else:
+            src_np = rng.integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+            gathered = src_np
+        src = torch.from_numpy(src_np.view(tdt).copy()).cuda()
+        ta = src if not pieces else torch.zeros(max(n, 1), dtype=src.dtype, device="cuda")
+        tb = torch.zeros(max(n, 1), dtype=src.dtype, device="cuda")
+        need = lib.clo_hip_radix_seg_workspace_bytes(n, nseg, es, digit_bits)
+        ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+        in_b = C.c_int(-1)
+        if pieces:
+            npc = len(pn)
+            extra = ((C.c_size_t * npc)(*pn), (C.c_size_t * npc)(*[int(x) for x in po]), (C.c_int * npc)(*ps), npc)
+        else:
+            extra = (None, None, None, 0)
+        _hip.check(lib.clo_hip_radix_sort_segmented(src.data_ptr(), ta.data_ptr(), tb.data_ptr(), n, (C.c_size_t * nseg)(*[int(x) for x in seg_counts]), nseg,
+                                                    *extra, es, shift, bits, digit_bits, ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream, C.byref(in_b)))
+        torch.cuda.synchronize()
+        got = (tb if in_b.value else ta).cpu().numpy().view(dt)[:n]
+        exp = np.empty_like(gathered)
+        at = 0
+        mask = dt((1 << bits) - 1)
+        for c in seg_counts:
+            seg = gathered[at:at + c]
+            exp[at:at + c] = seg[np.argsort((seg >> dt(shift)) & mask, kind="stable")]
+            at += c
+        assert np.array_equal(got, exp), "seed %d case %d: es %d n %d nseg %d shift %d bits %d digit %d pieces %s" % (seed, case, es, n, nseg, shift, bits, digit_bits, pieces)
+        if pieces:
+            assert np.array_equal(src.cpu().numpy().view(dt), src_np), "the source of a gathered sort changed"
