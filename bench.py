@@ -571,16 +571,23 @@ def main_sharded(args, world, rank, local_rank):
 # one GPU
 # ----------------------------------------------------------------------------
 
-def kernel_sources_sha16():
-    """Content hash of the kernel sources (cl_ops_amd/csrc/hip/*): the GPU box has no .git, so this is how a line
-    says which kernels it ran and whether profiles/traffic_*.json was collected on the same ones."""
-    import glob
+# the kernel sources a workload's launches come from (cl_ops_amd/csrc/hip/)
+KERNEL_SOURCES = {
+    "satradix": ["clo_hip_radix.hip", "clo_hip_radix4.hip", "clo_hip_radixw.hip", "clo_hip_radix1.hip", "clo_hip_radix_rank.h", "clo_hip_internal.h"],
+    "scan": ["clo_hip_scan.hip", "clo_hip_internal.h"],
+    "abitonic": ["clo_hip_bitonic.hip", "clo_hip_bitonic_impl.h", "clo_hip_bitonic_e4.hip", "clo_hip_internal.h"],
+    "sbitonic": ["clo_hip_bitonic.hip", "clo_hip_bitonic_impl.h", "clo_hip_bitonic_e4.hip", "clo_hip_internal.h"],
+}
+
+
+def kernel_sources_sha16(group):
+    """Content hash of the kernel sources of a workload's family: the GPU box has no .git, so this is how a line says
+    which kernels it ran and whether profiles/traffic_*.json was collected on the same ones."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "cl_ops_amd", "csrc", "hip", "*"))):
-        if f.endswith((".hip", ".h")):
-            h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+    for name in KERNEL_SOURCES[group]:
+        h.update(name.encode())
+        h.update(open(os.path.join(ROOT, "cl_ops_amd", "csrc", "hip", name), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -674,7 +681,7 @@ def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=Non
     traffic, tmeta = load_traffic(workload)
     if tmeta and tmeta.get("log2n") not in (None, log2n):
         traffic, tmeta = {}, None                      # measured at another size: not comparable
-    sha_now = kernel_sources_sha16()
+    sha_now = kernel_sources_sha16(group)
     stale = bool(traffic) and (tmeta or {}).get("kernels_sha16") != sha_now
     kernels = []
     for label in FAMILIES[group]:
