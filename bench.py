@@ -683,6 +683,18 @@ def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=Non
         traffic, tmeta = {}, None                      # measured at another size: not comparable
     sha_now = kernel_sources_sha16(group)
     stale = bool(traffic) and (tmeta or {}).get("kernels_sha16") != sha_now
+    # launches per step as the PMC collection saw them (for the live guard below): counted BEFORE the bytes are used —
+    # a stale file whose launches no longer match describes other kernels, and its bytes are not used at all
+    expected = {f: v["launches_per_step"] for f, v in traffic.items() if v.get("launches_per_step")}
+    seen_counts = {}
+    for label in FAMILIES[group]:
+        cnt, _ = _hip.timing_read(label)
+        if cnt:
+            seen_counts[label] = round(cnt / steps, 3)
+    counts_ok = None if not expected else bool(set(expected) == set(seen_counts) and all(abs(seen_counts[f] - expected[f]) < 1e-6 for f in expected))
+    traffic_dropped = bool(stale and counts_ok is False)
+    if traffic_dropped:
+        traffic = {}
     kernels = []
     for label in FAMILIES[group]:
         cnt, tot_ms = _hip.timing_read(label)
@@ -719,22 +731,24 @@ def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=Non
             "launches": int(round(dom["launches_per_step"] * steps)), "avg_launch_ms": dom["avg_launch_ms"],
             "bytes_per_launch": dom["bytes_per_launch"],
             "basis": ("stale PMC" if stale else "PMC traffic") + " (profiles/traffic_%s.json)" % workload if dom["traffic_pmc"] else
-                     "minimum moved bytes (no PMC summary for this size in profiles/)",
+                     ("minimum moved bytes (profiles/traffic_%s.json is stale AND counts other launches per step: not used)" % workload if traffic_dropped
+                      else "minimum moved bytes (no PMC summary for this size in profiles/)"),
         })
     # ---- live guard: what a stale PMC file cannot vouch for is checked against THIS run: the launches a step
     # makes per kernel family against the ones the PMC collection saw, and the kernels' summed durations against
     # the step (a kernel family that appeared, vanished or doubled, or time spent outside the listed kernels) ----
     seen = {k["name"]: k["launches_per_step"] for k in kernels}
-    expected = {f: v["launches_per_step"] for f, v in traffic.items() if v.get("launches_per_step")}
-    counts_ok = None if not expected else bool(set(expected) == set(seen) and all(abs(seen[f] - expected[f]) < 1e-6 for f in expected))
     ratio = kernel_ms / ms_step if ms_step > 0 else 0.0
     tol = 0.05 if ms_step >= 0.5 else (0.1 if ms_step >= 0.1 else 0.5)   # (launch-bound steps: the event pairs themselves are a share of the step)
     guard = {"launches_per_step": seen, "expected_launches_per_step": expected or None, "launch_counts_ok": counts_ok,
              "kernel_ms_per_step": round(kernel_ms, 4), "kernel_ms_over_step_ms": round(ratio, 4), "tolerance": tol,
              "timing_ok": bool(abs(ratio - 1.0) <= tol),
              "kernels_sha16": sha_now, "traffic_kernels_sha16": (tmeta or {}).get("kernels_sha16"),
-             "traffic_source_head": (tmeta or {}).get("source_head"), "traffic_stale": stale if traffic else None}
-    guard["ok"] = bool(guard["timing_ok"] and counts_ok is not False)
+             "traffic_source_head": (tmeta or {}).get("source_head"), "traffic_stale": stale if (traffic or traffic_dropped) else None,
+             "traffic_dropped": traffic_dropped}
+    # a file that claims to describe THESE kernels (same source hash) and counts other launches fails the run; a stale
+    # file is labelled, and dropped when even its launches differ
+    guard["ok"] = bool(guard["timing_ok"] and (counts_ok is not False or stale))
     roof.update({
         "kernels": kernels,
         "kernel_ms_per_step": round(kernel_ms, 4),                # sum over the list: what is left of ms_per_step is launch gaps
@@ -876,7 +890,7 @@ def main_single(args):
         out["configs_wall_s"] = round(time.perf_counter() - t0, 1)
         ok = ok and all(c.get("correct") for c in configs.values())
     print(json.dumps(out), flush=True)
-    if out["live_guard"]["launch_counts_ok"] is False:
+    if out["live_guard"]["launch_counts_ok"] is False and not out["live_guard"]["traffic_stale"]:
         return 1
     return 0 if ok else 1
 
