@@ -239,6 +239,7 @@ static cl_bool clo_sort_satradix_check_status(CloSort* sorter, CCLQueue* cq, GEr
 #ifndef SAT_PIPE_MIN_NUMEL   /* (the sanitizer build of tests/hoststub shrinks it) */
 #define SAT_PIPE_MIN_NUMEL ((size_t) 1 << 24)
 #endif
+#define SAT_PIPE_DEFAULT_BYTES ((size_t) 128 << 20)   /* the default takes the pipeline from this array size on */
 #define SAT_PIPE_CHUNKS 8
 #define SAT_PIPE_BITS 4
 #define SAT_PIPE_BUCKETS (1 << SAT_PIPE_BITS)
@@ -325,7 +326,9 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 	if (numel < SAT_PIPE_MIN_NUMEL || numel > 0xffffffffull) return CL_FALSE;
 	{   /* default: on, unless the caller profiles the exec queue (see above); CLO_SORT_HOST_PIPELINE=0 / 1 decides for both */
 		const int flag = ((clo_sort_satradix_data*) clo_sort_get_data(sorter))->host_pipeline;
-		const int want = flag >= 0 ? flag : !ccl_queue_is_profiling(cq_exec);
+		/* (unset: from 128 MiB on — at 64 MiB, 2^24 uint32, the blocking path is the shorter: 2.96 against 3.20 ms host to
+		 * host, profiles/r04_hostsort_pipeline.txt; at 128 MiB the pipeline wins, 5.54 against 5.74) */
+		const int want = flag >= 0 ? flag : (!ccl_queue_is_profiling(cq_exec) && numel * (size_t) es >= SAT_PIPE_DEFAULT_BYTES);
 		if (!want) return CL_FALSE;
 	}
 	*handled = 1;

@@ -63,9 +63,10 @@ typedef struct clo_sort_impl_def {
  * on it (upstream's do not either). clo_*_get_localmem_usage reports the LDS of the shape
  * that `numel` selects.
  * clo_sort_with_host_data: upstream's blocking path (copy in, sort, copy out), except that
- * satradix on unsigned keys from 2^24 elements on overlaps the sort with both copies (same
- * result bit for bit, 5-25 % less wall time, about twice the device time: clo_sort_satradix.c)
- * unless cq_exec is a profiling queue; CLO_SORT_HOST_PIPELINE=0 / 1 decides for all queues. */
+ * satradix on unsigned keys in arrays of 128 MiB and more overlaps the sort with both copies
+ * (same result bit for bit, 2-10 % less wall time; the exec queue then runs a split pass and
+ * sixteen segmented sorts instead of one sort: clo_sort_satradix.c) unless cq_exec is a profiling
+ * queue; CLO_SORT_HOST_PIPELINE=0 / 1 (read at clo_sort_new) decides for all queues from 2^24 elements. */
 CloSort* clo_sort_new(const char* type, const char* options, CCLContext* ctx,
 	CloType* elem_type, CloType* key_type, const char* compare, const char* get_key,
 	const char* compiler_opts, GError** err);
