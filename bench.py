@@ -827,16 +827,13 @@ def shard_world1_leg(etype, log2n, steps, warmup, radix, seed, slices=0):
     ms_step = wall / steps * 1e3
     ls_bytes = local_sort_bytes(n, es, radix)
     ls_s = phases.get("local_sort", 0.0)
-    return {"value": round(n * steps / wall / 1e6, 1), "unit": "Mkeys/s", "ms_per_step": round(ms_step, 4), "correct": ok,
-            "steps": steps, "warmup": warmup, "dtype": "u32" if es == 4 else "u64",
-            "config": {"workload": "satradix of 2^%d %s keys through clo_shard_sort_with_device_data on ONE rank over RCCL "
-                                   "(loopback: the rank sends every sub-bucket to itself)" % (log2n, "uint32" if es == 4 else "uint64"),
-                       "api": "clo_shard_sort_with_device_data (C API over RCCL)", "radix": radix},
+    return {"workload": "satradix of 2^%d %s keys through clo_shard_sort_with_device_data (C API) on ONE rank over RCCL, loopback=1"
+                        % (log2n, "uint32" if es == 4 else "uint64"),
+            "value": round(n * steps / wall / 1e6, 1), "unit": "Mkeys/s", "ms_per_step": round(ms_step, 4), "correct": ok, "steps": steps,
             "slices": x["slices"], "exchange_device_ms": round(x["ms"], 4),
             "phases_ms": {k: round(v * 1e3, 4) for k, v in sorted(phases.items())},
-            "local_sort_roofline": {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "bytes": ls_bytes,
-                                    "frac": round(ls_bytes / ls_s / HBM_PEAK, 4) if ls_s > 0 else None,
-                                    "basis": "minimum bytes a plain local sort of the same keys moves / the local_sort phase"},
+            # bytes a plain local sort of the same keys must move at least / the local_sort phase; the whole step adds the exchange's copy
+            "local_sort_frac": round(ls_bytes / ls_s / HBM_PEAK, 4) if ls_s > 0 else None,
             "step_frac": round((ls_bytes + 2 * n * es) / (ms_step * 1e-3) / HBM_PEAK, 4)}
 
 
@@ -846,15 +843,17 @@ CONFIG_LEGS = (("1_sbitonic_2p16", "sbitonic", 50, 5), ("2_scan_2p26", "scan", 3
 
 
 def leg_summary(full):
+    """A config leg as it travels in the headline's line: what the verdict asked for (value, ms_per_step, correct,
+    dominant-kernel frac, step_frac, cpu_baseline) and not much more — the line stays a few KB."""
     r = full["roofline"]
-    out = {"value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"], "correct": full["correct"],
-           "steps": full["steps"], "warmup": full["warmup"], "dtype": full["dtype"], "config": full["config"],
-           "kernel": r.get("kernel"), "frac": r.get("frac"), "bound": r.get("bound"), "basis": r.get("basis"),
-           "avg_launch_ms": r.get("avg_launch_ms"), "step_frac": r.get("step_frac"),
-           "kernels": {k["name"]: [k["launches_per_step"], k["avg_launch_ms"]] for k in r.get("kernels", [])},
-           "live_guard_ok": full["live_guard"]["ok"], "kernel_ms_over_step_ms": full["live_guard"]["kernel_ms_over_step_ms"]}
+    basis = r.get("basis") or ""
+    out = {"workload": full["config"]["workload"], "value": full["value"], "unit": full["unit"], "ms_per_step": full["ms_per_step"],
+           "correct": full["correct"], "steps": full["steps"], "kernel": r.get("kernel"), "frac": r.get("frac"), "bound": r.get("bound"),
+           "basis": "stale PMC" if basis.startswith("stale") else ("PMC" if basis.startswith("PMC") else "min bytes"),
+           "step_frac": r.get("step_frac"), "guard_ok": full["live_guard"]["ok"]}
     if "cpu_baseline" in full:
-        out["cpu_baseline"] = full["cpu_baseline"]
+        c = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"]}
     return out
 
 
