@@ -321,6 +321,8 @@ class HipScanOps:
         """dst[:n] = carry + exclusive scan of src[:n]; carry: 1-element int64 device tensor or None."""
         need = self.lib.clo_hip_scan_workspace_bytes(n, self.elem_size, self.sum_size)
         if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None:      # the old range goes back to torch's allocator: the library must stop vouching for it
+                self.lib.clo_hip_scan_workspace_forget(self._ws.data_ptr())
             self._ws = self.torch.empty(need, dtype=self.torch.uint8, device=src.device)
             self._hip.check(self.lib.clo_hip_scan_workspace_init(self._ws.data_ptr(), need, self.stream), "clo_hip_scan_workspace_init")
         self._hip.check(self.lib.clo_hip_scan_exclusive_carry(
