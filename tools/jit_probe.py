@@ -1,3 +1,5 @@
+"""Developer probe (GPU box): abitonic with identity keys (ahead-of-time min / max networks), a partial key (ahead-of-time
+general compare) and two expressions that go through hiprtc. usage: python tools/jit_probe.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
