@@ -398,8 +398,6 @@ def _run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local
         probe_wd = _Watchdog(min(watchdog, 120.0) if watchdog and watchdog > 0 else 0.0, "rank %d, C-driver probe sort of leg %s" % (rank, name))
         try:
             sharded = CShardedSorter(etype, local_rank, options="radix=%d%s" % (radix, ",slices=%d" % slices if slices else ""))
-            if os.environ.get("CLO_BENCH_FAIL_PROBE") == str(rank):      # (tests/test_bench_launch.py: the fallback itself)
-                raise RuntimeError("probe failure injected on rank %d" % rank)
             pn = 1 << 22
             ph = make_input(workload, pn, seed + 977 + rank)
             pt = torch.from_numpy(ph.view(np.int32 if es == 4 else np.int64)).to(be.device)
