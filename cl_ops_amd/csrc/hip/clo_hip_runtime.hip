@@ -174,8 +174,13 @@ void clo_hip_env_refresh(void) {
 	if (const char* m = getenv("CLO_RADIX_SWEEP")) e.radix_sweep = atoi(m) != 0 ? 1 : 0;
 	if (const char* m = getenv("CLO_R1_POOLS")) e.r1_pools = atoi(m);
 	e.no_digits = getenv("CLO_RADIX_NO_DIGITS") != nullptr;
-	g_env = e;
-	g_env_read = 1;
+	// (objects may be created on several threads while others sort: field by field, never a torn struct — the values
+	// only differ from the ones already there when the environment changed between two object creations)
+	__atomic_store_n(&g_env.max_spins, e.max_spins, __ATOMIC_RELAXED);
+	__atomic_store_n(&g_env.radix_sweep, e.radix_sweep, __ATOMIC_RELAXED);
+	__atomic_store_n(&g_env.r1_pools, e.r1_pools, __ATOMIC_RELAXED);
+	__atomic_store_n(&g_env.no_digits, e.no_digits, __ATOMIC_RELAXED);
+	__atomic_store_n(&g_env_read, 1, __ATOMIC_RELEASE);
 }
 int clo_hip_event_synchronize(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }
 int clo_hip_event_query(void* event) { return event ? (int) hipEventQuery((hipEvent_t) event) : CLO_HIP_EARGS; }
