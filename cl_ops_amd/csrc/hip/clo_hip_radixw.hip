@@ -46,9 +46,9 @@ __device__ __forceinline__ void rw_clear(unsigned* __restrict__ clear, unsigned 
 // No thread needs to know more than its own bin: a bin that holds the whole tile says 1, a bin that holds a
 // part of it says 0 (several may, all the same value), an empty bin says nothing — exactly one of the first
 // two kinds exists in every tile, so the word is always written and never needs clearing or a barrier.
-__device__ __forceinline__ void rw_tile_info(unsigned h, unsigned count, unsigned* __restrict__ tinfo) {
-	if (h == count) tinfo[blockIdx.x] = 1u;
-	else if (h != 0u) tinfo[blockIdx.x] = 0u;
+__device__ __forceinline__ void rw_tile_info(unsigned h, unsigned count, unsigned* __restrict__ tinfo, unsigned tile) {
+	if (h == count) tinfo[tile] = 1u;
+	else if (h != 0u) tinfo[tile] = 0u;
 }
 
 // Where a tile of a segmented launch lies (clo_hip_internal.h): one 16-byte load, the same for the whole work-group.
@@ -125,7 +125,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 			h += x[0] + x[1] + x[2] + x[3];
 		}
 		thist[(size_t) blockIdx.x * R + d] = h;
-		rw_tile_info(h, count, tinfo);
+		rw_tile_info(h, count, tinfo, blockIdx.x);
 		rw_clear(clear, clear_words, blockIdx.x * R + d);
 		if constexpr (SEG) rw_clear(clear, clear_words, (gridDim.x + blockIdx.x) * R + d);   // (up to one chunk per tile, and the ticket's row)
 	}
@@ -134,26 +134,41 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 // The same histogram out of the digit bytes the pass before wrote (one byte per
 // element, in the order of the elements; clo_radix4_pair_kernel<..., DIG>): a quarter
 // (uint32) or an eighth (8-byte elements) of the bytes to read.
-template <int BITS, int ITEMS, int THREADS, bool SEG = false>   // ITEMS bytes per thread: 16 (4-byte elements) or 8; THREADS of the tile's shape
+// TPW tiles per work-group, one per THREADS / TPW consecutive threads with counters of their own: a tile of
+// 8-byte elements is 8 192 digit bytes — one 8-byte load per thread of a 1024-thread group left half as many
+// bytes in flight per CU as the 4-byte elements' 16 (150 us per launch against 98 for the same 256 MiB,
+// profiles/r04_satradix_u64_kernel_stats.csv); two such tiles share a group, 16 bytes per thread.
+template <int BITS, int ITEMS, int THREADS, bool SEG = false, int TPW = 1>   // ITEMS bytes per thread; THREADS / TPW * ITEMS = the tile
 __global__ __launch_bounds__(THREADS)
-void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned mask, unsigned* __restrict__ thist,
+void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, size_t n, unsigned tiles, unsigned mask, unsigned* __restrict__ thist,
 	unsigned* __restrict__ tinfo, unsigned* __restrict__ clear, unsigned clear_words, const clo_seg_tile* __restrict__ tdesc = nullptr) {
 	constexpr int R = 1 << BITS;
-	constexpr int TILE = THREADS * ITEMS;
+	constexpr int PART = THREADS / TPW;   // threads of one tile
+	constexpr int TILE = PART * ITEMS;
 	constexpr int COPIES = 32;
-	__shared__ __attribute__((aligned(16))) unsigned s_cnt[R * COPIES];
+	static_assert(PART % 64 == 0 && PART * TPW == THREADS, "whole waves per tile");
+	__shared__ __attribute__((aligned(16))) unsigned s_cnt[TPW * R * COPIES];
 	const unsigned tid = threadIdx.x, lane = tid & 63u;
-	size_t base = (size_t) blockIdx.x * TILE;
-	unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-	if constexpr (SEG) rw_seg_tile(tdesc, base, count, (unsigned) TILE);
+	const unsigned part = tid / PART, ptid = tid % PART;
+	const unsigned t = blockIdx.x * TPW + part;   // this thread's tile (the same for its whole wave)
+	size_t base = (size_t) t * TILE;
+	unsigned count = 0;
+	if (t < tiles) {
+		count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+		if constexpr (SEG) {
+			const clo_seg_tile td = tdesc[t];
+			base = (size_t) td.in_base;
+			count = td.count_seg & 0xffffu;
+		}
+	}
 	{
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
 		const vec4u z = { 0u, 0u, 0u, 0u };
-		for (unsigned i = tid; i < (unsigned) (R * COPIES / 4); i += THREADS) reinterpret_cast<vec4u*>(s_cnt)[i] = z;
+		for (unsigned i = tid; i < (unsigned) (TPW * R * COPIES / 4); i += THREADS) reinterpret_cast<vec4u*>(s_cnt)[i] = z;
 	}
 	__syncthreads();
-	const unsigned tbase = tid * ITEMS;
-	const unsigned cp = lane & (COPIES - 1);
+	const unsigned tbase = ptid * ITEMS;
+	unsigned* const cnt = s_cnt + part * (R * COPIES) + (lane & (COPIES - 1));
 	if (count == (unsigned) TILE) {
 		typedef unsigned vecA __attribute__((ext_vector_type(ITEMS / 4)));   // (the stream starts 256-byte aligned, a tile is a multiple of 16 bytes)
 		typedef unsigned vecU __attribute__((ext_vector_type(ITEMS / 4), aligned(1)));   // (a segment starts at any byte of it)
@@ -163,27 +178,32 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 		for (int k = 0; k < ITEMS / 4; ++k) {
 			#pragma unroll
 			for (int b = 0; b < 4; ++b)
-				atomicAdd(&s_cnt[((((unsigned) v[k] >> (8 * b)) & mask) << 5) + cp], 1u);
+				atomicAdd(&cnt[(((unsigned) v[k] >> (8 * b)) & mask) << 5], 1u);
 		}
 	} else {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
-			if (tbase + i < count) atomicAdd(&s_cnt[(((unsigned) dig[base + tbase + i] & mask) << 5) + cp], 1u);
+			if (tbase + i < count) atomicAdd(&cnt[((unsigned) dig[base + tbase + i] & mask) << 5], 1u);
 	}
 	__syncthreads();
-	for (unsigned d = tid; d < (unsigned) R; d += THREADS) {
+	for (unsigned i = tid; i < (unsigned) (TPW * R); i += THREADS) {
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
-		const vec4u* row = reinterpret_cast<const vec4u*>(&s_cnt[d * COPIES]);
+		const unsigned row_part = i / R, d = i % R, rt = blockIdx.x * TPW + row_part;
+		if (rt >= tiles) break;
+		const vec4u* row = reinterpret_cast<const vec4u*>(&s_cnt[row_part * (R * COPIES) + d * COPIES]);
 		unsigned h = 0;
 		#pragma unroll
 		for (int k = 0; k < COPIES / 4; ++k) {
 			const vec4u x = row[(k + d) & (COPIES / 4 - 1)];
 			h += x[0] + x[1] + x[2] + x[3];
 		}
-		thist[(size_t) blockIdx.x * R + d] = h;
-		rw_tile_info(h, count, tinfo);
-		rw_clear(clear, clear_words, blockIdx.x * R + d);
-		if constexpr (SEG) rw_clear(clear, clear_words, (gridDim.x + blockIdx.x) * R + d);
+		unsigned rcount;   // (the row's tile, which may be another part's)
+		if constexpr (SEG) rcount = tdesc[rt].count_seg & 0xffffu;
+		else { const size_t rb = (size_t) rt * TILE; rcount = (n - rb) < (size_t) TILE ? (unsigned) (n - rb) : (unsigned) TILE; }
+		thist[(size_t) rt * R + d] = h;
+		rw_tile_info(h, rcount, tinfo, rt);
+		rw_clear(clear, clear_words, rt * R + d);
+		if constexpr (SEG) rw_clear(clear, clear_words, (tiles + rt) * R + d);
 	}
 }
 
@@ -234,7 +254,7 @@ void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned t
 	unsigned* __restrict__ partial, unsigned* __restrict__ toff, const clo_seg_chunk* __restrict__ cdesc = nullptr) {
 	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
 	constexpr int GA = RW_CS_THREADS / R;   // thread groups of the look-back (all threads)
-	constexpr int LB = 8;                   // published rows a thread asks for at once
+	constexpr int LB = 8;                   // published rows a thread asks for at once (16: the same times; 32: twice as long — registers)
 	__shared__ unsigned s_p[G * R], s_lb[GA * R], s_w[4], s_c;
 	const unsigned tid = threadIdx.x, d = tid % R, g = tid / R, lane = tid & 63u, wave = tid >> 6;
 	if (tid == 0) s_c = __hip_atomic_fetch_add(&partial[(size_t) chunks * R], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -495,10 +515,10 @@ int clo_radixw_launch_tilehist_bytes_seg(const unsigned char* dig, const clo_seg
 	unsigned* thist, unsigned* tinfo, unsigned* partial, bool big, hipStream_t s) {
 	const unsigned clear_words = (sg.nchunks + 1u) << bits;
 	if (bits != 8 || !big) return CLO_HIP_EUNSUPPORTED;
-	if (elem_size == 8) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<8, 8, 1024, true>), dim3(sg.ntiles), dim3(1024), 0, s,
-		dig, (size_t) 0, mask, thist, tinfo, partial, clear_words, sg.tiles);
+	if (elem_size == 8) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<8, 16, 1024, true, 2>), dim3((sg.ntiles + 1u) / 2u), dim3(1024), 0, s,
+		dig, (size_t) 0, sg.ntiles, mask, thist, tinfo, partial, clear_words, sg.tiles);
 	else if (elem_size == 4) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<8, 16, 1024, true>), dim3(sg.ntiles), dim3(1024), 0, s,
-		dig, (size_t) 0, mask, thist, tinfo, partial, clear_words, sg.tiles);
+		dig, (size_t) 0, sg.ntiles, mask, thist, tinfo, partial, clear_words, sg.tiles);
 	else return CLO_HIP_EUNSUPPORTED;
 	return (int) hipGetLastError();
 }
@@ -553,10 +573,10 @@ int clo_radixw_launch_tilehist(const void* in, size_t n, int elem_size, int bits
 int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int elem_size, int bits, unsigned mask,
 	unsigned* thist, unsigned* tinfo, unsigned* partial, unsigned tiles, bool big, hipStream_t s) {
 	const unsigned clear_words = partial ? clo_radixw_clear_words(bits, tiles) : 0u;
-	#define CLO_RW_THB1(B, I, T) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T>), dim3(tiles), dim3(T), 0, s, dig, n, mask, thist, tinfo, partial, clear_words)
+	#define CLO_RW_THB1(B, I, T, W) hipLaunchKernelGGL((clo_radixw_tilehist_bytes_kernel<B, I, T, false, W>), dim3((tiles + W - 1u) / W), dim3(T), 0, s, dig, n, tiles, mask, thist, tinfo, partial, clear_words)
 	#define CLO_RW_THB(B) case B: \
 		if (!big) return CLO_HIP_EUNSUPPORTED;   /* (the stream goes with the big tiles) */ \
-		if (elem_size == 8) CLO_RW_THB1(B, 8, 1024); else CLO_RW_THB1(B, 16, 1024); \
+		if (elem_size == 8) CLO_RW_THB1(B, 16, 1024, 2u); else CLO_RW_THB1(B, 16, 1024, 1u); \
 		break
 	if (elem_size != 4 && elem_size != 8) return CLO_HIP_EUNSUPPORTED;
 	switch (bits) {
