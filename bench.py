@@ -683,7 +683,9 @@ def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=Non
     stale = bool(traffic) and (tmeta or {}).get("kernels_sha16") != sha_now
     # launches per step as the PMC collection saw them (for the live guard below): counted BEFORE the bytes are used —
     # a stale file whose launches no longer match describes other kernels, and its bytes are not used at all
-    expected = {f: v["launches_per_step"] for f, v in traffic.items() if v.get("launches_per_step")}
+    # (a run with CLO_RADIX_SWEEP=1 forces the other path: its launches are the ones the forced collection saw)
+    lkey = "sweep_launches_per_step" if os.environ.get("CLO_RADIX_SWEEP") == "1" else "launches_per_step"
+    expected = {f: v[lkey] for f, v in traffic.items() if v.get(lkey)}
     seen_counts = {}
     for label in FAMILIES[group]:
         cnt, _ = _hip.timing_read(label)

@@ -62,8 +62,8 @@ got = (tb if in_b.value else ta).cpu().numpy().view(dt)
 exp = np.empty_like(a)
 at = 0
 for c in seg_counts:                      # every segment on its own, stably, by the low kb bits
-    seg = a[at:at + c]
-    exp[at:at + c] = seg[np.argsort(seg & dt((1 << kb) - 1), kind="stable")]
+    part = a[at:at + c]
+    exp[at:at + c] = part[np.argsort(part & dt((1 << kb) - 1), kind="stable")]
     at += c
 print("2^%d %s, %d segments, %d key bits: segmented sort %.3f ms%s" % (logn, etype, nseg, kb, tot / 10, "" if np.array_equal(got, exp) else "  WRONG"))
 lib.clo_hip_timing_reset()

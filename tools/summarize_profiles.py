@@ -222,4 +222,11 @@ for workload in ("satradix_u32", "satradix_pairs", "satradix_u64", "scan", "abit
     for k in (b.get("roofline") or {}).get("kernels", []):
         if k["name"] in d["families"]:
             d["families"][k["name"]]["launches_per_step"] = k["launches_per_step"]
+    sj = os.path.join(src, "pmc_FETCH_SIZE_%s_sweep.json" % workload)   # the forced single-sweep path, where it was collected
+    if os.path.exists(sj):
+        lines = [l for l in open(sj).read().splitlines() if l.startswith("{")]
+        if lines:
+            for k in (json.loads(lines[-1]).get("roofline") or {}).get("kernels", []):
+                if k["name"] in d["families"]:
+                    d["families"][k["name"]]["sweep_launches_per_step"] = k["launches_per_step"]
     json.dump(d, open(tj, "w"), indent=1)
