@@ -668,7 +668,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 				return NULL;
 			}
 			evt = e;
-			in_b = b;
+			if (slice_n[j] > 0 || j == 0) in_b = b;   /* (the same for every slice: it follows from the key bits — an empty slice must not have the last word) */
 		}
 		out_buf = in_b ? ss->result : ss->recv;
 	}

@@ -574,6 +574,8 @@ static CCLEvent* clo_sort_satradix_sort_segments(CloSort* sorter, CCLQueue* cq_e
 			if (per_kernel) clo_kernel_events_remove(&ke, NULL); else ccl_queue_abort_command(cq_exec, evt);
 			return NULL;
 		}
+	} else {
+		*result_in_b = ((key_bits + 7) / 8) % 2;   /* (include/clo_hip.h: where a sort of these key bits ends; an empty one says the same as its neighbours) */
 	}
 	if (per_kernel) {
 		GError* e2 = NULL;

@@ -211,6 +211,11 @@ static void test_shard(int world, int es, size_t n_per_rank, const char* options
 			uint64_t v = rnd();
 			if (skew == 1 && (i % 3) == 0) v |= 1ull << 63;                 /* uneven buckets */
 			if (skew == 2 || fail_stage == 2) v |= 7ull << 61;               /* every key into the last rank's bucket: it must grow */
+			if (skew == 3) {                                                  /* every key in the lowest quarter of its rank's range: of four slices only the first carries keys */
+				int bits = 0;
+				while ((1 << bits) < world) ++bits;
+				v &= ~(3ull << (62 - bits));
+			}
 			if (es == 4) ((uint32_t*) a->in)[i] = (uint32_t) (v >> 32); else ((uint64_t*) a->in)[i] = v;
 		}
 		total += a->n;
@@ -257,6 +262,8 @@ int main(int argc, char** argv) {
 	test_shard(4, 4, n, "slices=8", 1, 0, 2);
 	test_shard(8, 8, n, NULL, 0, 0, 3);
 	test_shard(8, 4, n, "slices=4", 2, 0, 2);     /* one bucket far fuller than the capacity: every rank grows or agrees */
+	test_shard(2, 4, n, "slices=4", 3, 0, 2);     /* empty slices (the last ones): the result's buffer does not depend on them */
+	test_shard(1, 8, n * 2, "loopback=1,slices=4", 3, 0, 1);
 	test_shard(4, 4, n, "radix=4", 0, 0, 2);      /* a radix without segmented sorts: one exchange, plain sort */
 	test_shard(2, 4, 50, NULL, 0, 0, 2);          /* tiny: one exchange */
 	test_shard(4, 8, n, NULL, 0, 1, 1);           /* a rank with bad arguments: all fail, then all sort */

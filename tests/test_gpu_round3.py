@@ -366,6 +366,30 @@ def test_c_shard_sort_slices_over_real_rccl_world_one(gpu, monkeypatch, etype, o
     s.close()
 
 
+@pytest.mark.parametrize("etype", ["uint", "ulong"])
+@pytest.mark.parametrize("where", ["low", "high", "middle"])
+def test_c_shard_sort_slices_without_keys(gpu, etype, where):
+    """Keys that leave whole slices EMPTY — every key in the lowest, the highest or one middle quarter of the key
+    space, so that one of the four slices carries everything: an empty slice has no sort of its own, and which of the
+    two buffers holds the result must not depend on it (an empty LAST slice used to name the wrong buffer)."""
+    import torch
+    from cl_ops_amd.multigpu import CShardedSorter
+    dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
+    bits = 8 * np.dtype(dt).itemsize
+    n = (1 << 23) + 77
+    a = np.random.default_rng(23).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True) >> dt(2)
+    a |= dt({"low": 0, "middle": 2, "high": 3}[where]) << dt(bits - 2)
+    t = torch.from_numpy(a.view(tdt).copy()).cuda()
+    s = CShardedSorter(etype, 0, options="slices=4,loopback=1")
+    for rep in range(2):
+        out, m = s.sort(t)
+        s.check()
+        torch.cuda.synchronize()
+        assert m == n and np.array_equal(out.cpu().numpy().view(dt), np.sort(a))
+        assert s.ss.exchange()["slices"] == 4
+    s.close()
+
+
 @pytest.mark.parametrize("options,slices", [(None, 4), ("slices=8", 8)])
 def test_c_shard_sort_four_ranks_on_one_gpu(gpu, tmp_path, options, slices):
     """Four ranks (2 bucket bits + 2 or 3 slice bits: the partition's two-split form, 4 and 5 bits) on the
