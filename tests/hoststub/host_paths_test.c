@@ -192,6 +192,21 @@ static void* rank_main(void* p) {
 	return NULL;
 }
 
+/* fuzz (skew >= 10): the distribution's parameters and the ranks' sizes, drawn by fuzz_shard */
+static uint64_t fz_and, fz_or, fz_lo, fz_span, fz_values[16];
+static int fz_nvalues;
+static size_t fz_n[8];
+static uint64_t fuzz_key(int mode, size_t i) {
+	switch (mode) {
+		case 10: return rnd();                                            /* uniform */
+		case 11: return (rnd() & fz_and) | fz_or;                         /* some bits fixed: whole buckets, sub-buckets and slices stay empty */
+		case 12: return fz_values[rnd() % (uint64_t) fz_nvalues];         /* a handful of values */
+		case 13: return fz_lo + (fz_span ? rnd() % fz_span : 0);          /* one range of the key space */
+		case 14: return fz_lo + (uint64_t) i * (fz_span / 20000 + 1);     /* ascending */
+		default: return fz_or;                                            /* all equal */
+	}
+}
+
 static void test_shard(int world, int es, size_t n_per_rank, const char* options, int skew, int fail_stage, int calls) {
 	fabric f;
 	memset(&f, 0, sizeof(f));
@@ -205,10 +220,10 @@ static void test_shard(int world, int es, size_t n_per_rank, const char* options
 		memset(a, 0, sizeof(*a));
 		a->f = &f; a->rank = r; a->es = es; a->options = options; a->calls = calls;
 		a->fail_stage = fail_stage; a->fail_rank = world - 1;
-		a->n = n_per_rank + (size_t) r * 37;
+		a->n = skew >= 10 ? fz_n[r] : n_per_rank + (size_t) r * 37;
 		a->in = malloc((a->n + 1000) * (size_t) es);
 		for (size_t i = 0; i < a->n; ++i) {
-			uint64_t v = rnd();
+			uint64_t v = skew >= 10 ? fuzz_key(skew, i) : rnd();
 			if (skew == 1 && (i % 3) == 0) v |= 1ull << 63;                 /* uneven buckets */
 			if (skew == 2 || fail_stage == 2) v |= 7ull << 61;               /* every key into the last rank's bucket: it must grow */
 			if (skew == 3) {                                                  /* every key in the lowest quarter of its rank's range: of four slices only the first carries keys */
@@ -243,8 +258,35 @@ static void test_shard(int world, int es, size_t n_per_rank, const char* options
 	pthread_barrier_destroy(&f.bar);
 }
 
+/* Random worlds, sizes (empty ranks included), options and key distributions through the whole protocol. */
+static int fuzz_shard(int cases, uint64_t seed) {
+	static const char* const opts[] = { NULL, "slices=1", "slices=2", "slices=4", "slices=8", "radix=256", "radix=256,slices=4", "radix=4", "slices=auto" };
+	rng_state = seed * 0x9e3779b97f4a7c15ull + 88172645463325252ull;
+	for (int c = 0; c < cases; ++c) {
+		const int world = 1 << (int) (rnd() % 4), es = (rnd() & 1) ? 4 : 8, mode = 10 + (int) (rnd() % 6);
+		const char* o = opts[rnd() % (sizeof(opts) / sizeof(opts[0]))];
+		char options[64];
+		snprintf(options, sizeof(options), "%s%s%s", o ? o : "", (o && world == 1) ? "," : "", world == 1 ? "loopback=1" : "");
+		for (int r = 0; r < world; ++r) fz_n[r] = (rnd() % 5 == 0) ? 0 : (size_t) (rnd() % 14000);
+		fz_and = rnd() | rnd(); fz_or = rnd() & rnd() & rnd();
+		fz_nvalues = 1 + (int) (rnd() % 16);
+		for (int k = 0; k < 16; ++k) fz_values[k] = rnd();
+		fz_lo = rnd(); fz_span = (rnd() >> (rnd() % 60)) ; if (fz_lo + fz_span < fz_lo) fz_span = ~fz_lo;
+		const int before = failures;
+		test_shard(world, es, 0, options[0] ? options : NULL, mode, 0, 1 + (int) (rnd() % 3));
+		if (failures != before) fprintf(stderr, "   (fuzz case %d of seed %llu: world %d, %d-byte keys, mode %d, options '%s', sizes %zu %zu %zu %zu ...)\n",
+			c, (unsigned long long) seed, world, es, mode, options, fz_n[0], fz_n[1], fz_n[2], fz_n[3]);
+	}
+	return failures;
+}
+
 int main(int argc, char** argv) {
 	const int quick = argc > 1 && strcmp(argv[1], "quick") == 0;
+	if (argc > 1 && strcmp(argv[1], "fuzz") == 0) {
+		const int bad = fuzz_shard(argc > 2 ? atoi(argv[2]) : 100, argc > 3 ? strtoull(argv[3], NULL, 10) : 1);
+		if (bad) fprintf(stderr, "%d check(s) failed\n", bad); else printf("shard fuzz ok\n");
+		return bad ? 1 : 0;
+	}
 	GError* err = NULL;
 	CCLContext* ctx = ccl_context_new_from_device_index(0, &err);
 	if (!ctx) { report(&err, "ccl_context_new_from_device_index"); return 2; }

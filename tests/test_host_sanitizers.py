@@ -37,6 +37,13 @@ def test_host_paths_under_sanitizers(tmp_path, name, flags, needles):
     assert r.returncode == 0 and "host paths ok" in r.stdout, out[-4000:]
     for n in needles:
         assert n not in out, out[-4000:]
+    # the sharded sort's fuzz: random worlds (1 .. 8 ranks, empty ranks included), options and key distributions — fixed
+    # bits, a handful of values, one range, ascending, all equal: whole buckets, sub-buckets and slices stay empty
+    r = subprocess.run([exe, "fuzz", "150", "7"], capture_output=True, text=True, timeout=900, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "shard fuzz ok" in r.stdout, out[-4000:]
+    for n in needles:
+        assert n not in out, out[-4000:]
 
 
 def test_the_stub_is_not_in_the_product():
