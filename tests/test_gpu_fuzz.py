@@ -188,3 +188,45 @@ def test_fuzz_segmented_sort(gpu, seed):
         assert np.array_equal(got, exp), "seed %d case %d: es %d n %d nseg %d shift %d bits %d digit %d pieces %s" % (seed, case, es, n, nseg, shift, bits, digit_bits, pieces)
         if pieces:
             assert np.array_equal(src.cpu().numpy().view(dt), src_np), "the source of a gathered sort changed"
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_sharded_sort_loopback(gpu, seed):
+    """The sharded C path on one rank over real RCCL (`loopback=1`): random slice counts and key distributions that
+    leave sub-buckets and whole slices EMPTY or put everything into one (fixed bits, a handful of values, one range of
+    the key space, ascending keys, all equal), sizes on both sides of the slicing threshold — against numpy's sort.
+    The same object sorts several inputs in a row (buffers, events and the adaptive table are reused)."""
+    import torch
+    from cl_ops_amd.multigpu import CShardedSorter
+    rng = np.random.default_rng(5000 + seed)
+    for etype in ("uint", "ulong"):
+        dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
+        top = int(np.iinfo(dt).max)
+        opt = [None, "slices=1", "slices=2", "slices=4", "slices=8", "radix=256,slices=4"][int(rng.integers(0, 6))]
+        s = CShardedSorter(etype, 0, options=(opt + "," if opt else "") + "loopback=1")
+        for case in range(6):
+            n = int(rng.choice([0, 1, 70000, (1 << 22) - 3, (1 << 22) + 4099, (1 << 23) + 17]))
+            mode = int(rng.integers(0, 6))
+            if mode == 0:
+                a = rng.integers(0, top, n, dtype=dt, endpoint=True)
+            elif mode == 1:     # some bits fixed
+                a = (rng.integers(0, top, n, dtype=dt, endpoint=True) & dt(rng.integers(0, top, dtype=dt, endpoint=True) | rng.integers(0, top, dtype=dt, endpoint=True))) \
+                    | dt(rng.integers(0, top, dtype=dt, endpoint=True) & rng.integers(0, top, dtype=dt, endpoint=True) & rng.integers(0, top, dtype=dt, endpoint=True))
+            elif mode == 2:     # a handful of values
+                vals = rng.integers(0, top, int(rng.integers(1, 17)), dtype=dt, endpoint=True)
+                a = vals[rng.integers(0, vals.size, n)]
+            elif mode == 3:     # one range of the key space
+                lo = int(rng.integers(0, top, dtype=dt, endpoint=True))
+                span = min(top - lo, top >> int(rng.integers(0, 8 * np.dtype(dt).itemsize - 4)))
+                a = (dt(lo) + rng.integers(0, span, n, dtype=dt, endpoint=True)).astype(dt)
+            elif mode == 4:     # ascending
+                a = (np.arange(n, dtype=np.uint64) * np.uint64(max(1, (top // max(n, 1)) >> int(rng.integers(0, 8))))).astype(dt)
+            else:               # all equal
+                a = np.full(n, rng.integers(0, top, dtype=dt, endpoint=True), dtype=dt)
+            t = torch.from_numpy(np.ascontiguousarray(a).view(tdt).copy()).cuda() if n else torch.empty(0, dtype=torch.int32 if etype == "uint" else torch.int64, device="cuda")
+            out, m = s.sort(t)
+            s.check()
+            torch.cuda.synchronize()
+            assert m == n, (etype, opt, mode, n)
+            assert np.array_equal(out.cpu().numpy().view(dt)[:n], np.sort(a)), (etype, opt, mode, n)
+        s.close()
