@@ -32,8 +32,12 @@ static void report(GError** err, const char* what) {
 	if (err && *err) { fprintf(stderr, "%s: %s\n", what, (*err)->message); clo_gerror_free(*err); *err = NULL; }
 }
 
+static uint64_t fuzz_key(int mode, size_t i);
+
 /* ---- 1. pipelined host sort ---- */
-static void test_host_sort(CCLContext* ctx, const char* type_name, size_t n, int pairs) {
+static void test_host_sort_mode(CCLContext* ctx, const char* type_name, size_t n, int pairs, int mode);
+static void test_host_sort(CCLContext* ctx, const char* type_name, size_t n, int pairs) { test_host_sort_mode(ctx, type_name, n, pairs, 0); }
+static void test_host_sort_mode(CCLContext* ctx, const char* type_name, size_t n, int pairs, int mode) {
 	GError* err = NULL;
 	CloType et = clo_type_by_name(type_name, &err), kt = CLO_UINT;
 	const size_t es = clo_type_sizeof(et);
@@ -46,7 +50,13 @@ static void test_host_sort(CCLContext* ctx, const char* type_name, size_t n, int
 	void* out = malloc(n * es);
 	void* ref = malloc(n * es);
 	for (size_t i = 0; i < n; ++i) {
-		if (es == 4) ((uint32_t*) in)[i] = (uint32_t) rnd();
+		if (mode >= 10) {   /* fuzz: the key from the drawn distribution; pairs carry the index as the value */
+			const uint64_t v = fuzz_key(mode, i);
+			if (es == 4) ((uint32_t*) in)[i] = (uint32_t) (v >> 32);
+			else if (pairs) ((uint64_t*) in)[i] = (v & 0xffffffff00000000ull) | (uint64_t) i;
+			else ((uint64_t*) in)[i] = v;
+		}
+		else if (es == 4) ((uint32_t*) in)[i] = (uint32_t) rnd();
 		else if (pairs) ((uint64_t*) in)[i] = ((rnd() % 1000) << 52) | i;   /* few keys: equal keys keep their order (the value = the index) */
 		else ((uint64_t*) in)[i] = rnd();
 	}
@@ -274,6 +284,13 @@ static int fuzz_shard(int cases, uint64_t seed) {
 		fz_lo = rnd(); fz_span = (rnd() >> (rnd() % 60)) ; if (fz_lo + fz_span < fz_lo) fz_span = ~fz_lo;
 		const int before = failures;
 		test_shard(world, es, 0, options[0] ? options : NULL, mode, 0, 1 + (int) (rnd() % 3));
+		if (c % 4 == 0) {   /* the pipelined host sort on the same kind of keys (sizes above the build's threshold, below 2^32 / 4096) */
+			GError* err = NULL;
+			CCLContext* ctx = ccl_context_new_from_device_index(0, &err);
+			const int kind = (int) (rnd() % 3);
+			test_host_sort_mode(ctx, kind == 0 ? "uint" : "ulong", 4096 + (size_t) (rnd() % 150000), kind == 2, mode);
+			ccl_context_destroy(ctx);
+		}
 		if (failures != before) fprintf(stderr, "   (fuzz case %d of seed %llu: world %d, %d-byte keys, mode %d, options '%s', sizes %zu %zu %zu %zu ...)\n",
 			c, (unsigned long long) seed, world, es, mode, options, fz_n[0], fz_n[1], fz_n[2], fz_n[3]);
 	}
