@@ -420,11 +420,12 @@ def test_c_shard_ranks_fail_together(gpu, tmp_path, fail):
 # ----------------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind,n", [("uint", (1 << 24) + 12345), ("ulong", 1 << 24), ("pairs", (1 << 24) + 7), ("uint", 1 << 25),
-                                    ("ulong", (1 << 25) + 13)])   # (the last chunk is of the other tile shape than the full ones)
+                                    ("ulong", (1 << 25) + 13),    # (the last chunk is of the other tile shape than the full ones)
+                                    ("narrow", (1 << 24) + 5)])   # (every key in ONE of the 256 sub-buckets)
 @pytest.mark.parametrize("two_queues", [False, True])
 def test_sort_host_data_pipelined_equals_blocking(gpu, monkeypatch, kind, n, two_queues):
-    """With CLO_SORT_HOST_PIPELINE=1 satradix's host-data path splits every chunk by the top 4 key bits
-    as it arrives and sorts / copies out bucket by bucket; the result is upstream's blocking path's
+    """With CLO_SORT_HOST_PIPELINE=1 satradix's host-data path splits every chunk by the top 8 key bits
+    as it arrives and sorts / copies out bucket by bucket (16 buckets of 16 sub-buckets, one segmented sort each); the result is upstream's blocking path's
     (sort/clo_sort_abstract.c:348-395) bit for bit, also for key/value pairs (stable)."""
     import cl_ops_amd as clo
     ctx, q = gpu
@@ -436,6 +437,9 @@ def test_sort_host_data_pipelined_equals_blocking(gpu, monkeypatch, kind, n, two
     elif kind == "ulong":
         a = rng.integers(0, np.iinfo(np.uint64).max, n, dtype=np.uint64, endpoint=True)
         make = lambda: clo.Sorter("satradix", ctx, "ulong")        # noqa: E731
+    elif kind == "narrow":
+        a = (rng.integers(0, 1 << 20, n, dtype=np.uint32) | np.uint32(0x5a000000))
+        make = lambda: clo.Sorter("satradix", ctx, "uint")         # noqa: E731
     else:   # few distinct keys: equal keys must keep their input order
         a = (rng.integers(0, 1000, n, dtype=np.uint64) << np.uint64(32 + 20)) | np.arange(n, dtype=np.uint64)
         make = lambda: clo.Sorter("satradix", ctx, "ulong", key_type="uint", get_key="(uint) ((x) >> 32)")   # noqa: E731
