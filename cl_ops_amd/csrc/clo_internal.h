@@ -25,15 +25,18 @@
 
 /* CLO_DEBUG=1 in the environment turns on the g_debug-style trace upstream
  * emits under log domain "cl_ops" (e.g. clo_sort_satradix.c:171,192). */
-int clo_debug_enabled(void);
+/* Helpers shared by the host drivers: not part of the library's interface (the headers under include/ are), so not exported either. */
+#define CLO_INTERNAL __attribute__((visibility("hidden")))
+
+CLO_INTERNAL int clo_debug_enabled(void);
 #define clo_debug(...) do { if (clo_debug_enabled()) { fprintf(stderr, "cl_ops-DEBUG: " __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
 /* Environment switches of the host drivers: read when an object is made, never per call. CLO_NO_WARMUP (no
  * dummy sorts / scans at the first object of a kind), and the 0 / 1 switches CLO_SORT_HOST_PIPELINE (satradix's
  * clo_sort_with_host_data: pipelined or blocking whatever the queue) and CLO_SBITONIC_STEPS (sbitonic with one
  * launch per step). */
-int clo_env_no_warmup(void);
-int clo_env_flag(const char* name);
+CLO_INTERNAL int clo_env_no_warmup(void);
+CLO_INTERNAL int clo_env_flag(const char* name);
 
 /* A grow-only device allocation cached inside a sorter/scanner object, so the
  * hot path never calls hipMalloc after the first use (upstream allocates and
@@ -44,8 +47,8 @@ typedef struct {
 } clo_devbuf;
 
 /* Returns 0 or a clo_hip status. Contents are NOT preserved when it grows. */
-int clo_devbuf_reserve(clo_devbuf* b, size_t bytes);
-void clo_devbuf_release(clo_devbuf* b);
+CLO_INTERNAL int clo_devbuf_reserve(clo_devbuf* b, size_t bytes);
+CLO_INTERNAL void clo_devbuf_release(clo_devbuf* b);
 
 /* Buffers cached in a sorter / scanner belong to one queue at a time. When a
  * call arrives on another queue than the previous one, its work must come after
@@ -62,8 +65,8 @@ typedef struct {
 	CCLQueue* cq;    /* the queue of the last call (held), or NULL */
 	void* evt;       /* created the first time two live queues alternate */
 } clo_stream_guard;
-int clo_stream_guard_enter(clo_stream_guard* g, CCLQueue* cq);   /* before the call's first enqueue; 0 or a clo_hip status */
-void clo_stream_guard_release(clo_stream_guard* g);
+CLO_INTERNAL int clo_stream_guard_enter(clo_stream_guard* g, CCLQueue* cq);   /* before the call's first enqueue; 0 or a clo_hip status */
+CLO_INTERNAL void clo_stream_guard_release(clo_stream_guard* g);
 
 /* A launch sequence that depends only on its arguments (buffers, size,
  * stream), cached as an executable hipGraph: the FIRST call with a given key
@@ -81,9 +84,9 @@ typedef struct {
 	int variant, seen;
 } clo_graph_cache;
 typedef int (*clo_enqueue_fn)(void* user, void* stream);
-int clo_graph_cache_run(clo_graph_cache* gc, int allowed, const void* k0, const void* k1, size_t n, int variant,
+CLO_INTERNAL int clo_graph_cache_run(clo_graph_cache* gc, int allowed, const void* k0, const void* k1, size_t n, int variant,
 	void* stream, clo_enqueue_fn enqueue, void* user);
-void clo_graph_cache_release(clo_graph_cache* gc);
+CLO_INTERNAL void clo_graph_cache_release(clo_graph_cache* gc);
 
 /* Extensions of a scan implementation that are NOT part of the public
  * CloScanImplDef (whose layout is upstream's, clo_scan_abstract.in.h:41-103: a
@@ -103,8 +106,8 @@ typedef struct {
 		const void* carry_in_dev, void* carry_out_dev, GError** err);
 	cl_bool (*check_status)(struct clo_scan* scanner, CCLQueue* cq, GError** err);
 } clo_scan_impl_ext;
-const clo_scan_impl_ext* clo_scan_impl_ext_find(const char* name);
-extern const clo_scan_impl_ext clo_scan_blelloch_ext;
+CLO_INTERNAL const clo_scan_impl_ext* clo_scan_impl_ext_find(const char* name);
+CLO_INTERNAL extern const clo_scan_impl_ext clo_scan_blelloch_ext;
 
 /* The same for sort implementations (CloSortImplDef keeps upstream's layout,
  * clo_sort_abstract.in.h:43-110).
@@ -137,8 +140,8 @@ typedef struct {
 		int key_shift, int key_bits, int* result_in_b, int* handled, GError** err);
 	cl_bool (*reserve_segments)(struct clo_sort* sorter, CCLQueue* cq_exec, size_t numel, int nseg, int* handled, GError** err);
 } clo_sort_impl_ext;
-const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name);
-extern const clo_sort_impl_ext clo_sort_satradix_ext;
+CLO_INTERNAL const clo_sort_impl_ext* clo_sort_impl_ext_find(const char* name);
+CLO_INTERNAL extern const clo_sort_impl_ext clo_sort_satradix_ext;
 
 /* Per-kernel events on a profiling queue. Upstream enqueues every kernel itself
  * and names its event (clo_sort_satradix.c:282,295,312; clo_scan_blelloch.c:158,
@@ -158,13 +161,13 @@ typedef struct {
 	CCLEvent* last;
 	int failed;
 } clo_kernel_events;
-void clo_kernel_events_install(clo_kernel_events* ke, CCLQueue* cq, const clo_kname* map, size_t nmap, const char* other);
+CLO_INTERNAL void clo_kernel_events_install(clo_kernel_events* ke, CCLQueue* cq, const clo_kname* map, size_t nmap, const char* other);
 /* Removes the observer; returns the last kernel's event (NULL if there was no
  * launch) and reports a failed event operation through err. */
-CCLEvent* clo_kernel_events_remove(clo_kernel_events* ke, GError** err);
+CLO_INTERNAL CCLEvent* clo_kernel_events_remove(clo_kernel_events* ke, GError** err);
 
 /* Set *err from a clo_hip_* status (domain CCL_HIP_ERROR); returns 1 if st != 0. */
-int clo_hip_failed(int st, GError** err, const char* what);
+CLO_INTERNAL int clo_hip_failed(int st, GError** err, const char* what);
 
 /* Parse one "key=value" option list the way upstream does
  * (g_strsplit_set on "," then "="; clo_sort_abitonic.c:486-543,
@@ -172,6 +175,6 @@ int clo_hip_failed(int st, GError** err, const char* what);
  * token; a token without exactly one '=' makes it return 0 and set *bad to a
  * malloc'd copy of the token. cb returns 0 to abort. */
 typedef int (*clo_option_cb)(const char* key, const char* value, const char* token, void* user, GError** err);
-int clo_parse_options(const char* options, clo_option_cb cb, void* user, const char* algo, GError** err);
+CLO_INTERNAL int clo_parse_options(const char* options, clo_option_cb cb, void* user, const char* algo, GError** err);
 
 #endif

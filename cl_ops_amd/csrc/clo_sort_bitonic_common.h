@@ -16,12 +16,12 @@ typedef struct {
 	int steps;   /* sbitonic: CLO_SBITONIC_STEPS=1 when the sorter was made (one launch per step instead of the tiled schedule) */
 } clo_bitonic_state;
 
-void clo_bitonic_state_release(clo_bitonic_state* state);
+CLO_INTERNAL void clo_bitonic_state_release(clo_bitonic_state* state);
 
 /* Runs one of the two HIP schedules on (data_in -> data_out | in place).
  * tiled = 0: one launch per step (sbitonic); 1: LDS/register tiles (abitonic).
  * Returns the event closing the command, or NULL with *err set. */
-CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, int one_name, const char* evt_name,
+CLO_INTERNAL CCLEvent* clo_bitonic_run(CloSort* sorter, clo_bitonic_state* state, int tiled, int one_name, const char* evt_name,
 	const char* copy_evt_name, CCLQueue* cq_exec, CCLQueue* cq_comm, CCLBuffer* data_in,
 	CCLBuffer* data_out, size_t numel, GError** err);
 

@@ -40,6 +40,17 @@ def test_library_exports_every_declared_symbol():
         C.c_void_p.in_dll(lib, n)  # the plugin vtables are data symbols
 
 
+def test_library_exports_nothing_but_the_declared_interface():
+    """The other direction: every clo_* / ccl_* symbol the library exports is declared in include/*.h — the helpers
+    shared by the host drivers (clo_internal.h) are hidden."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and re.match(r"(clo|ccl)_", l.split()[-1])}
+    data = {"clo_sort_sbitonic_def", "clo_sort_abitonic_def", "clo_sort_satradix_def", "clo_sort_gselect_def", "clo_scan_blelloch_def"}
+    extra = sorted(exported - declared_functions() - data)
+    assert not extra, "exported but not declared in include/*.h: %s" % extra
+
+
 def test_product_does_not_link_the_oracle():
     import subprocess
     out = subprocess.run(["nm", "-D", _hip.LIB_PATH], capture_output=True, text=True).stdout
