@@ -34,16 +34,106 @@ __global__ void fill_kernel(E* keys, const unsigned* off, unsigned low_bits) {
 	}
 }
 
+// EXPERIMENT (probe only): the product's split, every element present, with the stage laid out so that the reload of a
+// thread's ITEMS consecutive elements — 16-byte reads 64 bytes apart between lanes: four lanes of every group of 16 on
+// one bank quad, 16 LDS cycles instead of 4 — is conflict-free. SWZ 1: the 16-byte chunk index XORed with two bits of the
+// thread index (no LDS growth, three more VALU per element); SWZ 2: four dwords of padding after every 64 (LDS + 6 %,
+// two more VALU per element).
+template <int SWZ, int ITEMS, int PER> __device__ __forceinline__ unsigned swz_index(unsigned p) {   // ITEMS elements per thread, PER per 16 bytes
+	constexpr unsigned LI = ITEMS == 16 ? 4 : 3, LP = PER == 4 ? 2 : 1;
+	if (SWZ == 1) return p ^ (((p >> (LI + 2)) & 3u) << LP);
+	if (SWZ == 2) return p + ((p >> (LI + 2)) << LP);
+	return p;
+}
+template <typename E, int THREADS, int ITEMS, int HMAX, int SWZ>
+__device__ __forceinline__ void swz_split(const E (&key)[ITEMS], unsigned dshift, unsigned dmask,
+	E* s_stage, unsigned* s_end, unsigned (*s_wtot)[HMAX], unsigned (*s_wbase)[HMAX]) {
+	constexpr int BITS = 4;
+	constexpr int H = pc_words<BITS>::H;
+	constexpr int WAVES = THREADS / 64;
+	const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	unsigned long long run = 0, c2 = 0;
+	unsigned rb[ITEMS / 4];
+	const unsigned nbits = (unsigned) __builtin_popcount(dmask);
+	#pragma unroll
+	for (int k = 0; k < ITEMS / 4; ++k) rb[k] = 0;
+	#pragma unroll
+	for (int i = ITEMS - 1; i >= 0; --i) {
+		if (ITEMS == 16 && i == 7) c2 = run;
+		const unsigned sh = pc_digit<E>(key[i], dshift, dmask, nbits) * 4u;
+		pc_put_byte(rb[i >> 2], (unsigned) (run >> sh), i & 3);
+		run += 1ull << sh;
+	}
+	const unsigned long long c = run - c2;
+	#pragma unroll
+	for (int k = 0; k < ITEMS / 4; ++k) rb[k] &= 0x0f0f0f0fu;
+	unsigned w[H];
+	pc2_wave_scan<BITS, (ITEMS > 8)>(c, c2, w);
+	if (lane == 63) {
+		#pragma unroll
+		for (int j = 0; j < H; ++j) s_wtot[wave][j] = w[j];
+	}
+	clo_lds_barrier();
+	if (wave == 0) {
+		constexpr int ROUNDS = (H + 3) / 4;
+		const unsigned wv = lane & 15u, q = lane >> 4;
+		unsigned excl[ROUNDS], tot[ROUNDS];
+		#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+			const unsigned j = r * 4 + q;
+			const unsigned x = (j < (unsigned) H && wv < (unsigned) WAVES) ? s_wtot[wv][j] : 0u;
+			unsigned incl = dpp_add<0x111, 0xF>(x);
+			incl = dpp_add<0x112, 0xF>(incl);
+			incl = dpp_add<0x114, 0xF>(incl);
+			incl = dpp_add<0x118, 0xF>(incl);
+			excl[r] = incl - x;
+			tot[r] = incl;
+		}
+		unsigned acc = 0, dstart16[H];
+		#pragma unroll
+		for (int j = 0; j < H; ++j) {
+			const unsigned t = (unsigned) __builtin_amdgcn_readlane((int) tot[j / 4], (j % 4) * 16 + 15);
+			dstart16[j] = acc | ((acc + (t & 0xffffu)) << 16);
+			acc += (t & 0xffffu) + (t >> 16);
+		}
+		#pragma unroll
+		for (int r = 0; r < ROUNDS; ++r) {
+			unsigned mine = dstart16[r * 4];
+			#pragma unroll
+			for (int k = 1; k < 4; ++k) if (r * 4 + k < H && q == (unsigned) k) mine = dstart16[r * 4 + k];
+			const unsigned j = r * 4 + q;
+			if (j < (unsigned) H && wv < (unsigned) WAVES) s_wbase[wv][j] = mine + excl[r];
+		}
+	}
+	clo_lds_barrier();
+	typedef unsigned short __attribute__((may_alias)) pc_u16;
+	pc_u16* const tab = reinterpret_cast<pc_u16*>(s_end) + ((tid & ~63u) + ((tid & 31u) << 1) + ((tid >> 5) & 1u));
+	#pragma unroll
+	for (int j = 0; j < H; ++j) {
+		const unsigned e2 = w[j] + s_wbase[wave][j];
+		tab[(2 * j) * THREADS] = (unsigned short) e2;
+		tab[(2 * j + 1) * THREADS] = (unsigned short) (e2 >> 16);
+	}
+	#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		if (i > 0 && i % PC_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+		const unsigned d = pc_digit<E>(key[i], dshift, dmask, nbits);
+		const unsigned end = tab[d * THREADS];
+		s_stage[swz_index<SWZ, ITEMS, 16 / (int) sizeof(E)>(pc_sub_byte(end, rb[i >> 2], i & 3) - 1u)] = key[i];
+	}
+	clo_lds_barrier();
+}
+
 // One work-group per sub-bucket: THREADS x ITEMS slots, the sub-bucket fills the first `count` of them.
 // COAL: the sub-bucket goes through the stage on its way in and out (whole-wave runs of consecutive elements instead of
 // one run of ITEMS elements per thread at an address that is only element-aligned).
-template <typename E, int THREADS, int ITEMS, int MODE, bool PAD, bool COAL>   // PAD: empty slots hold the largest key and are sorted along (the split's branch-free path); MODE 0: load + splits + store; 1: load + store only (the copy floor); 2: splits on garbage, no global traffic but the offsets
+template <typename E, int THREADS, int ITEMS, int MODE, bool PAD, bool COAL, int SWZ = 0>   // SWZ: the experimental stage layouts above (PAD, splits alone or with the per-thread loads / stores); PAD: empty slots hold the largest key and are sorted along (the split's branch-free path); MODE 0: load + splits + store; 1: load + store only (the copy floor); 2: splits on garbage, no global traffic but the offsets
 __global__ __launch_bounds__(THREADS)
 void local_sort_kernel(E* __restrict__ keys, const unsigned* __restrict__ off, unsigned low_bits, unsigned* __restrict__ oversize) {
 	constexpr int H = pc_words<4>::H;
 	constexpr int WAVES = THREADS / 64;
 	constexpr int CAP = THREADS * ITEMS;
-	__shared__ __attribute__((aligned(16))) E s_stage[CAP];
+	__shared__ __attribute__((aligned(16))) E s_stage[SWZ == 2 ? CAP + CAP / 16 : CAP];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][H];
 	__shared__ unsigned s_wbase[WAVES][H];
@@ -59,7 +149,9 @@ void local_sort_kernel(E* __restrict__ keys, const unsigned* __restrict__ off, u
 	auto reload = [&]() {
 		#pragma unroll
 		for (int k = 0; k < ITEMS / PER; ++k) {
-			const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[tbase + k * PER]);
+			const unsigned at = SWZ == 1 ? tbase + ((unsigned) k ^ ((threadIdx.x >> 2) & 3u)) * PER
+				: SWZ == 2 ? tbase + (threadIdx.x >> 2) * PER + k * PER : tbase + k * PER;
+			const vec16 t = *reinterpret_cast<const vec16*>(&s_stage[at]);
 			#pragma unroll
 			for (int q = 0; q < PER; ++q) key[k * PER + q] = t[q];
 		}
@@ -79,7 +171,8 @@ void local_sort_kernel(E* __restrict__ keys, const unsigned* __restrict__ off, u
 	if (MODE != 1) {
 		for (unsigned done = 0; done < low_bits; done += 4) {
 			const unsigned bits = low_bits - done < 4u ? low_bits - done : 4u;
-			pc_local_split<E, 4, THREADS, ITEMS, H>(key, done, (1u << bits) - 1u, PAD ? (unsigned) CAP : n, s_stage, s_end, s_wtot, s_wbase);
+			if constexpr (SWZ != 0) swz_split<E, THREADS, ITEMS, H, SWZ>(key, done, (1u << bits) - 1u, s_stage, s_end, s_wtot, s_wbase);
+			else pc_local_split<E, 4, THREADS, ITEMS, H>(key, done, (1u << bits) - 1u, PAD ? (unsigned) CAP : n, s_stage, s_end, s_wtot, s_wbase);
 			if (!(COAL && MODE == 0) || done + 4 < low_bits) reload();
 		}
 	}
@@ -101,7 +194,7 @@ void local_sort_kernel(E* __restrict__ keys, const unsigned* __restrict__ off, u
 	} else if (key[0] == (E) 0x12345u) keys[lo] = key[1];
 }
 
-template <typename E, int THREADS, int ITEMS, int MODE, bool PAD, bool COAL>
+template <typename E, int THREADS, int ITEMS, int MODE, bool PAD, bool COAL, int SWZ = 0>
 static float run(E* keys, const unsigned* off, unsigned buckets, unsigned low_bits, unsigned* oversize, int reps, const E* pristine, size_t n) {
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -110,7 +203,7 @@ static float run(E* keys, const unsigned* off, unsigned buckets, unsigned low_bi
 		CK(hipMemcpy(keys, pristine, n * sizeof(E), hipMemcpyDeviceToDevice));   // (also: the keys arrive as the pass before would leave them, freshly written)
 		CK(hipMemset(oversize, 0, 4));
 		CK(hipEventRecord(e0, 0));
-		hipLaunchKernelGGL((local_sort_kernel<E, THREADS, ITEMS, MODE, PAD, COAL>), dim3(buckets), dim3(THREADS), 0, 0, keys, off, low_bits, oversize);
+		hipLaunchKernelGGL((local_sort_kernel<E, THREADS, ITEMS, MODE, PAD, COAL, SWZ>), dim3(buckets), dim3(THREADS), 0, 0, keys, off, low_bits, oversize);
 		CK(hipEventRecord(e1, 0));
 		CK(hipEventSynchronize(e1));
 		float ms = 0;
@@ -157,6 +250,16 @@ static int probe(int logn, unsigned top_bits) {
 		printf("  %4d threads x %2d slots (capacity %5d)%s%s: sort %.3f ms%s, load + store alone %.3f, splits alone %.3f; oversize sub-buckets %u\n", T, I, T * I, \
 			P ? " padded" : "       ", C ? " through the stage" : "                  ", full, ok ? "" : " NOT SORTED", copy, alu, over); \
 	} while (0)
+	#define RUNS(T, I, Z) do { \
+		const float full = run<E, T, I, 0, true, false, Z>(d_keys, d_off, buckets, low_bits, d_over, 5, d_pristine, n); \
+		std::vector<E> h(1 << 22); CK(hipMemcpy(h.data(), d_keys + (n / 2), h.size() * sizeof(E), hipMemcpyDeviceToHost)); \
+		const bool ok = std::is_sorted(h.begin(), h.end()); \
+		const float alu = run<E, T, I, 2, true, false, Z>(d_keys, d_off, buckets, low_bits, d_over, 5, d_pristine, n); \
+		printf("  %4d threads x %2d slots, stage layout %d (0 linear as shipped, 1 chunk index XOR thread bits, 2 padded rows): sort %.3f ms%s, splits alone %.3f\n", T, I, Z, full, ok ? "" : " NOT SORTED", alu); \
+	} while (0)
+	if (sizeof(E) == 4) { RUNS(320, 16, 0); RUNS(320, 16, 1); RUNS(320, 16, 2); RUNS(512, 16, 0); RUNS(512, 16, 1); RUNS(512, 16, 2); }
+	else { RUNS(768, 8, 0); RUNS(768, 8, 1); RUNS(768, 8, 2); }
+	#undef RUNS
 	if (sizeof(E) == 4) {
 		RUN(320, 16, true, false); RUN(320, 16, true, true); RUN(320, 16, false, true); RUN(384, 16, true, true); RUN(512, 16, false, true);
 	} else {
