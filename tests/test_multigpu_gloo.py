@@ -36,7 +36,10 @@ def _worker(rank, world, port, elem_type, n, skew, out_dir):
         t_dt = torch.int32 if elem_type == "uint" else torch.int64
         rng = np.random.default_rng(100 + rank)
         hi = np.iinfo(np_dt).max
-        if skew:   # most keys in one bucket: exercises the receive-capacity path
+        if skew == "empty":   # a rank without keys, and every key of the others in bucket 0: ranks that send / receive nothing
+            n = 0 if rank == world - 1 else n
+            a = rng.integers(0, hi >> 4, n, dtype=np_dt, endpoint=True)
+        elif skew:   # most keys in one bucket: exercises the receive-capacity path
             a = rng.integers(0, hi // 8, n, dtype=np_dt, endpoint=True)
             a[: n // 10] = rng.integers(0, hi, n // 10, dtype=np_dt, endpoint=True)
         else:
@@ -54,7 +57,8 @@ def _worker(rank, world, port, elem_type, n, skew, out_dir):
 
 @pytest.mark.parametrize("world,elem_type,n,skew", [(2, "uint", 5000, False), (2, "ulong", 3000, False),
                                                      (4, "uint", 2000, False), (2, "uint", 4000, True),
-                                                     (8, "uint", 1500, False), (8, "ulong", 700, True)])   # the driver's N = 8 plan
+                                                     (8, "uint", 1500, False), (8, "ulong", 700, True),    # the driver's N = 8 plan
+                                                     (2, "uint", 3000, "empty"), (4, "ulong", 900, "empty")])
 def test_sharded_sort_over_gloo(tmp_path, world, elem_type, n, skew):
     import torch.multiprocessing as mp
     port = _free_port()
