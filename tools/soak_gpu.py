@@ -1,0 +1,77 @@
+"""Developer soak (GPU box): a handful of long-lived sorter / scanner objects, used over and over on arrays whose sizes
+jump around (their cached workspaces grow, are reused for smaller arrays, see other tile shapes and pass kinds), every
+result checked against numpy. What the fuzz tools do not cover: state a call leaves behind for the next one (tickets,
+epochs, hand-off words, cached buffers). python tools/soak_gpu.py [seconds=240] [seed=1]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cl_ops_amd as clo  # noqa: E402
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ctx = clo.Context(0)
+    q = clo.Queue(ctx)
+    objs = [
+        ("satradix", "uint", clo.Sorter("satradix", ctx, "uint")),
+        ("satradix", "ulong", clo.Sorter("satradix", ctx, "ulong")),
+        ("satradix256", "uint", clo.Sorter("satradix", ctx, "uint", options="radix=256")),
+        ("satradix", "ushort", clo.Sorter("satradix", ctx, "ushort")),
+        ("abitonic", "uint", clo.Sorter("abitonic", ctx, "uint")),
+        ("sbitonic", "int", clo.Sorter("sbitonic", ctx, "int")),
+        ("scan", "uint", clo.Scanner("blelloch", ctx, "uint", "uint")),
+        ("scan64", "uint", clo.Scanner("blelloch", ctx, "uint", "ulong")),
+    ]
+    cap = 1 << 25
+    src, dst = clo.Buffer(ctx, cap * 8), clo.Buffer(ctx, cap * 8)
+    t0 = time.time()
+    calls = bad = 0
+    last_print = t0
+    while time.time() - t0 < seconds:
+        name, et, o = objs[int(rng.integers(0, len(objs)))]
+        dt = clo.api.CLO_TYPE_NP[et]
+        top = 25 if name.startswith("satradix") or name.startswith("scan") else (22 if name == "abitonic" else 16)
+        logn = int(rng.integers(1, top + 1))
+        n = int(rng.integers(max(1, 1 << (logn - 1)), (1 << logn) + 1))
+        if name.startswith("scan"):
+            a = rng.integers(0, 128, n).astype(dt)
+            sdt = clo.api.CLO_TYPE_NP["ulong" if name == "scan64" else "uint"]
+            src.write(q, a)
+            o.with_device_data(q, src, dst, n)
+            got = dst.read(q, sdt, n)
+            exp = np.concatenate((np.zeros(1, np.uint64), np.cumsum(a.astype(np.uint64))[:-1])).astype(sdt)
+        else:
+            info = np.iinfo(dt)
+            mode = int(rng.integers(0, 4))
+            if mode == 0:
+                a = rng.integers(info.min, int(info.max) + 1, n, dtype=np.int64 if info.min < 0 else np.uint64).astype(dt)
+            elif mode == 1:    # few distinct values
+                a = rng.integers(0, 7, n).astype(dt)
+            elif mode == 2:    # sorted already
+                a = np.sort(rng.integers(0, int(info.max) + 1, n, dtype=np.uint64).astype(dt))
+            else:              # a narrow range
+                a = (rng.integers(0, 1 << 10, n) + (int(info.max) >> 3)).astype(dt)
+            src.write(q, a)
+            in_place = bool(rng.integers(0, 2))
+            o.with_device_data(q, src, None if in_place else dst, n)
+            got = (src if in_place else dst).read(q, dt, n)
+            exp = np.sort(a)
+        calls += 1
+        if not np.array_equal(got, exp):
+            bad += 1
+            print("MISMATCH", name, et, n, flush=True)
+        if time.time() - last_print > 30:
+            last_print = time.time()
+            print("... %d calls, %d bad" % (calls, bad), flush=True)
+    print("soak: %d calls in %.0f s, %d mismatches" % (calls, time.time() - t0, bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
