@@ -1,6 +1,7 @@
 /*
  * clo_oracle.c — CPU restatement of the cl_ops sort/scan hot path (see
- * clo_oracle.h for scope, citations and pin status). TEST INFRASTRUCTURE ONLY.
+ * clo_oracle.h for scope, citations and pin status: parity unpinned — the reference
+ * holds no vectors for this path and cannot be run here). TEST INFRASTRUCTURE ONLY.
  *
  * Conventions: elements are handled as raw little-endian unsigned integers of
  * elem_size bytes (held in uint64_t). "ref:" comments name the upstream

@@ -11,7 +11,7 @@
  * element; here each kernel is restated as loops over work-groups/work-items
  * with the barriers turned into loop boundaries.
  *
- * Pin status: the upstream tree holds NO golden vectors or unit tests for
+ * Pin status: PARITY UNPINNED. The upstream tree holds NO golden vectors or unit tests for
  * sort/scan (only src/tests/test_rng.c). Its only known-answer checks for this
  * path are the benchmark self-checks (clo_sort_bench.c:211-226 adjacent-pair
  * order, clo_scan_bench.c:252-271 serial exclusive scan), restated below as
