@@ -191,8 +191,8 @@ int clo_hip_radix_takes_first_digits(size_t numel, int elem_size, int key_kind, 
 int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
 	int elem_size, int key_shift, int key_bits, int key_kind, int digit_bits, const unsigned char* first_digits,
 	void* workspace, size_t workspace_bytes, void* stream);
-/* Diagnostic: a device buffer of 4 x tiles uint64 that the single-sweep passes fill with per-tile clock stamps
- * (ticket drawn, keys loaded, look-back done, stored) until it is taken away again with NULL. Off by default. */
+/* Diagnostic: a device buffer of 8 x tiles uint64 that the LAST single-sweep pass of a sort fills with per-tile
+ * s_memtime stamps (tile drawn ... stored) until it is taken away again with NULL. Process-wide, off by default. */
 int clo_hip_radix_debug_stamps(void* buffer, size_t tiles);
 
 /* Segmented sort (new functionality, the local step of the sharded sort): `nseg` (1..256) segments of ONE array —

@@ -239,3 +239,40 @@ def test_segmented_sort_from_a_larger_source(gpu, dt, key_bits):
     gathered = np.concatenate([big[starts[k, c]:starts[k, c] + sizes[k, c]] for k in range(nseg) for c in range(nchunk)])
     assert np.array_equal(got, _expect(gathered, seg_counts, 3, key_bits))
     assert np.array_equal(src.cpu().numpy().view(dt), big)
+
+
+def test_sweep_pass_clock_stamps_diagnostic(gpu, monkeypatch):
+    """clo_hip_radix_debug_stamps (include/clo_hip.h): while a buffer is registered, the last single-sweep pass of a sort
+    leaves eight words per tile — seven s_memtime stamps in program order, then (XCC id << 32 | work-group) — and
+    nothing is written once the buffer is taken away again. The sort's result is the same either way."""
+    torch = gpu
+    import cl_ops_amd as clo
+    from cl_ops_amd._hip import lib
+    lib.clo_hip_radix_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
+    monkeypatch.setenv("CLO_RADIX_SWEEP", "1")
+    ctx = clo.Context(0)
+    q = clo.Queue(ctx)
+    n = (1 << 20) + 77
+    a = np.random.default_rng(3).integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    s = clo.Sorter("satradix", ctx, "uint")               # (reads the switch)
+    tiles_max = 4096
+    stamps = torch.zeros(tiles_max * 8, dtype=torch.int64, device="cuda")
+    assert lib.clo_hip_radix_debug_stamps(stamps.data_ptr(), tiles_max) == 0
+    try:
+        got = s.with_host_data(a, q)
+    finally:
+        assert lib.clo_hip_radix_debug_stamps(None, 0) == 0
+    assert np.array_equal(got, np.sort(a))
+    st = stamps.cpu().numpy().view(np.uint64).reshape(tiles_max, 8)
+    used = np.flatnonzero(st[:, 0])
+    assert used.size >= n // 16384 and used.size == used[-1] + 1     # tiles 0 .. T-1 of the pass, whatever its tile shape
+    t = st[used, :7].astype(np.int64)
+    assert np.all(np.diff(t, axis=1) >= 0)                            # stamps in program order
+    assert np.all((st[used, 7] >> np.uint64(32)) < 8)                 # an XCC id
+    stamps.zero_()
+    again = s.with_host_data(a, q)
+    torch.cuda.synchronize()
+    assert np.array_equal(again, got) and int(stamps.abs().sum().item()) == 0
+    s.close()
+    q.close()
+    ctx.close()
