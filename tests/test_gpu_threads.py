@@ -171,3 +171,42 @@ def test_host_data_pipelines_side_by_side(clo):
     assert not any(w.is_alive() for w in workers), "a worker is stuck"
     assert errors == []
     ctx.close()
+
+
+def test_objects_give_their_device_memory_back(clo):
+    """Sorters, scanners and their queues created, used and destroyed over and over: the device's free memory comes back
+    to where it was (cached workspaces, pipeline buffers, events and streams all belong to an object and go with it)."""
+    import torch
+    ctx = clo.Context(0)
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 1 << 32, 1 << 21, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 128, 1 << 21).astype(np.uint32)
+
+    def cycle():
+        q = clo.Queue(ctx)
+        for alg, opts in (("satradix", None), ("satradix", "radix=256"), ("abitonic", None), ("sbitonic", None)):
+            s = clo.Sorter(alg, ctx, "uint", options=opts)
+            n = a.size if alg != "sbitonic" else 1 << 15
+            src, dst = clo.Buffer(ctx, n * 4), clo.Buffer(ctx, n * 4)
+            src.write(q, a[:n])
+            s.with_device_data(q, src, dst, n)
+            assert np.array_equal(dst.read(q, np.uint32, n), np.sort(a[:n]))
+            if alg == "satradix":
+                assert np.array_equal(s.with_host_data(a, q), np.sort(a))
+            for x in (src, dst, s):
+                x.close()
+        sc = clo.Scanner("blelloch", ctx, "uint", "ulong")
+        got = sc.with_host_data(b, q)
+        assert int(got[-1]) == int(b[:-1].sum())
+        sc.close()
+        q.close()
+
+    cycle()                       # (first use: code objects, the runtime's own pools)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (64 << 20), "device memory lost over 12 cycles: %.1f MiB" % ((free0 - free1) / 2**20)
+    ctx.close()
