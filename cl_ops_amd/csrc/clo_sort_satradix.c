@@ -667,6 +667,10 @@ static const char* clo_sort_satradix_init(CloSort* sorter, const char* options, 
 	}
 	if (data->scan_type == NULL) data->scan_type = strdup(CLO_SORT_SATRADIX_SCAN_DEFAULT);
 	data->scan_opts = c.scan_opts ? c.scan_opts : strdup("");
+	if (!data->scan_type || !data->scan_opts) {   /* (out of host memory) */
+		satradix_free(data);
+		return NULL;
+	}
 	/* Upstream hands the per-digit counters to a CloScan of this type
 	 * (clo_sort_satradix.c:94,298) and so fails at the first sort when the type or
 	 * its options are not valid. Here the counter scan is fused into the radix
