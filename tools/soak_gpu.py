@@ -28,6 +28,10 @@ def main():
         ("scan", "uint", clo.Scanner("blelloch", ctx, "uint", "uint")),
         ("scan64", "uint", clo.Scanner("blelloch", ctx, "uint", "ulong")),
     ]
+    import torch
+    from cl_ops_amd.multigpu import CShardedSorter
+    objs += [("shard", "uint", CShardedSorter("uint", 0, options="loopback=1")), ("shard", "ulong", CShardedSorter("ulong", 0, options="loopback=1,slices=4")),
+             ("hostsort", "uint", objs[0][2]), ("hostsort", "ulong", objs[1][2])]
     cap = 1 << 25
     src, dst = clo.Buffer(ctx, cap * 8), clo.Buffer(ctx, cap * 8)
     t0 = time.time()
@@ -39,7 +43,24 @@ def main():
         top = 25 if name.startswith("satradix") or name.startswith("scan") else (22 if name == "abitonic" else 16)
         logn = int(rng.integers(1, top + 1))
         n = int(rng.integers(max(1, 1 << (logn - 1)), (1 << logn) + 1))
-        if name.startswith("scan"):
+        if name == "shard":        # the sharded C path over RCCL on this one rank: sizes on both sides of the slicing threshold
+            n = int(rng.integers(0, 1 << int(rng.integers(10, 25))))
+            mode = int(rng.integers(0, 3))
+            top_v = int(np.iinfo(dt).max)
+            a = rng.integers(0, top_v, n, dtype=dt, endpoint=True) if mode == 0 else (rng.integers(0, top_v, n, dtype=dt, endpoint=True) >> dt.type(int(rng.integers(1, 12)))) if mode == 1 \
+                else np.full(n, rng.integers(0, top_v, dtype=dt, endpoint=True), dtype=dt)
+            t = torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if et == "uint" else np.int64).copy()).cuda()
+            out, m = o.sort(t, n)
+            o.check()
+            torch.cuda.synchronize()
+            got, exp = (out.cpu().numpy().view(dt)[:m] if m else np.empty(0, dt)), np.sort(a)
+        elif name == "hostsort":   # clo_sort_with_host_data, around its pipelining threshold (128 MiB)
+            n = int(rng.integers(1 << 20, (1 << 25) + 4097)) if et == "uint" else int(rng.integers(1 << 20, (1 << 24) + 4097))
+            a = rng.integers(0, int(np.iinfo(dt).max), n, dtype=dt, endpoint=True)
+            if rng.integers(0, 2):
+                a >>= dt.type(int(rng.integers(1, 10)))
+            got, exp = o.with_host_data(a, q), np.sort(a)
+        elif name.startswith("scan"):
             a = rng.integers(0, 128, n).astype(dt)
             sdt = clo.api.CLO_TYPE_NP["ulong" if name == "scan64" else "uint"]
             src.write(q, a)
