@@ -202,6 +202,7 @@ static void sort_warmup(CloSort* sorter, const char* type, size_t elem_size) {
 	/* satradix has three families of kernels, each in a code object of its own:
 	 * the one-launch sort (<= 2^14 elements), the chain-free passes, and the
 	 * single-sweep passes the library uses from 128 tiles on (4 MiB of elements) */
+	if (k == 0) (void) clo_hip_radix_preload();   /* (the chain-free passes start above the dummy sorts' sizes) */
 	const size_t sizes[3] = { 16, k == 0 ? 20000 : (k == 3 ? 2048 : 32768),
 		k == 0 && elem_size >= 4 ? ((size_t) 4 << 20) / elem_size : 0 };
 	for (int i = 0; i < 3; ++i) {

@@ -25,6 +25,7 @@
 //   CLO_RADIX_NO_DIGITS  set: no digit stream between the chain-free passes (tests compare both)
 struct clo_hip_env_t { unsigned max_spins; int radix_sweep; int r1_pools; int no_digits; };
 const clo_hip_env_t* clo_hip_env();
+int clo_radixw_preload();   // clo_hip_radixw.hip
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>

@@ -102,6 +102,8 @@ int clo_hip_radix_sort_fed(const void* src, void* dst, void* tmp, size_t numel,
 	return clo_radix4_sort(src, dst, tmp, numel, elem_size, key_shift, key_bits, digit_bits, kx, first_digits, workspace, s);
 }
 
+int clo_hip_radix_preload(void) { return clo_radixw_preload(); }
+
 size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, int digit_bits) {
 	return clo_radix4_seg_workspace_bytes(numel, nseg, elem_size, digit_bits);
 }

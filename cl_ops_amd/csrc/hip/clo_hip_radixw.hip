@@ -621,4 +621,11 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 	return (int) hipGetLastError();
 }
 
+// Loads this file's code object (HIP loads one at the first launch that needs it — 2.4 ms inside the first chain-free
+// pass of a process, which the sorter's warm-up sorts are too small to reach): asking for a kernel's attributes does it.
+int clo_radixw_preload() {
+	hipFuncAttributes a;
+	return (int) hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&clo_radix_seg_build_kernel));
+}
+
 size_t clo_radixw_lds_bytes(int digit_bits) { return 32 * ((size_t) 1 << digit_bits) * sizeof(unsigned); }

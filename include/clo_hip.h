@@ -171,6 +171,9 @@ int clo_hip_reduce_sum(const void* data_in, size_t numel, int elem_size, int ele
  * src is read, the sorted result is written to dst; tmp is scratch of the same
  * size. dst may equal src (in place); tmp must be distinct from both. src is
  * left untouched when dst != src. Asynchronous on `stream`. */
+/* Loads the code objects of the radix passes that a small first sort does not reach (HIP loads one at the first launch
+ * that needs it; upstream builds and loads every kernel in clo_sort_new, sort/clo_sort_abstract.c:144-179). */
+int clo_hip_radix_preload(void);
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits);
 /* 1 if the kernels of such a sort wait for other work-groups (the single-sweep
  * passes hand digit counts from tile to tile; every spin is bounded and a give-up

@@ -130,6 +130,7 @@ static int stable_sort(const void* src, void* dst, size_t n, int es, int shift, 
 }
 
 /* ---- radix sort ---- */
+int clo_hip_radix_preload(void) { return 0; }
 size_t clo_hip_radix_workspace_bytes(size_t numel, int elem_size, int key_bits, int digit_bits) {
 	(void) numel; (void) elem_size;
 	return (digit_bits < 1 || digit_bits > 8 || key_bits < 1) ? 0 : 1024;
