@@ -51,6 +51,7 @@ harness)
 	# the reference harness's own sweeps (host data in, exec-queue device time, 5 runs per size)
 	B="$ROOT/benchmarks/bin"
 	"$B/clo_hip_sort_bench" -a satradix -t uint -n 28 -r 5 > "$OUT/harness_satradix.txt" 2>&1 || exit 1
+	"$B/clo_hip_sort_bench" -a satradix -t ulong -n 27 -r 5 > "$OUT/harness_satradix_ulong.txt" 2>&1 || exit 1
 	"$B/clo_hip_sort_bench" -a abitonic -t uint -n 26 -r 5 > "$OUT/harness_abitonic.txt" 2>&1 || exit 1
 	"$B/clo_hip_sort_bench" -a sbitonic -t uint -n 20 -r 5 > "$OUT/harness_sbitonic.txt" 2>&1 || exit 1
 	"$B/clo_hip_sort_bench" -a gselect -t uint -n 16 -r 5 > "$OUT/harness_gselect.txt" 2>&1 || exit 1

@@ -183,6 +183,7 @@ for workload, needle in (("scan", "clo_scan_kernel"), ("abitonic", "tile_merge_k
 # ---- the C harnesses' sweeps ----
 NOTES = {
     "satradix": "benchmarks/bin/clo_hip_sort_bench -a satradix -t uint -n 28 -r 5",
+    "satradix_ulong": "benchmarks/bin/clo_hip_sort_bench -a satradix -t ulong -n 27 -r 5",
     "abitonic": "benchmarks/bin/clo_hip_sort_bench -a abitonic -t uint -n 26 -r 5",
     "sbitonic": "benchmarks/bin/clo_hip_sort_bench -a sbitonic -t uint -n 20 -r 5",
     "gselect": "benchmarks/bin/clo_hip_sort_bench -a gselect -t uint -n 16 -r 5",
