@@ -387,7 +387,10 @@ unsigned g_scan_max_spins = CLO_MAX_SPINS;   // CLO_MAX_SPINS in the environment
 // 8 rows, 108 with 16; capping at 64 for two groups spills 82 registers): the
 // shorter tile is what helps — its load, look-back and store phases alternate
 // twice as often.
-constexpr size_t SCAN_BIG_NUMEL = (size_t) 1 << 24;
+#ifndef CLO_SCAN_BIG_NUMEL32
+#define CLO_SCAN_BIG_NUMEL32 ((size_t) 1 << 21)
+#endif
+constexpr size_t SCAN_BIG_NUMEL = CLO_SCAN_BIG_NUMEL32;
 #ifndef CLO_SCAN_BIG_ROWS
 #define CLO_SCAN_BIG_ROWS 8
 #endif
@@ -395,10 +398,20 @@ constexpr size_t SCAN_BIG_NUMEL = (size_t) 1 << 24;
 #define CLO_SCAN_BIG_GROUPS 256
 #endif
 constexpr int SCAN_BIG_ROWS = CLO_SCAN_BIG_ROWS;
-constexpr int scan_threads(size_t numel) { return numel >= SCAN_BIG_NUMEL ? 1024 : 256; }
+// Where the large shape starts (round 4, tools/scan_sizes_probe.py; it was 2^24 for every sum type): the small shape
+// has every tile in flight at once and hands the super-tiles' prefixes on one after the other, 3.5 us a hop — 1024 tiles
+// of 8 192 elements (64-bit sums) are sixteen hops: 2^23 uint -> ulong took 0.083 ms BETWEEN 0.030 at 2^22 and 0.055 at
+// 2^24, found as a dip in the harness's sweep. From 2^21 elements on the large shape (64 and more tiles of 32 768) is
+// the faster one for both sum widths: uint -> ulong 2^23 0.083 -> 0.033 ms, 2^22 0.030 -> 0.025, 2^21 0.023 -> 0.021;
+// uint -> uint 2^23 0.026 -> 0.021, 2^22 0.020 -> 0.016, 2^21 0.0153 -> 0.0136 (2^20: slower, stays small).
+#ifndef CLO_SCAN_BIG_NUMEL64
+#define CLO_SCAN_BIG_NUMEL64 ((size_t) 1 << 21)
+#endif
+constexpr bool scan_big(size_t numel, int sum_size) { return numel >= (sum_size > 4 ? CLO_SCAN_BIG_NUMEL64 : SCAN_BIG_NUMEL); }
+constexpr int scan_threads(size_t numel, int sum_size) { return scan_big(numel, sum_size) ? 1024 : 256; }
 constexpr int scan_small_rows(int sum_size) { return sum_size > 4 ? 8 : 16; }
 constexpr size_t scan_tile_elems(size_t numel, int sum_size) {
-	return (size_t) scan_threads(numel) * SCAN_VEC * (numel >= SCAN_BIG_NUMEL ? SCAN_BIG_ROWS : scan_small_rows(sum_size));
+	return (size_t) scan_threads(numel, sum_size) * SCAN_VEC * (scan_big(numel, sum_size) ? SCAN_BIG_ROWS : scan_small_rows(sum_size));
 }
 
 // Granules a workspace for `tiles` tiles holds, and how many of them (at its
@@ -436,7 +449,7 @@ int launch_scan(const void* in, void* out, size_t n, const clo_u64* carry_in, cl
 		clo_timing_scope timing("scan", s);
 		// as many work-groups as fit the chip at once; each draws tiles until none is left
 		const unsigned groups_big = (unsigned) (tiles < CLO_SCAN_BIG_GROUPS ? tiles : CLO_SCAN_BIG_GROUPS), groups_small = (unsigned) (tiles < 2048 ? tiles : 2048);
-		if (scan_threads(n) == 1024)
+		if (scan_threads(n, (int) sizeof(TOut)) == 1024)
 			hipLaunchKernelGGL((clo_scan_kernel<TIn, TOut, TSum, SCAN_BIG_ROWS, 1024>), dim3(groups_big), dim3(1024), 0, s,
 				(const TIn*) in, (TOut*) out, n, hdr, state, sstate, sagg, sacc, aligned, g_scan_xflags,
 				carry_in, carry_out, (unsigned) (tiles - 1), max_spins, ws_granules);
