@@ -634,14 +634,14 @@ int clo_radix1_applies(size_t n, int elem_size, int digit_bits) {
 	const size_t tiles = (n + (size_t) 512 * (elem_size == 8 ? 8 : 16) - 1) / ((size_t) 512 * (elem_size == 8 ? 8 : 16));
 	if (mode == 1) return tiles > 1;
 	// The library's choice (measured, docs/lab_notebook.md; profiles/r03_sweep_sizes*.txt, r03_sweep_edge*.txt):
-	// 4 .. 256 tiles (2^15 .. 2^21 4-byte elements, 2^14 .. 2^20 8-byte ones): the sort is launch-bound and
+	// 2 .. 256 tiles (up to 2^21 4-byte elements, 2^20 8-byte ones): the sort is launch-bound and
 	// the sweeps need 6 launches instead of 12: 5-25 % less time (and half the events on a profiling
 	// queue). Above that the chain-free passes are ahead, and no work-group ever waits for another's
 	// result there. The switch moved down as their counter scan got cheaper: round 2 switched at 1024 tiles,
 	// round 3 at 512 when the scan's three kernels lost 10 us per pass, then at 256 when they became
 	// one launch (2^22 uint32: 0.104 vs 0.119 ms, 2^23: 0.144 vs 0.190; 2^21 uint64: 0.187 vs 0.199;
 	// 2^21 pairs: 0.093 vs 0.107 — at 2^21 uint32 the sweeps still win, 0.090 vs 0.095).
-	return tiles >= 4 && tiles <= 256;
+	return tiles >= 2 && tiles <= 256;   // (round 4: from 2 tiles, not 4 — 8 193 uint64 keys 0.109 -> 0.083 ms, 16 385 uint32 keys 0.065 -> 0.055)
 }
 
 size_t clo_radix1_workspace_bytes(size_t n, int elem_size, int key_bits) {

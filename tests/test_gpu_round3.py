@@ -620,6 +620,7 @@ def test_radix_sort_fed_with_first_digits(gpu, kind, logn, shift, bits):
     n = (1 << logn) + 1234
     a = np.random.default_rng(logn + shift).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
     key = (a >> dt(shift)) & dt((1 << bits) - 1 if bits < 64 else np.iinfo(dt).max)
+    lib.clo_hip_env_refresh()        # (the switches are read when an object is made: none has been, in this test, since an earlier one changed them)
     takes = lib.clo_hip_radix_takes_first_digits(n, es, 0, 4)
     assert takes == (1 if n * es >= ((64 if es == 8 else 256) << 20) else 0)
     wsb = lib.clo_hip_radix_workspace_bytes(n, es, bits, 4)
