@@ -401,7 +401,7 @@ def _run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local
             pn = 1 << 22
             ph = make_input(workload, pn, seed + 977 + rank)
             pt = torch.from_numpy(ph.view(np.int32 if es == 4 else np.int64)).to(be.device)
-            probe = CShardedSorter(etype, local_rank, options="radix=%d,slices=2" % radix, transport=sharded.transport)
+            probe = CShardedSorter(etype, local_rank, options="radix=%d,slices=2,slice_min=1" % radix, transport=sharded.transport)
             try:
                 po, pm = probe.sort(pt, pn)
                 probe.check()

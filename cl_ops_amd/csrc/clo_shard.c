@@ -24,8 +24,13 @@
 #define SHARD_TAIL 5                        /* words after a rank's counts in the gather: status, receive capacity, then the
                                              * adaptive slices' sample: sequence number of a finished call, its device us, its slices */
 #define SHARD_ROW (SHARD_SUBS + SHARD_TAIL)
-#ifndef SHARD_SLICE_MIN_PER_RANK   /* (the sanitizer build of tests/hoststub shrinks it) */
-#define SHARD_SLICE_MIN_PER_RANK ((uint64_t) 1 << 22)   /* below this many keys per rank (global mean) one exchange and a plain sort are used */
+/* Below this many BYTES of keys per rank (global mean) one exchange and a plain sort are used: a segmented sort of 256
+ * sub-buckets pays off once they span many tiles each. One rank over RCCL, segmented against plain, ms per call
+ * (profiles/r04_shard_threshold_probe.txt): uint32 2^24 0.457 / 0.362, 2^25 0.627 / 0.603, 2^26 1.127 / 1.120, 2^27
+ * 1.883 / 1.980; uint64 2^24 0.933 / 0.851, 2^25 1.566 / 1.536, 2^26 2.661 / 2.755, 2^27 4.918 / 5.409 — the curves cross at
+ * 256 MiB per rank for both widths (round 4 first set 2^22 KEYS). The option "slice_min=<bytes>" overrides it. */
+#ifndef SHARD_SLICE_MIN_BYTES_PER_RANK   /* (the sanitizer build of tests/hoststub shrinks it) */
+#define SHARD_SLICE_MIN_BYTES_PER_RANK ((uint64_t) 256 << 20)
 #endif
 #define SHARD_TRIES 2                       /* calls per slice count before the adaptive choice settles */
 
@@ -36,6 +41,7 @@ struct clo_shard_sort {
 	CloType elem_type;
 	int elem_size, bucket_bits, subs;     /* subs = SHARD_SUBS / world: sub-buckets (segments) per rank */
 	int slices_opt;                       /* 1, 2, 4, 8 as asked for, 0 = adaptive, -1 = one rank without loopback: no exchange */
+	uint64_t slice_min_bytes;             /* per rank (global mean): below it one exchange + a plain sort */
 	int segmented;                        /* the sorter runs segmented sorts (radix 16 / 256) */
 	clo_devbuf send, workspace, counts;   /* partitioned shard; partition workspace; my row + the gathered rows (uint64) */
 	CCLBuffer* recv;                      /* what arrives (owned; grown on demand; from the transport's recv_alloc when it has one) */
@@ -169,10 +175,11 @@ size_t clo_shard_plan_slice(const uint64_t* counts, size_t row, int world, int s
 
 /* ---------------- the object ---------------- */
 
-/* "slices=S" and "loopback=0|1" are ours, the rest goes to satradix. Returns a malloc'd copy of the rest, or NULL on a bad value. */
-static char* shard_options(const char* options, int* slices, int* loopback, GError** err) {
+/* "slices=S", "loopback=0|1" and "slice_min=BYTES" are ours, the rest goes to satradix. Returns a malloc'd copy of the rest, or NULL on a bad value. */
+static char* shard_options(const char* options, int* slices, int* loopback, uint64_t* slice_min, GError** err) {
 	*slices = 0;
 	*loopback = 0;
+	*slice_min = SHARD_SLICE_MIN_BYTES_PER_RANK;
 	const size_t len = options ? strlen(options) : 0;
 	char* rest = (char*) calloc(len + 1, 1);
 	if (!rest) return NULL;
@@ -194,6 +201,8 @@ static char* shard_options(const char* options, int* slices, int* loopback, GErr
 			}
 		} else if (n > 9 && strncmp(p, "loopback=", 9) == 0) {
 			*loopback = atoi(p + 9) != 0;
+		} else if (n > 10 && strncmp(p, "slice_min=", 10) == 0) {
+			*slice_min = (uint64_t) strtoull(p + 10, NULL, 10);
 		} else if (n > 0) {
 			if (rest[0]) strcat(rest, ",");
 			strncat(rest, p, n);
@@ -220,7 +229,8 @@ CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, 
 		return NULL;
 	}
 	int slices = 0, loopback = 0;
-	char* sort_options = shard_options(options, &slices, &loopback, err);
+	uint64_t slice_min = 0;
+	char* sort_options = shard_options(options, &slices, &loopback, &slice_min, err);
 	if (!sort_options) return NULL;
 	/* (one rank has nothing to exchange; `loopback=1` sends the rank's keys to itself through the whole
 	 * protocol: a rehearsal of the exchange over the transport on a one-GPU box) */
@@ -238,6 +248,7 @@ CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, 
 	ss->bucket_bits = bits;
 	ss->subs = SHARD_SUBS / world;
 	ss->slices_opt = slices;
+	ss->slice_min_bytes = slice_min;
 	{   /* does this sorter run segmented sorts (radix 16 / 256)? Otherwise: one exchange and a plain sort, always */
 		const clo_sort_impl_ext* ext = clo_sort_impl_ext_find("satradix");
 		int handled = 0;
@@ -545,7 +556,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 	}
 	const size_t total = totals[me];
 	/* small arrays, or a sorter without segmented sorts: one exchange, one plain sort (the sub-buckets of a destination are neighbours in `send`) */
-	const int sliced = ss->segmented && grand / (uint64_t) G >= SHARD_SLICE_MIN_PER_RANK;
+	const int sliced = ss->segmented && grand > 0 && grand / (uint64_t) G * (uint64_t) es >= ss->slice_min_bytes;
 	int use = 1;
 	if (sliced) {
 		adaptive_sample(ss, M, G);

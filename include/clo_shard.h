@@ -28,8 +28,10 @@
  * of the same keys makes (4 for uint, 8 for ulong) — the exchange is what a sharded sort
  * adds, not a pass. (Round 3 partitioned on log2(G S) <= 6 bits and sorted every slice
  * on the full key width: one pass more, and S mid-size sorts instead of shared launches.)
- * Arrays below 2^22 keys per rank (global mean) and sorters whose radix is neither 16 nor
- * 256 use one exchange and one plain sort of the whole bucket.
+ * Arrays below 256 MiB of keys per rank (global mean: where a segmented sort of 256
+ * sub-buckets starts to beat a plain sort of the whole bucket, measured; the option
+ * `slice_min=<bytes>` moves it) and sorters whose radix is neither 16 nor 256 use one
+ * exchange and one plain sort of the whole bucket.
  * The two exchanges go through a small table of functions (CloShardTransport):
  * RCCL in production (clo_shard_transport_new_rccl), anything else that moves the
  * same bytes in tests (two ranks on one GPU cannot use RCCL).
@@ -108,7 +110,7 @@ typedef struct clo_shard_sort CloShardSort;
 
 /* elem_type: CLO_UINT or CLO_ULONG (the key is the whole element); options: the
  * satradix options of the local sort ("radix=16" ...), `slices=S` (1, 2, 4, 8 or auto —
- * the default, see above) and `loopback=1`: with a world of ONE rank, run the whole
+ * the default, see above), `slice_min=<bytes per rank>` (see above) and `loopback=1`: with a world of ONE rank, run the whole
  * protocol all the same, the rank sending every slice to itself through the transport
  * (a rehearsal of config 5's code path on a one-GPU box; without it one rank takes a
  * shortcut: copy + local sort). The transport stays the caller's. */

@@ -203,7 +203,7 @@ def test_fuzz_sharded_sort_loopback(gpu, seed):
         dt, tdt = (np.uint32, np.int32) if etype == "uint" else (np.uint64, np.int64)
         top = int(np.iinfo(dt).max)
         opt = [None, "slices=1", "slices=2", "slices=4", "slices=8", "radix=256,slices=4"][int(rng.integers(0, 6))]
-        s = CShardedSorter(etype, 0, options=(opt + "," if opt else "") + "loopback=1")
+        s = CShardedSorter(etype, 0, options=(opt + "," if opt else "") + "loopback=1,slice_min=%d" % (16 << 20))
         for case in range(6):
             n = int(rng.choice([0, 1, 70000, (1 << 22) - 3, (1 << 22) + 4099, (1 << 23) + 17]))
             mode = int(rng.integers(0, 6))

@@ -264,7 +264,7 @@ def _shard_worker(rank, world, port, etype, n, options, fail, out_dir):
             a[: a.size // 3] |= dt(1) << dt(bits - 1)              # uneven buckets
             a[a.size // 3: a.size // 2] &= dt((1 << (bits - 3)) - 1)   # and one sub-bucket much fuller than the others
         local = torch.from_numpy(a.view(tdt).copy()).cuda()
-        s = CShardedSorter(etype, 0, transport=tr, options=options)
+        s = CShardedSorter(etype, 0, transport=tr, options=(options + "," if options else "") + "slice_min=16777216")   # (slices from 16 MiB per rank on: the default, 256 MiB, is a size for a node)
         text = ""
         if fail:
             # a failure of ONE rank's own: stage 1 — its arguments are wrong (numel beyond its buffer), found before the
@@ -354,7 +354,7 @@ def test_c_shard_sort_slices_over_real_rccl_world_one(gpu, monkeypatch, etype, o
     n = (1 << 23) + 4099
     a = np.random.default_rng(17).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
     t = torch.from_numpy(a.view(tdt).copy()).cuda()
-    s = CShardedSorter(etype, 0, options=(options + "," if options else "") + "loopback=1")   # (one rank alone would skip the exchange)
+    s = CShardedSorter(etype, 0, options=(options + "," if options else "") + "loopback=1,slice_min=16777216")   # (one rank alone would skip the exchange)
     for rep in range(2):                                   # (the second call reuses every buffer and event)
         out, m = s.sort(t)
         s.check()
@@ -380,7 +380,7 @@ def test_c_shard_sort_slices_without_keys(gpu, etype, where):
     a = np.random.default_rng(23).integers(0, np.iinfo(dt).max, n, dtype=dt, endpoint=True) >> dt(2)
     a |= dt({"low": 0, "middle": 2, "high": 3}[where]) << dt(bits - 2)
     t = torch.from_numpy(a.view(tdt).copy()).cuda()
-    s = CShardedSorter(etype, 0, options="slices=4,loopback=1")
+    s = CShardedSorter(etype, 0, options="slices=4,loopback=1,slice_min=16777216")
     for rep in range(2):
         out, m = s.sort(t)
         s.check()

@@ -12,8 +12,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the pipelines' size thresholds, shrunk so that a run takes seconds (the product's values: 2^24, 2^25, 2^24, 2^22)
-SHRINK = ["-DSAT_PIPE_MIN_NUMEL=4096", "-DCLO_SCAN_PIPE_MIN_NUMEL=65536", "-DCLO_SCAN_PIPE_CHUNK_MAX=16384", "-DSHARD_SLICE_MIN_PER_RANK=2048"]
+# the pipelines' size thresholds, shrunk so that a run takes seconds (the product's values: 2^24, 2^25, 2^24 elements, 256 MiB per rank)
+SHRINK = ["-DSAT_PIPE_MIN_NUMEL=4096", "-DCLO_SCAN_PIPE_MIN_NUMEL=65536", "-DCLO_SCAN_PIPE_CHUNK_MAX=16384", "-DSHARD_SLICE_MIN_BYTES_PER_RANK=8192"]
 
 
 def _build(tmp_path, name, flags):

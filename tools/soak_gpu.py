@@ -30,7 +30,7 @@ def main():
     ]
     import torch
     from cl_ops_amd.multigpu import CShardedSorter
-    objs += [("shard", "uint", CShardedSorter("uint", 0, options="loopback=1")), ("shard", "ulong", CShardedSorter("ulong", 0, options="loopback=1,slices=4")),
+    objs += [("shard", "uint", CShardedSorter("uint", 0, options="loopback=1,slice_min=%d" % (16 << 20))), ("shard", "ulong", CShardedSorter("ulong", 0, options="loopback=1,slices=4,slice_min=%d" % (32 << 20))),
              ("hostsort", "uint", objs[0][2]), ("hostsort", "ulong", objs[1][2])]
     cap = 1 << 25
     src, dst = clo.Buffer(ctx, cap * 8), clo.Buffer(ctx, cap * 8)
