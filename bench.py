@@ -222,7 +222,7 @@ def cpu_baseline(workload, host_input, radix, sample_log2n):
     sample of the same input, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = min(len(os.sched_getaffinity(0)), 16)  # the box's CPU share for one GPU
+    cores = len(os.sched_getaffinity(0))   # every core this process may run on (SURVEY §8d: "all host cores, core count printed")
     m = min(host_input.size, 1 << sample_log2n)
     sample = host_input[:m]
     t0 = time.perf_counter()
@@ -240,14 +240,13 @@ def cpu_baseline(workload, host_input, radix, sample_log2n):
         ok = bool(out[1] == sample[0])
     else:
         t0 = time.perf_counter()
-        out, _ = O.abitonic(sample, dev_max_lws=256) if workload == "abitonic" else (O.sbitonic(sample), 0)
-        cores = 1
+        out, _ = O.abitonic(sample, dev_max_lws=256, threads=cores) if workload == "abitonic" else (O.sbitonic(sample, threads=cores), 0)
         ok = bool(np.all(out[:-1] <= out[1:]))
     dt = time.perf_counter() - t0
     unit = "MValues/s" if workload == "scan" else "Mkeys/s"
     return {"value": round(m / dt / 1e6, 3), "unit": unit, "cores": cores, "kind": "port",
             "sample": "first 2^%d elements of the same input, oracle/clo_oracle.c %s, %.1f s%s"
-                      % (int(np.log2(m)), "OpenMP" if cores > 1 else "serial", dt, "" if ok else " (CHECK FAILED)")}
+                      % (int(np.log2(m)), ("OpenMP on all %d cores of the affinity mask" % cores) if cores > 1 else "serial", dt, "" if ok else " (CHECK FAILED)")}
 
 
 # ----------------------------------------------------------------------------
@@ -780,7 +779,7 @@ def single_leg(workload, log2n, steps, warmup, radix, seed, cpu_sample_log2n=Non
     if with_cpu:
         # sized for about 10-30 core-seconds of CPU work
         default_sample = {"satradix_u32": 28, "satradix_pairs": 27, "satradix_u64": 26, "scan": 26,
-                          "abitonic": 20, "sbitonic": 16}[workload]
+                          "abitonic": 24, "sbitonic": 16}[workload]
         out["cpu_baseline"] = cpu_baseline(workload, host, radix, min(cpu_sample_log2n or default_sample, log2n))
     return out
 
@@ -809,13 +808,15 @@ def shard_world1_leg(etype, log2n, steps, warmup, radix, seed, slices=0):
         s.check()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        # (the result buffer belongs to the object and is only valid until the next call: copy it out NOW, before the
+        # phase loop sorts again — with adaptive slices or a grow it may even be reallocated)
+        got = out_t[:m].cpu().numpy().view(host.dtype)
         s.phase_times = {}
         for _ in range(steps):
             s.sort(src)
         torch.cuda.synchronize()
         phases = {k: v / steps for k, v in s.collect_phase_times().items()}
         x = s.ss.exchange()
-        got = out_t[:m].cpu().numpy().view(host.dtype)
         ok = m == n and bool(np.all(got[:-1] <= got[1:]))
         ok = ok and int(np.bitwise_xor.reduce(got)) == int(np.bitwise_xor.reduce(host))
         ok = ok and int(got.sum(dtype=np.uint64)) == int(host.sum(dtype=np.uint64))
@@ -833,6 +834,7 @@ def shard_world1_leg(etype, log2n, steps, warmup, radix, seed, slices=0):
             "slices": x["slices"], "exchange_device_ms": round(x["ms"], 4),
             "phases_ms": {k: round(v * 1e3, 4) for k, v in sorted(phases.items())},
             # bytes a plain local sort of the same keys must move at least / the local_sort phase; the whole step adds the exchange's copy
+            # (with slices > 1 the local_sort phase includes the stream's waits for the later slices: a lower bound of the sort's rate)
             "local_sort_frac": round(ls_bytes / ls_s / HBM_PEAK, 4) if ls_s > 0 else None,
             "step_frac": round((ls_bytes + 2 * n * es) / (ms_step * 1e-3) / HBM_PEAK, 4)}
 

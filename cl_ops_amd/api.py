@@ -141,11 +141,13 @@ SHARD_A2A = C.CFUNCTYPE(ci, vp, vp, C.POINTER(sz), C.POINTER(sz), vp, C.POINTER(
 SHARD_DESTROY = C.CFUNCTYPE(None, vp)
 SHARD_ALLOC = C.CFUNCTYPE(vp, vp, sz)
 SHARD_FREE = C.CFUNCTYPE(None, vp, vp)
+SHARD_ASYNC = C.CFUNCTYPE(ci, vp)
 
 
 class ShardTransportStruct(C.Structure):
     _fields_ = [("user", vp), ("rank", ci), ("world", ci), ("all_gather_u64", SHARD_AG), ("all_to_all_v", SHARD_A2A),
-                ("destroy", SHARD_DESTROY), ("abort", SHARD_DESTROY), ("recv_alloc", SHARD_ALLOC), ("recv_free", SHARD_FREE)]
+                ("destroy", SHARD_DESTROY), ("abort", SHARD_DESTROY), ("recv_alloc", SHARD_ALLOC), ("recv_free", SHARD_FREE),
+                ("async_error", SHARD_ASYNC)]
 
 
 _sig("clo_shard_rccl_unique_id", _u32, vp, _E)
@@ -155,6 +157,7 @@ _sig("clo_shard_sort_new", vp, vp, C.POINTER(ShardTransportStruct), ci, C.c_char
 _sig("clo_shard_sort_destroy", None, vp)
 _sig("clo_shard_sort_with_device_data", vp, vp, vp, vp, sz, C.POINTER(vp), C.POINTER(sz), _E)
 _sig("clo_shard_sort_get_phase_ms", None, vp, C.POINTER(C.c_double * 4))
+_sig("clo_shard_sort_finish", _u32, vp, vp, C.c_uint, _E)
 _sig("clo_shard_plan", None, C.POINTER(C.c_uint64), ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
 _sig("clo_shard_plan_slice", sz, C.POINTER(C.c_uint64), sz, ci, ci, ci, ci, ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
      C.POINTER(sz), C.POINTER(sz), C.POINTER(sz))
@@ -482,11 +485,12 @@ class ShardTransport:
         return cls(p)
 
     @classmethod
-    def custom(cls, rank, world, all_gather_u64, all_to_all_v, recv_alloc=None, recv_free=None):
+    def custom(cls, rank, world, all_gather_u64, all_to_all_v, recv_alloc=None, recv_free=None, async_error=None):
         """all_gather_u64(send_ptr, recv_ptr, count, stream) -> status;
         all_to_all_v(send_ptr, send_bytes, send_off, recv_ptr, recv_bytes, recv_off, stream) -> status
         (the four arrays as Python lists of `world` ints); optional recv_alloc(bytes) -> device pointer or None,
-        recv_free(ptr): the transport's own memory for the receive buffers."""
+        recv_free(ptr): the transport's own memory for the receive buffers; async_error() -> 0 or a status, polled by the
+        sort's bounded waits."""
         def ag(user, s, r, count, stream):
             return int(all_gather_u64(s, r, count, stream) or 0)
 
@@ -502,9 +506,13 @@ class ShardTransport:
 
         def rf(user, ptr):
             recv_free(ptr)
+
+        def ae(user):
+            return int(async_error() or 0)
         st = ShardTransportStruct(None, rank, world, SHARD_AG(ag), SHARD_A2A(a2a), SHARD_DESTROY(), SHARD_DESTROY(ab),
-                                  SHARD_ALLOC(ra) if recv_alloc else SHARD_ALLOC(), SHARD_FREE(rf) if recv_free else SHARD_FREE())
-        t = cls(C.pointer(st), keep=(st, ag, a2a, ab, ra, rf), owned=False)
+                                  SHARD_ALLOC(ra) if recv_alloc else SHARD_ALLOC(), SHARD_FREE(rf) if recv_free else SHARD_FREE(),
+                                  SHARD_ASYNC(ae) if async_error else SHARD_ASYNC())
+        t = cls(C.pointer(st), keep=(st, ag, a2a, ab, ra, rf, ae), owned=False)
         t.aborted = aborted          # non-empty once the C driver has asked for an abort
         return t
 
@@ -533,6 +541,15 @@ class ShardSort:
                                             C.byref(out), C.byref(m), err.ref)
         err.raise_if_set()
         return lib.ccl_buffer_get_device_ptr(out), m.value
+
+    def finish(self, q_exec, timeout_ms=0):
+        """Bounded wait for what the last call left running (clo_shard_sort_finish); raises CloError when the time is up or
+        the transport has failed — this rank's side of the transport is aborted then."""
+        err = _Err()
+        ok = lib.clo_shard_sort_finish(self.h, q_exec.h, int(timeout_ms), err.ref)
+        err.raise_if_set()
+        if not ok:
+            raise CloError("clo", CLO_ERROR_LIBRARY, "clo_shard_sort_finish failed")
 
     def phase_ms(self):
         a = (C.c_double * 4)()

@@ -15,7 +15,9 @@
 #include "clo_shard.h"
 #include "clo_internal.h"
 
+#include <sched.h>
 #include <string.h>
+#include <time.h>
 
 #define SHARD_MAX_WORLD 8
 #define SHARD_MAX_SLICES 8
@@ -42,6 +44,8 @@ struct clo_shard_sort {
 	int elem_size, bucket_bits, subs;     /* subs = SHARD_SUBS / world: sub-buckets (segments) per rank */
 	int slices_opt;                       /* 1, 2, 4, 8 as asked for, 0 = adaptive, -1 = one rank without loopback: no exchange */
 	uint64_t slice_min_bytes;             /* per rank (global mean): below it one exchange + a plain sort */
+	unsigned timeout_ms;                  /* bound of every host wait for the peers; 0 = none */
+	int dead;                             /* a wait gave up and the transport was aborted: only destroy is left */
 	int segmented;                        /* the sorter runs segmented sorts (radix 16 / 256) */
 	clo_devbuf send, workspace, counts;   /* partitioned shard; partition workspace; my row + the gathered rows (uint64) */
 	CCLBuffer* recv;                      /* what arrives (owned; grown on demand; from the transport's recv_alloc when it has one) */
@@ -65,6 +69,7 @@ struct clo_shard_sort {
 	double best_us[4];                    /* by log2(slices): best device time seen (max over ranks), 0 = none */
 	int tried[4];
 	uint64_t class_total;                 /* the global key count the table was built for */
+	uint64_t class_seq;                   /* the call that started this size class: samples of earlier calls belong to another */
 };
 
 /* ---------------- RCCL transport ---------------- */
@@ -87,6 +92,11 @@ static int rccl_all_to_all_v(void* user, const void* send, const size_t* sb, con
 static void rccl_abort(void* user) {
 	rccl_user* u = (rccl_user*) user;
 	if (u && u->comm) { clo_hip_rccl_comm_abort(u->comm); u->comm = NULL; }
+}
+
+static int rccl_async_error(void* user) {
+	rccl_user* u = (rccl_user*) user;
+	return (u && u->comm) ? clo_hip_rccl_comm_async_error(u->comm) : 0;
 }
 
 static void rccl_destroy(void* user) {
@@ -115,6 +125,7 @@ CloShardTransport* clo_shard_transport_new_rccl(const void* id, int rank, int wo
 	t->all_to_all_v = rccl_all_to_all_v;
 	t->destroy = rccl_destroy;
 	t->abort = rccl_abort;
+	t->async_error = rccl_async_error;
 	return t;
 }
 
@@ -175,11 +186,12 @@ size_t clo_shard_plan_slice(const uint64_t* counts, size_t row, int world, int s
 
 /* ---------------- the object ---------------- */
 
-/* "slices=S", "loopback=0|1" and "slice_min=BYTES" are ours, the rest goes to satradix. Returns a malloc'd copy of the rest, or NULL on a bad value. */
-static char* shard_options(const char* options, int* slices, int* loopback, uint64_t* slice_min, GError** err) {
+/* "slices=S", "loopback=0|1", "slice_min=BYTES" and "timeout_ms=N" are ours, the rest goes to satradix. Returns a malloc'd copy of the rest, or NULL on a bad value. */
+static char* shard_options(const char* options, int* slices, int* loopback, uint64_t* slice_min, unsigned* timeout_ms, GError** err) {
 	*slices = 0;
 	*loopback = 0;
 	*slice_min = SHARD_SLICE_MIN_BYTES_PER_RANK;
+	*timeout_ms = 0;
 	const size_t len = options ? strlen(options) : 0;
 	char* rest = (char*) calloc(len + 1, 1);
 	if (!rest) return NULL;
@@ -203,6 +215,14 @@ static char* shard_options(const char* options, int* slices, int* loopback, uint
 			*loopback = atoi(p + 9) != 0;
 		} else if (n > 10 && strncmp(p, "slice_min=", 10) == 0) {
 			*slice_min = (uint64_t) strtoull(p + 10, NULL, 10);
+		} else if (n > 11 && strncmp(p, "timeout_ms=", 11) == 0) {
+			const long long v = atoll(p + 11);
+			if (v < 0 || v > 0x7fffffffll) {
+				clo_gerror_set(err, CLO_ERROR, CLO_ERROR_ARGS, "timeout_ms must be between 0 and 2^31 - 1 (got '%.*s')", (int) (n - 11), p + 11);
+				free(rest);
+				return NULL;
+			}
+			*timeout_ms = (unsigned) v;
 		} else if (n > 0) {
 			if (rest[0]) strcat(rest, ",");
 			strncat(rest, p, n);
@@ -230,7 +250,8 @@ CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, 
 	}
 	int slices = 0, loopback = 0;
 	uint64_t slice_min = 0;
-	char* sort_options = shard_options(options, &slices, &loopback, &slice_min, err);
+	unsigned timeout_ms = 0;
+	char* sort_options = shard_options(options, &slices, &loopback, &slice_min, &timeout_ms, err);
 	if (!sort_options) return NULL;
 	/* (one rank has nothing to exchange; `loopback=1` sends the rank's keys to itself through the whole
 	 * protocol: a rehearsal of the exchange over the transport on a one-GPU box) */
@@ -249,6 +270,7 @@ CloShardSort* clo_shard_sort_new(CCLContext* ctx, CloShardTransport* transport, 
 	ss->subs = SHARD_SUBS / world;
 	ss->slices_opt = slices;
 	ss->slice_min_bytes = slice_min;
+	ss->timeout_ms = timeout_ms;
 	{   /* does this sorter run segmented sorts (radix 16 / 256)? Otherwise: one exchange and a plain sort, always */
 		const clo_sort_impl_ext* ext = clo_sort_impl_ext_find("satradix");
 		int handled = 0;
@@ -350,7 +372,15 @@ static int shard_prepare_events(CloShardSort* ss) {
 static cl_bool shard_reserve_sorter(CloShardSort* ss, CCLQueue* cq_exec, size_t cap, GError** err) {
 	const clo_sort_impl_ext* ext = clo_sort_impl_ext_find("satradix");
 	if (!ext) return CL_TRUE;
-	if (ext->reserve && !ext->reserve(ss->sorter, cq_exec, cap, err)) return CL_FALSE;   /* one exchange + plain sort (small arrays) */
+	/* one exchange + plain sort: only calls whose mean shard is below slice_min take it, and a rank's bucket is then at most
+	 * G times that mean — with segmented sorts there is no need for the plain sort's partner buffer beyond that size
+	 * (config 5: 2.5 GiB per rank that the sliced path never touches) */
+	size_t plain_cap = cap;
+	if (ss->segmented) {
+		const uint64_t most = (uint64_t) ss->t->world * (ss->slice_min_bytes / (uint64_t) ss->elem_size + 1u);
+		if (most < (uint64_t) plain_cap) plain_cap = (size_t) most;
+	}
+	if (ext->reserve && !ext->reserve(ss->sorter, cq_exec, plain_cap, err)) return CL_FALSE;
 	if (ss->segmented && ext->reserve_segments) {
 		int handled = 0;
 		if (!ext->reserve_segments(ss->sorter, cq_exec, cap, ss->subs, &handled, err)) return CL_FALSE;
@@ -360,6 +390,47 @@ static cl_bool shard_reserve_sorter(CloShardSort* ss, CCLQueue* cq_exec, size_t 
 
 /* This rank cannot go on and its peers may already be inside a collective: end the transport. */
 static void shard_abort(CloShardSort* ss) {
+	if (ss->t->abort) ss->t->abort(ss->t->user);
+}
+
+/* ---- bounded waits ----
+ * Waiting for a stream that carries a collective is waiting for the PEERS: one that never joins (a crashed process) or
+ * that aborted leaves hipStreamSynchronize blocked for ever. So the host polls instead — the stream(s), and the
+ * transport's asynchronous error state (RCCL: ncclCommGetAsyncError) — and gives up when `timeout_ms` have passed.
+ * 0 = done; CLO_HIP_ENOTREADY = the time is up; anything else = a stream's or the transport's error. Without a
+ * bound and without an async_error hook this is the plain blocking wait of rounds 3-4. */
+static double shard_now_ms(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double) ts.tv_sec * 1e3 + (double) ts.tv_nsec * 1e-6;
+}
+
+static int shard_wait_streams(CloShardSort* ss, void* s0, void* s1, unsigned timeout_ms) {
+	if (timeout_ms == 0 && !ss->t->async_error) {
+		int st = s0 ? clo_hip_stream_synchronize(s0) : 0;
+		if (st == 0 && s1) st = clo_hip_stream_synchronize(s1);
+		return st;
+	}
+	const double t0 = shard_now_ms();
+	for (unsigned spins = 0; ; ++spins) {
+		int st = s0 ? clo_hip_stream_query(s0) : 0;
+		if (st == 0 && s1) st = clo_hip_stream_query(s1);
+		if (st != CLO_HIP_ENOTREADY) return st;
+		if (ss->t->async_error && (st = ss->t->async_error(ss->t->user)) != 0) return st;
+		const double waited = shard_now_ms() - t0;
+		if (timeout_ms != 0 && waited >= (double) timeout_ms) return CLO_HIP_ENOTREADY;
+		if (waited < 2.0) sched_yield();   /* (the count exchange sits on the call's critical path: no sleeping while it is young) */
+		else { const struct timespec nap = { 0, 50000 }; nanosleep(&nap, NULL); }
+	}
+}
+
+/* The wait `what` ended in `st` != 0: this rank leaves the transport (its peers' bounded waits, or their async_error, tell them). */
+static void shard_wait_failed(CloShardSort* ss, int st, unsigned timeout_ms, const char* what, GError** err) {
+	if (st == CLO_HIP_ENOTREADY)
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "timed out after %u ms waiting for %s (a peer did not take part): this rank's side of the transport was aborted", timeout_ms, what);
+	else
+		clo_hip_failed(st, err, what);
+	ss->dead = 1;
 	if (ss->t->abort) ss->t->abort(ss->t->user);
 }
 
@@ -374,6 +445,9 @@ static int slice_log2(int s) { return s == 1 ? 0 : s == 2 ? 1 : s == 4 ? 2 : 3; 
 static void adaptive_sample(CloShardSort* ss, const uint64_t* M, int G) {
 	const uint64_t seq0 = M[SHARD_SUBS + 2];
 	if (seq0 == 0 || seq0 <= ss->sampled_seq) return;
+	/* (a call's time arrives two calls later: after a change of size class the one or two samples still on their way are
+	 * the OLD class's — best_us is a minimum that never expires, a much smaller array's time would bias it for good) */
+	if (seq0 < ss->class_seq) return;
 	uint64_t us = 0;
 	for (int p = 0; p < G; ++p) {
 		const uint64_t* tail = M + (size_t) p * SHARD_ROW + SHARD_SUBS;
@@ -390,6 +464,7 @@ static void adaptive_sample(CloShardSort* ss, const uint64_t* M, int G) {
 static int adaptive_choose(CloShardSort* ss, uint64_t grand) {
 	if (ss->class_total == 0 || grand > 2 * ss->class_total || 2 * grand < ss->class_total) {   /* another size class: start over */
 		ss->class_total = grand;
+		ss->class_seq = ss->seq;   /* (the call in progress: the first of the new class) */
 		for (int i = 0; i < 4; ++i) { ss->best_us[i] = 0.0; ss->tried[i] = 0; }
 	}
 	static const int order[4] = { 4, 2, 1, 8 };
@@ -431,6 +506,10 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 	void* stream = ccl_queue_get_stream(cq_exec);
 	const size_t bytes = numel * (size_t) es;
 	ss->have_phase = 0;
+	if (ss->dead) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "an earlier wait of this sharded sort gave up and aborted its transport: destroy it");
+		return NULL;
+	}
 
 	if (ss->slices_opt < 0) {   /* one rank, nothing to exchange: a copy and the local sort */
 		if (numel > 0 && bytes > ccl_buffer_get_size(data_in)) {
@@ -512,11 +591,15 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 	st = clo_hip_memcpy_h2d_async(my_row + SHARD_SUBS, ss->tail_host, sizeof(ss->tail_host), stream);
 	if (st == 0) st = ss->t->all_gather_u64(ss->t->user, my_row, all_rows, row, stream);
 	if (st == 0) st = clo_hip_memcpy_d2h_async(ss->counts_host, all_rows, (size_t) G * row * sizeof(uint64_t), stream);
-	if (st == 0) st = clo_hip_stream_synchronize(stream);
 	if (st != 0) {   /* the exchange itself is broken: nothing left to agree through */
 		clo_gerror_free(local);
 		clo_hip_failed(st, err, "all-gather of the bucket counts");
 		shard_abort(ss);
+		return NULL;
+	}
+	if ((st = shard_wait_streams(ss, stream, NULL, ss->timeout_ms)) != 0) {   /* (bounded: a peer that never joins must not hang this rank) */
+		clo_gerror_free(local);
+		shard_wait_failed(ss, st, ss->timeout_ms, "the all-gather of the bucket counts", err);
 		return NULL;
 	}
 	const uint64_t* M = ss->counts_host;
@@ -578,11 +661,15 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 		st = clo_hip_memcpy_h2d_async(my_row, ss->tail_host, sizeof(uint64_t), stream);
 		if (st == 0) st = ss->t->all_gather_u64(ss->t->user, my_row, all_rows, 1, stream);
 		if (st == 0) st = clo_hip_memcpy_d2h_async(ss->grow_host, all_rows, (size_t) G * sizeof(uint64_t), stream);
-		if (st == 0) st = clo_hip_stream_synchronize(stream);
 		if (st != 0) {
 			clo_gerror_free(local);
 			clo_hip_failed(st, err, "agreement after growing the receive buffers");
 			shard_abort(ss);
+			return NULL;
+		}
+		if ((st = shard_wait_streams(ss, stream, NULL, ss->timeout_ms)) != 0) {
+			clo_gerror_free(local);
+			shard_wait_failed(ss, st, ss->timeout_ms, "the agreement after growing the receive buffers", err);
 			return NULL;
 		}
 		for (int p = 0; p < G; ++p) {
@@ -691,4 +778,21 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 	*data_out = out_buf;
 	*numel_out = total;
 	return evt;
+}
+
+cl_bool clo_shard_sort_finish(CloShardSort* ss, CCLQueue* cq_exec, unsigned timeout_ms, GError** err) {
+	clo_return_val_if_fail(ss != NULL && cq_exec != NULL, CL_FALSE);
+	clo_return_val_if_fail(err == NULL || *err == NULL, CL_FALSE);
+	if (ss->dead) {
+		clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "an earlier wait of this sharded sort gave up and aborted its transport: destroy it");
+		return CL_FALSE;
+	}
+	if (timeout_ms == 0) timeout_ms = ss->timeout_ms;
+	/* the transfer stream first (what the peers owe this rank), then cq_exec (the sorts that wait for it) */
+	const int st = shard_wait_streams(ss, ss->slices_opt < 0 ? NULL : ss->comm_stream, ccl_queue_get_stream(cq_exec), timeout_ms);
+	if (st != 0) {
+		shard_wait_failed(ss, st, timeout_ms, "the key exchange and the local sorts", err);
+		return CL_FALSE;
+	}
+	return ccl_queue_finish(cq_exec, err);   /* (returns at once; reports what the sorts left in their status words) */
 }

@@ -463,6 +463,9 @@ static cl_bool clo_sort_satradix_host_pipeline(CloSort* sorter, CCLQueue* cq_exe
 			what = "clo_hip_radix_sort_segmented";
 			st = clo_hip_radix_sort_segmented(r->part.ptr, passes % 2 ? data->tmp.ptr : final, passes % 2 ? final : data->tmp.ptr, tot, seg_counts, per,
 				pn, po, ps, np, es, ks->key_shift, rest, bits_in_digit, data->seg_ws.ptr, data->seg_ws.bytes, s_exec, &in_b);
+			/* (which buffer ends up holding the result follows from the pass count; the two were chosen above from THIS
+			 * file's count — should the sort's pass schedule ever differ, fail loudly rather than copy out the wrong one) */
+			if (st == 0 && in_b != passes % 2) { what = "clo_hip_radix_sort_segmented (result buffer parity)"; st = CLO_HIP_EARGS; }
 		}
 		what = seg ? what : "hipMemcpyAsync(d2d)";
 		for (int c = 0; c < nchunks && st == 0 && !seg; ++c) {

@@ -105,6 +105,17 @@ int clo_hip_bitonic_tiled(void* data, size_t numel, int elem_size,
 	}
 }
 
+size_t clo_hip_bitonic_lds_bytes(size_t numel, int elem_size, int tiled) {
+	if (!tiled) return 0;   // one launch per (stage, step): registers only
+	switch (elem_size) {
+		case 1: return tiled_lds_bytes<uint8_t>(numel);
+		case 2: return tiled_lds_bytes<uint16_t>(numel);
+		case 4: return tiled_lds_bytes<uint32_t>(numel);
+		case 8: return tiled_lds_bytes<uint64_t>(numel);
+		default: return 0;
+	}
+}
+
 size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) {
 	if (!family) return 0;
 	const std::string f(family);

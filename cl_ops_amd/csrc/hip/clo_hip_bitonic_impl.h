@@ -775,6 +775,22 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 	return (int) hipGetLastError();
 }
 
+// Static LDS per work-group of the kernels tiled_run launches for `numel` elements (introspection:
+// clo_sort_get_localmem_usage of sbitonic / abitonic) — the same three cases as above: below 2^Q elements the
+// one-launch-per-step kernels (registers only); up to one tile the run-time-schedule kernel, whose array is sized for
+// 256 threads x 2^Q values whatever the tile it is given; from 2^KLF elements on the compile-time-schedule kernels
+// (presort, merge, two-level strided), all on tiles of 2^KLF elements. One padding slot per 32.
+template <typename E>
+size_t tiled_lds_bytes(size_t numel) {
+	constexpr int Q = sizeof(E) == 8 ? 4 : 5;
+	constexpr unsigned TBF = 9, KLF = TBF + Q;
+	const size_t n = nlpo2(numel ? numel : 1);
+	const unsigned T = log2u(n);
+	if (T < (unsigned) Q) return 0;
+	const size_t tile = T < KLF ? ((size_t) 256 << Q) : ((size_t) 1 << KLF);
+	return (tile + tile / 32) * sizeof(E);
+}
+
 template <typename E>
 int tiled_impl(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, hipStream_t s) {

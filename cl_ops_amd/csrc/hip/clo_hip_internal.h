@@ -177,22 +177,48 @@ __device__ __forceinline__ unsigned clo_mbcnt(clo_u64 mask) {
 		__builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
 }
 
-template <typename T>
-__device__ __forceinline__ T clo_wave_reduce_sum(T x) {
-	#pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-	return x;
+// Wave64 prefix sums of INTEGER values (32 or 64 bits) on the DPP network — four shifts inside the rows of 16 lanes,
+// two row broadcasts — with no LDS traffic and nothing to wait for. (Rounds 1-4 went through __shfl_up, i.e. one
+// ds_bpermute_b32 per step and `s_waitcnt lgkmcnt(0)` behind each: six dependent LDS round trips per scan, 48 of them per
+// tile in the scan kernel. Integer addition is associative: the sums are the same bits.)
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T clo_dpp_add(T x) {
+	static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit integers");
+	if constexpr (sizeof(T) == 4) {
+		return (T) ((unsigned) x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true));
+	} else {
+		const unsigned long long v = (unsigned long long) x;
+		const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) v, CTRL, ROW_MASK, 0xF, true);
+		const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) (v >> 32), CTRL, ROW_MASK, 0xF, true);
+		return (T) (v + (((unsigned long long) hi << 32) | lo));
+	}
 }
 
 // Inclusive scan across the 64 lanes of a wave.
 template <typename T>
 __device__ __forceinline__ T clo_wave_scan_inclusive(T x, unsigned lane) {
-	#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		T y = __shfl_up(x, off, 64);
-		if (lane >= (unsigned) off) x += y;
-	}
+	(void) lane;
+	x = clo_dpp_add<0x111, 0xF>(x);   // row_shr:1
+	x = clo_dpp_add<0x112, 0xF>(x);   // row_shr:2
+	x = clo_dpp_add<0x114, 0xF>(x);   // row_shr:4
+	x = clo_dpp_add<0x118, 0xF>(x);   // row_shr:8
+	x = clo_dpp_add<0x142, 0xA>(x);   // row_bcast:15 into rows 1 and 3
+	x = clo_dpp_add<0x143, 0xC>(x);   // row_bcast:31 into rows 2 and 3
 	return x;
+}
+
+// Sum over the 64 lanes, in every lane (wave-uniform: it comes back through a scalar register).
+template <typename T>
+__device__ __forceinline__ T clo_wave_reduce_sum(T x) {
+	const T incl = clo_wave_scan_inclusive<T>(x, 0u);
+	if constexpr (sizeof(T) == 4) {
+		return (T) (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
+	} else {
+		const unsigned long long v = (unsigned long long) incl;
+		const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) v, 63);
+		const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (v >> 32), 63);
+		return (T) (((unsigned long long) hi << 32) | lo);
+	}
 }
 
 #endif  // __HIPCC__

@@ -203,7 +203,7 @@ void clo_radix1_sweep_kernel(const E* __restrict__ in, E* __restrict__ out, size
 	__shared__ __attribute__((aligned(16))) E s_stage[TILE];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][HMAX];
-	__shared__ unsigned s_wbase[WAVES][HMAX];
+	__shared__ __attribute__((aligned(16))) unsigned s_wbase[WAVES][HMAX];
 	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
 	__shared__ unsigned s_w4[4];
 	__shared__ unsigned s_tile;

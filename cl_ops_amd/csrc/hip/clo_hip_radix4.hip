@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "clo_hip.h"
 #include "clo_hip_internal.h"
@@ -74,7 +75,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	constexpr bool ALIAS = pair_shape<E, BIG>::ALIAS;   // the table of ends inside the stage
 	__shared__ unsigned s_end[ALIAS ? 1 : THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][HMAX];
-	__shared__ unsigned s_wbase[WAVES][HMAX];
+	__shared__ __attribute__((aligned(16))) unsigned s_wbase[WAVES][HMAX];
 	__shared__ unsigned s_delta[R2];   // global index = tile-local position + delta[D]
 	__shared__ unsigned s_w4[4];
 
@@ -185,57 +186,75 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	}
 
 	// contiguous runs to HBM: a thread takes VEC consecutive positions of the
-	// sorted tile; inside a run they go out as one 16-byte store
+	// sorted tile; inside a run they go out as one 16-byte store.
+	// Compiled twice, with and without the key transform of the last pass (`kx_out`: signed / floating-point keys):
+	// tested per element it put a chain of scalar branches — and two 64-bit register copies per store — into the
+	// path of every sort (round 5).
 	constexpr int VEC = sizeof(E) >= 8 ? 1 : 4;
 	typedef E vecE __attribute__((ext_vector_type(VEC)));
 	typedef E vecE_u __attribute__((ext_vector_type(VEC), aligned(sizeof(E))));
-	#pragma unroll
-	for (int j = 0; j < ITEMS / VEC; ++j) {
-		const unsigned p = (j * THREADS + tid) * VEC;
-		if (full) {
-			const vecE v = *reinterpret_cast<const vecE*>(&s_stage[p]);
-			const unsigned d0 = (unsigned) (v[0] >> shift) & mask2, dl = (unsigned) (v[VEC - 1] >> shift) & mask2;
-			const unsigned gi0 = p + s_delta[d0];
-			if (d0 == dl && gi0 <= n32 - VEC) {
-				vecE vo = v;
-				if (kx_out.kind) {
+	// Four next digits as one dword. When the next digit is a whole byte of the key (next_shift a multiple of 8: any sort
+	// whose key starts at bit 0, 8, ...) three byte permutes gather them; otherwise shifts and masks.
+	const bool dig_bytes = DIG && VEC == 4 && (next_shift & 7u) == 0u && next_shift < 8u * (unsigned) sizeof(E);
+	const unsigned dig_b = next_shift >> 3;   // (wave-uniform: the selectors live in scalar registers)
+	const unsigned dig_sel_lo = 0x0c0c0400u + dig_b * 0x0101u, dig_sel_hi = 0x04000c0cu + dig_b * 0x01010000u;
+	const unsigned nbits2 = (unsigned) __builtin_popcount(mask2);   // (mask2 is a run of ones from bit 0: a bit-field extract per digit)
+	const auto scatter = [&](auto kx_tag) {
+		constexpr bool KX = decltype(kx_tag)::value;
+		#pragma unroll
+		for (int j = 0; j < ITEMS / VEC; ++j) {
+			const unsigned p = (j * THREADS + tid) * VEC;
+			if (full) {
+				const vecE v = *reinterpret_cast<const vecE*>(&s_stage[p]);
+				const unsigned d0 = pc_digit<E>(v[0], shift, mask2, nbits2), dl = pc_digit<E>(v[VEC - 1], shift, mask2, nbits2);
+				const unsigned gi0 = p + s_delta[d0];
+				if (d0 == dl && gi0 <= n32 - VEC) {
+					vecE vo = v;
+					if constexpr (KX) {
+						#pragma unroll
+						for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(v[k], kx_out);
+					}
+					*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
+					if constexpr (DIG) {
+						if constexpr (VEC == 4) {
+							typedef unsigned u32_u __attribute__((aligned(1)));
+							unsigned dg;
+							if (dig_bytes)
+								dg = __builtin_amdgcn_perm((unsigned) v[1], (unsigned) v[0], dig_sel_lo) | __builtin_amdgcn_perm((unsigned) v[3], (unsigned) v[2], dig_sel_hi);
+							else
+								dg = ((unsigned) (v[0] >> next_shift) & 255u) | (((unsigned) (v[1] >> next_shift) & 255u) << 8)
+									| (((unsigned) (v[2] >> next_shift) & 255u) << 16) | ((unsigned) (v[3] >> next_shift) << 24);
+							*reinterpret_cast<u32_u*>(dig_out + gi0) = dg;
+						} else {
+							dig_out[gi0] = (unsigned char) (v[0] >> next_shift);
+						}
+					}
+				} else {
 					#pragma unroll
-					for (int k = 0; k < VEC; ++k) vo[k] = clo_keyx_inv<E>(v[k], kx_out);
-				}
-				*reinterpret_cast<vecE_u*>(&out[gi0]) = vo;
-				if constexpr (DIG) {
-					if constexpr (VEC == 4) {
-						typedef unsigned u32_u __attribute__((aligned(1)));
-						*reinterpret_cast<u32_u*>(dig_out + gi0) = ((unsigned) (v[0] >> next_shift) & 255u) | (((unsigned) (v[1] >> next_shift) & 255u) << 8)
-							| (((unsigned) (v[2] >> next_shift) & 255u) << 16) | ((unsigned) (v[3] >> next_shift) << 24);
-					} else {
-						dig_out[gi0] = (unsigned char) (v[0] >> next_shift);
+					for (int k = 0; k < VEC; ++k) {
+						const unsigned gi = p + k + s_delta[pc_digit<E>(v[k], shift, mask2, nbits2)];
+						if (gi < n32) {
+							out[gi] = KX ? clo_keyx_inv<E>(v[k], kx_out) : v[k];
+							if constexpr (DIG) dig_out[gi] = (unsigned char) (v[k] >> next_shift);
+						}
 					}
 				}
 			} else {
 				#pragma unroll
 				for (int k = 0; k < VEC; ++k) {
-					const unsigned gi = p + k + s_delta[(unsigned) (v[k] >> shift) & mask2];
-					if (gi < n32) {
-						out[gi] = clo_keyx_inv<E>(v[k], kx_out);
-						if constexpr (DIG) dig_out[gi] = (unsigned char) (v[k] >> next_shift);
-					}
-				}
-			}
-		} else {
-			#pragma unroll
-			for (int k = 0; k < VEC; ++k) {
-				if (p + k < count) {
-					const E e = s_stage[p + k];
-					const unsigned gi = p + k + s_delta[(unsigned) (e >> shift) & mask2];
-					if (gi < n32) {
-						out[gi] = clo_keyx_inv<E>(e, kx_out);
-						if constexpr (DIG) dig_out[gi] = (unsigned char) (e >> next_shift);
+					if (p + k < count) {
+						const E e = s_stage[p + k];
+						const unsigned gi = p + k + s_delta[pc_digit<E>(e, shift, mask2, nbits2)];
+						if (gi < n32) {
+							out[gi] = KX ? clo_keyx_inv<E>(e, kx_out) : e;
+							if constexpr (DIG) dig_out[gi] = (unsigned char) (e >> next_shift);
+						}
 					}
 				}
 			}
 		}
-	}
+	};
+	if (kx_out.kind) scatter(std::true_type()); else scatter(std::false_type());
 }
 
 // ---------------------------------------------------------------------------
@@ -257,7 +276,7 @@ void clo_radix4_small_kernel(const E* in, E* out, unsigned n, unsigned key_shift
 	__shared__ __attribute__((aligned(16))) E s_stage[THREADS * ITEMS];
 	__shared__ unsigned s_end[THREADS * PC_END_STRIDE];
 	__shared__ unsigned s_wtot[WAVES][H];
-	__shared__ unsigned s_wbase[WAVES][H];
+	__shared__ __attribute__((aligned(16))) unsigned s_wbase[WAVES][H];
 
 	const unsigned tbase = threadIdx.x * ITEMS;
 	E key[ITEMS];

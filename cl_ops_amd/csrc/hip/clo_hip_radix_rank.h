@@ -41,7 +41,10 @@ __device__ __forceinline__ unsigned dpp_add(unsigned x) {
 	return x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true);
 }
 
-constexpr int PC_BATCH = 4;        // lookups of ends requested together in a full tile
+#ifndef CLO_PC_BATCH
+#define CLO_PC_BATCH 4
+#endif
+constexpr int PC_BATCH = CLO_PC_BATCH;        // lookups of ends requested together in a full tile
 constexpr int PC_END_STRIDE = 8;   // dwords per thread in the table of ends: 16 digits x 16 bits (digit-major, see pc_local_split)
 
 template <int BITS> struct pc_words { static constexpr int H = (1 << BITS) >= 2 ? (1 << BITS) / 2 : 1; };
@@ -132,15 +135,45 @@ __device__ __forceinline__ void pc_put_byte(unsigned& dst, unsigned x, int K) {
 		default: asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(dst) : "v"(x)); break;
 	}
 }
-__device__ __forceinline__ unsigned pc_sub_byte(unsigned a, unsigned b, int K) {
+// (a - byte K of b) mod 2^16, zero-extended: one SDWA subtract whose destination is the low word (the high one padded with zeros).
+__device__ __forceinline__ unsigned pc_sub_byte16(unsigned a, unsigned b, int K) {
 	unsigned r;
 	switch (K) {
-		case 0: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b)); break;
-		case 1: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b)); break;
-		case 2: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b)); break;
-		default: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b)); break;
+		case 0: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b)); break;
+		case 1: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b)); break;
+		case 2: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b)); break;
+		default: asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b)); break;
 	}
 	return r;
+}
+// Both 16-bit halves of a word at once, each mod 2^16 (no carry from the low half into the high one): a * S + b, a * S.
+typedef unsigned short pc_u16x2 __attribute__((ext_vector_type(2)));
+template <int S>
+__device__ __forceinline__ unsigned pc_pk_scale(unsigned a) {
+	if constexpr (S == 1) return a;
+	const pc_u16x2 r = __builtin_bit_cast(pc_u16x2, a) * (unsigned short) S;
+	return __builtin_bit_cast(unsigned, r);
+}
+template <int S>
+__device__ __forceinline__ unsigned pc_pk_scale_add(unsigned a, unsigned b) {
+	unsigned r;   // (one v_pk_mad_u16; from C the compiler makes a packed shift and a packed add of it)
+	if constexpr (S == 1) asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	else asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"((unsigned) S * 0x00010001u), "v"(b));
+	return r;
+}
+// (x & 0x0f0f0f0f) * S + S * 0x01010101 for S = 1, 2, 4, 8: an and, and one shift-and-add
+template <int S>
+__device__ __forceinline__ unsigned pc_rank_bytes(unsigned x) {
+	x &= 0x0f0f0f0fu;
+	if constexpr (S == 1) {
+		return x + 0x01010101u;
+	} else {
+		unsigned r;
+		constexpr int SH = S == 2 ? 1 : (S == 4 ? 2 : 3);
+		static_assert(S == 2 || S == 4 || S == 8, "element sizes 1, 2, 4, 8");
+		asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(SH), "s"((unsigned) S * 0x01010101u));
+		return r;
+	}
 }
 // The digit of a key: one bit-field extract for elements of up to 4 bytes
 // (nbits = the number of bits of the digit's mask, the same for the whole launch).
@@ -198,8 +231,15 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 		}
 	}
 	const unsigned long long c = run - c2;
+	// Positions are kept as BYTE offsets into the stage, in 16 bits: the table of ends holds end * sizeof(E) mod 2^16
+	// (a tile is at most 64 KiB: only an end at the very end of a 64 KiB tile wraps, to 0), a rank byte holds
+	// (before + 1) * sizeof(E) <= 128, and one SDWA subtract into the low word gives the element's address —
+	// (end - before - 1) * sizeof(E) mod 2^16, always inside the stage — with no decrement, shift or mask per element
+	// (round 5: two VALU instructions per element and split fewer).
+	constexpr unsigned ES = (unsigned) sizeof(E);
+	static_assert((size_t) THREADS * ITEMS * sizeof(E) <= 65536, "byte offsets of the stage fit in 16 bits");
 	#pragma unroll
-	for (int k = 0; k < ITEMS / 4; ++k) rb[k] &= 0x0f0f0f0fu;
+	for (int k = 0; k < ITEMS / 4; ++k) rb[k] = pc_rank_bytes<(int) ES>(rb[k]);
 	counted(c, c2);
 	unsigned w[H];
 	pc2_wave_scan<BITS, (ITEMS > 8)>(c, c2, w);
@@ -243,7 +283,7 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 			#pragma unroll
 			for (int k = 1; k < 4; ++k) if (r * 4 + k < H && q == (unsigned) k) mine = dstart16[r * 4 + k];
 			const unsigned j = r * 4 + q;
-			if (j < (unsigned) H && wv < (unsigned) WAVES) s_wbase[wv][j] = mine + excl[r];
+			if (j < (unsigned) H && wv < (unsigned) WAVES) s_wbase[wv][j] = pc_pk_scale<(int) ES>(mine + excl[r]);   // (bytes, see above)
 		}
 	}
 	mid();
@@ -257,13 +297,26 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 	// writes, half of the kernel's LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT.)
 	typedef unsigned short __attribute__((may_alias)) pc_u16;   // (the array is declared as dwords)
 	pc_u16* const tab = reinterpret_cast<pc_u16*>(s_end) + ((tid & ~63u) + ((tid & 31u) << 1) + ((tid >> 5) & 1u));
+	unsigned wb[H];   // the wave's bases (16-byte LDS reads where the row is that long; s_wbase is declared 16-byte aligned)
+	if constexpr (H % 4 == 0 && HMAX % 4 == 0) {
+		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
+		#pragma unroll
+		for (int k = 0; k < H / 4; ++k) {
+			const vec4u t = reinterpret_cast<const vec4u*>(s_wbase[wave])[k];
+			wb[4 * k] = t[0]; wb[4 * k + 1] = t[1]; wb[4 * k + 2] = t[2]; wb[4 * k + 3] = t[3];
+		}
+	} else {
+		#pragma unroll
+		for (int j = 0; j < H; ++j) wb[j] = s_wbase[wave][j];
+	}
 	#pragma unroll
 	for (int j = 0; j < H; ++j) {
-		const unsigned e2 = w[j] + s_wbase[wave][j];
+		const unsigned e2 = pc_pk_scale_add<(int) ES>(w[j], wb[j]);   // ends of digits 2j, 2j + 1 in bytes, each mod 2^16
 		tab[(2 * j) * THREADS] = (unsigned short) e2;
 		if (2 * j + 1 < (1 << BITS)) tab[(2 * j + 1) * THREADS] = (unsigned short) (e2 >> 16);
 	}
-	unsigned pos[ALIAS ? ITEMS / 2 : 1];
+	unsigned pos[ALIAS ? ITEMS : 1];
+	char* const stage_bytes = reinterpret_cast<char*>(s_stage);
 	#pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		// (lookups in flight: PC_BATCH at a time — all ITEMS at once cost 2 * ITEMS registers)
@@ -271,12 +324,9 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 		if (FULL || tbase + i < count) {
 			const unsigned d = pc_digit<E>(key[i], dshift, dmask, nbits);
 			const unsigned end = tab[d * THREADS];
-			if constexpr (ALIAS) {   // position kept (16 bits), stored after the barrier below
-				const unsigned p = pc_sub_byte(end, rb[i >> 2], i & 3) - 1u;
-				if (i & 1) pos[i >> 1] |= p << 16; else pos[i >> 1] = p & 0xffffu;
-			} else {
-				s_stage[pc_sub_byte(end, rb[i >> 2], i & 3) - 1u] = key[i];   // end - before - 1 (counts of these very elements: always inside the tile)
-			}
+			const unsigned at = pc_sub_byte16(end, rb[i >> 2], i & 3);   // (end - before - 1) * sizeof(E): counts of these very elements, always inside the tile
+			if constexpr (ALIAS) pos[i] = at;   // stored after the barrier below
+			else *reinterpret_cast<E*>(stage_bytes + at) = key[i];
 		}
 	}
 	if constexpr (ALIAS) {
@@ -284,7 +334,7 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 		clo_lds_barrier();
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
-			if (FULL || tbase + i < count) s_stage[(i & 1) ? pos[i >> 1] >> 16 : pos[i >> 1] & 0xffffu] = key[i];
+			if (FULL || tbase + i < count) *reinterpret_cast<E*>(stage_bytes + pos[i]) = key[i];
 	}
 	clo_lds_barrier();
 }

@@ -37,6 +37,7 @@ struct rccl_api {
 	decltype(&::ncclCommInitRank) CommInitRank = nullptr;
 	decltype(&::ncclCommDestroy) CommDestroy = nullptr;
 	decltype(&::ncclCommAbort) CommAbort = nullptr;
+	decltype(&::ncclCommGetAsyncError) CommGetAsyncError = nullptr;
 	decltype(&::ncclAllGather) AllGather = nullptr;
 	decltype(&::ncclSend) Send = nullptr;
 	decltype(&::ncclRecv) Recv = nullptr;
@@ -54,7 +55,7 @@ const rccl_api& rccl() {
 		for (const char* name : { "librccl.so.1", "/opt/rocm/lib/librccl.so.1" }) if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
 		if (!h) return;
 		#define CLO_RCCL_SYM(n) api.n = (decltype(api.n)) dlsym(h, "nccl" #n)
-		CLO_RCCL_SYM(GetUniqueId); CLO_RCCL_SYM(CommInitRank); CLO_RCCL_SYM(CommDestroy); CLO_RCCL_SYM(CommAbort); CLO_RCCL_SYM(AllGather);
+		CLO_RCCL_SYM(GetUniqueId); CLO_RCCL_SYM(CommInitRank); CLO_RCCL_SYM(CommDestroy); CLO_RCCL_SYM(CommAbort); CLO_RCCL_SYM(CommGetAsyncError); CLO_RCCL_SYM(AllGather);
 		CLO_RCCL_SYM(Send); CLO_RCCL_SYM(Recv); CLO_RCCL_SYM(GroupStart); CLO_RCCL_SYM(GroupEnd);
 		#undef CLO_RCCL_SYM
 		api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
@@ -93,6 +94,14 @@ int clo_hip_rccl_comm_abort(void* comm) {
 	if (!comm) return 0;
 	if (!rccl().CommAbort) return CLO_HIP_EUNSUPPORTED;
 	return rccl_status(rccl().CommAbort((ncclComm_t) comm));
+}
+
+int clo_hip_rccl_comm_async_error(void* comm) {
+	if (!comm) return CLO_HIP_EARGS;
+	if (!rccl().CommGetAsyncError) return 0;   // (an RCCL without it: nothing to report)
+	ncclResult_t async = ncclSuccess;
+	const ncclResult_t r = rccl().CommGetAsyncError((ncclComm_t) comm, &async);
+	return rccl_status(r != ncclSuccess ? r : async);
 }
 
 int clo_hip_rccl_all_gather_u64(void* comm, const uint64_t* send_dev, uint64_t* recv_dev, size_t count, void* stream) {

@@ -126,6 +126,11 @@ int clo_hip_stream_create_high_priority(void** stream) {
 }
 int clo_hip_stream_destroy(void* stream) { return (int) hipStreamDestroy((hipStream_t) stream); }
 int clo_hip_stream_synchronize(void* stream) { return (int) hipStreamSynchronize((hipStream_t) stream); }
+int clo_hip_stream_query(void* stream) {
+	const hipError_t e = hipStreamQuery((hipStream_t) stream);
+	if (e == hipErrorNotReady) { (void) hipGetLastError(); return CLO_HIP_ENOTREADY; }   // (not an error: nothing to leave behind)
+	return (int) e;
+}
 
 int clo_hip_malloc(void** dptr, size_t bytes) {
 	if (!dptr) return CLO_HIP_EARGS;
@@ -230,6 +235,7 @@ const char* clo_hip_error_string(int status) {
 		case CLO_HIP_EUNSUPPORTED: return "clo_hip: unsupported type or option";
 		case CLO_HIP_EWORKSPACE: return "clo_hip: workspace too small";
 		case CLO_HIP_ETIMEOUT: return "clo_hip: in-kernel look-back spin timed out";
+		case CLO_HIP_ENOTREADY: return "clo_hip: work on the stream is still running";
 		default:
 			if (status <= CLO_HIP_ERCCL) return "clo_hip: RCCL reported an error (status = CLO_HIP_ERCCL - ncclResult_t)";
 			return status > 0 ? hipGetErrorString((hipError_t) status) : "clo_hip: unknown error";

@@ -173,8 +173,11 @@ __device__ __forceinline__ void scan_publish(clo_u64* state, unsigned tile, unsi
 // TIn/TOut: memory types; TSum: 32- or 64-bit accumulator (sums narrower than
 // 32 bits are computed mod 2^32 and truncated on store, which is the same
 // residue).
+#ifndef CLO_SCAN_BIG_WAVES_PER_EU
+#define CLO_SCAN_BIG_WAVES_PER_EU 4
+#endif
 template <typename TIn, typename TOut, typename TSum, int ROWS, int SCAN_THREADS>
-__global__ __launch_bounds__(SCAN_THREADS)
+__global__ __launch_bounds__(SCAN_THREADS, (SCAN_THREADS == 1024 ? CLO_SCAN_BIG_WAVES_PER_EU : 1))
 void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t n,
 	unsigned* hdr, clo_u64* state, clo_u64* sstate, clo_u64* sagg, clo_u64* sacc, int aligned, unsigned xflags,
 	const clo_u64* __restrict__ carry_in, clo_u64* __restrict__ carry_out, unsigned last_tile,
@@ -197,7 +200,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	// clo_hip_scan_workspace_init wrote 0). Every work-group of the launch reads it
 	// before that happens again: the header only changes when all have left.
 	scan_ctl ctl;
-	ctl.epoch = __hip_atomic_load(&hdr[CLO_WS_EPOCH_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+	ctl.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(&hdr[CLO_WS_EPOCH_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
 	ctl.max_spins = max_spins;
 	ctl.status = &hdr[0];
 	const unsigned tiles = last_tile + 1u;
@@ -208,7 +211,9 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	for (;;) {
 	if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
 	__syncthreads();
-	const unsigned tile = s_tile;
+	// (read back from LDS the compiler takes the tile for a per-lane value: every row's address then becomes 64-bit vector
+	// arithmetic in registers of its own — 16 VGPRs for the loads, 16 for the stores; as a scalar it is a base in SGPRs)
+	const unsigned tile = (unsigned) __builtin_amdgcn_readfirstlane((int) s_tile);
 	const size_t base = (size_t) tile * TILE;
 	if (base >= n) {
 		// Leaving. The LAST work-group to leave (every group draws exactly one
@@ -241,8 +246,9 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		#pragma unroll
 		for (int r = 0; r < ROWS; ++r) {
 			TIn t[4];
-			if (xflags & 2u) load4_nt<TIn>(in + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
-			else load4<TIn>(in + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			const TIn* const rowp = in + base + (size_t) r * ROW_ELEMS;   // (wave-uniform: a scalar base + a 32-bit lane offset)
+			if (xflags & 2u) load4_nt<TIn>(rowp + tid * SCAN_VEC, t);
+			else load4<TIn>(rowp + tid * SCAN_VEC, t);
 			#pragma unroll
 			for (int c = 0; c < 4; ++c) v[r][c] = (TSum) t[c];
 		}
@@ -292,7 +298,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 			if (lane * PPL + k < (unsigned) PIECES) (&s_off[0][0])[lane * PPL + k] = run;
 			run += piece[k];
 		}
-		aggregate = __shfl(incl, 63, 64);
+		aggregate = clo_wave_reduce_sum<TSum>(lane == 63 ? incl : (TSum) 0);   // (lane 63's value, wave-uniform)
 	}
 
 	// ---- prefix of the tile (wave 0): two-level decoupled look-back ----
@@ -353,8 +359,9 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		for (int r = 0; r < ROWS; ++r) {
 			const TSum o = tile_excl + lane_excl[r];
 			TOut t[4] = { (TOut) o, (TOut) (o + v[r][0]), (TOut) (o + v[r][1]), (TOut) (o + v[r][2]) };
-			if (xflags & 4u) store4_nt<TOut>(out + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
-			else store4<TOut>(out + base + (size_t) r * ROW_ELEMS + tid * SCAN_VEC, t);
+			TOut* const rowp = out + base + (size_t) r * ROW_ELEMS;
+			if (xflags & 4u) store4_nt<TOut>(rowp + tid * SCAN_VEC, t);
+			else store4<TOut>(rowp + tid * SCAN_VEC, t);
 		}
 	} else {
 		#pragma unroll

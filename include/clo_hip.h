@@ -26,6 +26,7 @@ extern "C" {
 #define CLO_HIP_EUNSUPPORTED (-2)  /* type/option not built into this library */
 #define CLO_HIP_EWORKSPACE (-3)  /* workspace too small */
 #define CLO_HIP_ETIMEOUT   (-4)  /* an in-kernel bounded spin gave up (see clo_hip_check_status) */
+#define CLO_HIP_ENOTREADY  (-5)  /* clo_hip_stream_query: work enqueued on the stream is still running */
 #define CLO_HIP_ERCCL      (-100) /* RCCL failures: CLO_HIP_ERCCL - ncclResult_t */
 
 /* ---- device / runtime (replaces ccl_context_*, ccl_queue_*, ccl_buffer_*,
@@ -53,6 +54,7 @@ int clo_hip_stream_create(void** stream);
 int clo_hip_stream_create_high_priority(void** stream);
 int clo_hip_stream_destroy(void* stream);
 int clo_hip_stream_synchronize(void* stream);
+int clo_hip_stream_query(void* stream);   /* 0 = everything enqueued so far has completed; CLO_HIP_ENOTREADY = not yet; else an error */
 
 int clo_hip_malloc(void** dptr, size_t bytes);
 int clo_hip_free(void* dptr);
@@ -252,6 +254,9 @@ int clo_hip_rccl_comm_destroy(void* comm);
  * cannot take part in a collective its peers have already entered calls before it
  * returns its error. The handle is gone afterwards (no clo_hip_rccl_comm_destroy). */
 int clo_hip_rccl_comm_abort(void* comm);
+/* ncclCommGetAsyncError: 0 while the communicator is healthy, the RCCL status of an asynchronous failure (a peer that
+ * died, a network error) once there is one. Never blocks. */
+int clo_hip_rccl_comm_async_error(void* comm);
 int clo_hip_rccl_all_gather_u64(void* comm, const uint64_t* send_dev, uint64_t* recv_dev, size_t count, void* stream);
 int clo_hip_rccl_all_to_all_v(void* comm, int rank, int world,
 	const void* send_dev, const size_t* send_bytes, const size_t* send_offset_bytes,
@@ -367,6 +372,10 @@ int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms);
  * scan/clo_scan_blelloch.c:307-319). family: "radix_hist", "radix_pass",
  * "scan", "bitonic_tile", "bitonic_strided", "bitonic_step". */
 size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param);
+/* Static LDS bytes per work-group of the kernels the bitonic schedules launch for `numel` elements: tiled = 1 the tiled
+ * schedule (clo_hip_bitonic_tiled: 0 below 32 elements, the run-time-schedule tile kernel up to one tile, the
+ * compile-time-schedule kernels on 2^14-element tiles — 2^13 of 8 bytes — above), tiled = 0 one launch per step (0). */
+size_t clo_hip_bitonic_lds_bytes(size_t numel, int elem_size, int tiled);
 
 #ifdef __cplusplus
 }

@@ -60,10 +60,17 @@
  * can no longer happen); once all of this rank's transfers are enqueued, a later failure
  * (a sort that cannot be launched) is this rank's alone and is only RETURNED — the
  * exchange completes for the peers. An abort is local: it does not wake peers that are
- * already blocked inside a transfer with the aborted rank. A deployment that must survive
- * such a runtime failure polls ncclCommGetAsyncError or bounds its waits (bench.py: a
- * watchdog per leg); the protocol above only guarantees that no LOCAL failure — arguments,
- * memory — ever reaches that state.
+ * already blocked inside a transfer with the aborted rank — and a peer that never enters
+ * the collective at all (a crashed process) leaves the others waiting for it. The protocol
+ * above guarantees that no LOCAL failure — arguments, memory — ever reaches that state; for
+ * the rest the waits can be BOUNDED (round 5): the option `timeout_ms=N` bounds every host
+ * wait inside clo_shard_sort_with_device_data (the count exchange, the agreement round after
+ * growing buffers), and clo_shard_sort_finish(ss, cq_exec, timeout_ms, err) waits for what
+ * the call left running (the key exchange, the local sorts) for at most that long. Both poll
+ * the streams and the transport's async_error (RCCL: ncclCommGetAsyncError) instead of
+ * blocking; when the time is up or the transport reports a failure they abort this rank's
+ * side of the transport and return an error (CLO_ERROR_LIBRARY). The object is then only good
+ * for clo_shard_sort_destroy; the process itself stays usable (nothing is restarted).
  */
 #ifndef CLO_SHARD_H
 #define CLO_SHARD_H
@@ -95,6 +102,9 @@ typedef struct clo_shard_transport {
 	 * reported like any allocation failure (the ranks fail together). */
 	void* (*recv_alloc)(void* user, size_t bytes);
 	void (*recv_free)(void* user, void* ptr);
+	/* Optional, never blocks: 0 while the transport is healthy, a clo_hip status once it has failed asynchronously (RCCL:
+	 * ncclCommGetAsyncError — a peer that died or aborted, a link error). Polled by every bounded wait of the sort. */
+	int (*async_error)(void* user);
 } CloShardTransport;
 
 /* The 128-byte id one rank creates and every rank passes to
@@ -110,7 +120,8 @@ typedef struct clo_shard_sort CloShardSort;
 
 /* elem_type: CLO_UINT or CLO_ULONG (the key is the whole element); options: the
  * satradix options of the local sort ("radix=16" ...), `slices=S` (1, 2, 4, 8 or auto —
- * the default, see above), `slice_min=<bytes per rank>` (see above) and `loopback=1`: with a world of ONE rank, run the whole
+ * the default, see above), `slice_min=<bytes per rank>` (see above), `timeout_ms=N` (bounded
+ * waits, see "Failing together"; default 0 = wait for the peers without bound) and `loopback=1`: with a world of ONE rank, run the whole
  * protocol all the same, the rank sending every slice to itself through the transport
  * (a rehearsal of config 5's code path on a one-GPU box; without it one rank takes a
  * shortcut: copy + local sort). The transport stays the caller's. */
@@ -128,9 +139,18 @@ void clo_shard_sort_destroy(CloShardSort* ss);
 CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, CCLBuffer* data_in, size_t numel,
 	CCLBuffer** data_out, size_t* numel_out, GError** err);
 
-/* Host milliseconds the phases of the last call took up to their enqueue/sync
- * points and, when cq_exec profiles, device milliseconds: [0] partition, [1] count
- * exchange, [2] key exchange, [3] local sort. */
+/* Waits, for at most timeout_ms milliseconds (0: the object's `timeout_ms` option; that being 0 too: without bound), until
+ * everything the last clo_shard_sort_with_device_data enqueued — the key exchange on the transfer stream, the local sorts on
+ * cq_exec — has completed, polling the streams and the transport's async_error. CL_TRUE: done, the result may be read.
+ * CL_FALSE with an error: the time was up (a peer left the exchange hanging) or the transport or a stream reported a
+ * failure; this rank's side of the transport has been aborted (see "Failing together"). Not collective. */
+cl_bool clo_shard_sort_finish(CloShardSort* ss, CCLQueue* cq_exec, unsigned timeout_ms, GError** err);
+
+/* DEVICE milliseconds between the time stamps the last call left on cq_exec (zeros for one rank without `loopback=1`,
+ * which takes the shortcut): [0] partition, [1] count exchange (includes the host's wait for the counts), [2] from the
+ * plan to the arrival of the first slice (with one exchange: the whole key exchange), [3] local sort — for a sliced call
+ * this includes the stream's waits for the later slices' arrival, so it is NOT pure sorting time. Synchronises on the
+ * last stamp. */
 void clo_shard_sort_get_phase_ms(CloShardSort* ss, double device_ms[4]);
 
 /* The key exchange of the last call, for rooflines: bytes this rank sent to / received

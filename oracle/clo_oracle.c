@@ -127,9 +127,12 @@ static inline void cmpxch(void* data, size_t i1, size_t i2, int desc,
 
 /* One (stage, step) layer over the whole array: sbitonic.cl:38-69 == abit_any
  * (abitonic.cl:573-603). */
+/* `threads`: the work-items of a launch are independent (disjoint pairs / tiles), so the
+ * CPU baseline runs them on all host cores; 1 = the serial loop, same result. */
 static void layer_any(void* data, size_t n, unsigned stage, unsigned step,
-	const clo_oracle_desc* d) {
+	const clo_oracle_desc* d, int threads) {
 	size_t stride = (size_t) 1 << (step - 1);
+	#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
 	for (size_t gid = 0; gid < n / 2; ++gid) {
 		size_t i1 = (gid / stride) * stride * 2 + (gid % stride);
 		int desc = (int) ((gid >> (stage - 1)) & 1);
@@ -137,14 +140,19 @@ static void layer_any(void* data, size_t n, unsigned stage, unsigned step,
 	}
 }
 
-void clo_oracle_sbitonic(void* data, size_t numel, const clo_oracle_desc* d) {
+void clo_oracle_sbitonic_mt(void* data, size_t numel, const clo_oracle_desc* d, int threads) {
 	/* ref: clo_sort_sbitonic.c:73-80 (gws = nlpo2/2), :83 (stages = tzc(2*gws)),
 	 * :102-118 (stage 1..T, step stage..1, one launch each). */
 	size_t n = clo_oracle_nlpo2((unsigned int) numel);
 	unsigned T = clo_oracle_tzc((int) n);
+	if (threads <= 0) threads = omp_get_max_threads();
 	for (unsigned stage = 1; stage <= T; ++stage)
 		for (unsigned step = stage; step >= 1; --step)
-			layer_any(data, n, stage, step, d);
+			layer_any(data, n, stage, step, d, threads);
+}
+
+void clo_oracle_sbitonic(void* data, size_t numel, const clo_oracle_desc* d) {
+	clo_oracle_sbitonic_mt(data, numel, d, 1);
 }
 
 /* Typed "a == b" on raw key bits (the kernel's key_i == key_gid). */
@@ -194,8 +202,9 @@ static void priv_network(void* data, size_t base, size_t inc, unsigned S, int de
 
 /* abit_priv_{S}s{V}v launched with "step" p. ref: abitonic.cl:147-161. */
 static void kernel_priv(void* data, size_t n, unsigned stage, unsigned p, unsigned S,
-	const clo_oracle_desc* d) {
+	const clo_oracle_desc* d, int threads) {
 	size_t V = (size_t) 1 << S, block = (size_t) 1 << p, inc = block / V;
+	#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
 	for (size_t gid = 0; gid < n / V; ++gid) {
 		int desc = (int) (((gid * V) >> stage) & 1);
 		size_t base = ((gid * V) / block) * block + (gid % inc);
@@ -205,8 +214,9 @@ static void kernel_priv(void* data, size_t n, unsigned stage, unsigned p, unsign
 
 /* abit_local_sK: steps K..1 inside tiles of 2L. ref: abitonic.cl:40-47,118-145. */
 static void kernel_local(void* data, size_t n, unsigned stage, unsigned K, size_t L,
-	const clo_oracle_desc* d) {
+	const clo_oracle_desc* d, int threads) {
 	size_t tile = 2 * L;
+	#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
 	for (size_t w = 0; w < n / tile; ++w) {
 		unsigned char* t = (unsigned char*) data + w * tile * (size_t) d->elem_size;
 		for (unsigned q = K; q >= 1; --q) {
@@ -224,8 +234,9 @@ static void kernel_local(void* data, size_t n, unsigned stage, unsigned K, size_
 /* abit_hyb_sK_{S}s{V}v: tile of V*L, register networks for q = K, K-S, .., S.
  * ref: abitonic.cl:683-721 (2s4v), :824-870 (3s8v), :965-1028 (4s16v). */
 static void kernel_hyb(void* data, size_t n, unsigned stage, unsigned K, unsigned S,
-	size_t L, const clo_oracle_desc* d) {
+	size_t L, const clo_oracle_desc* d, int threads) {
 	size_t V = (size_t) 1 << S, tile = V * L;
+	#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
 	for (size_t w = 0; w < n / tile; ++w) {
 		unsigned char* t = (unsigned char*) data + w * tile * (size_t) d->elem_size;
 		for (unsigned q = K; q >= S; q -= S) {
@@ -250,9 +261,10 @@ typedef struct {
 	unsigned num_steps;
 } abit_step;
 
-int clo_oracle_abitonic(void* data, size_t numel, const clo_oracle_desc* d,
+int clo_oracle_abitonic_mt(void* data, size_t numel, const clo_oracle_desc* d,
 	size_t lws_max, size_t dev_max_lws,
-	unsigned minps, unsigned maxps, unsigned maxsfs) {
+	unsigned minps, unsigned maxps, unsigned maxsfs, int threads) {
+	if (threads <= 0) threads = omp_get_max_threads();
 
 	/* ref: clo_sort_abitonic.c:66-133 — candidate kernels per "stage finish"
 	 * step 2..12, in preference order, as (kind, S). kind 1 = local (S=1). */
@@ -326,10 +338,10 @@ int clo_oracle_abitonic(void* data, size_t numel, const clo_oracle_desc* d,
 		for (unsigned step = stage; step >= 1; ) {
 			const abit_step* s = &steps[step - 1];
 			switch (s->kind) {
-				case 0: layer_any(data, n, stage, step, d); break;
-				case 1: kernel_local(data, n, stage, s->K, s->lws, d); break;
-				case 2: kernel_priv(data, n, stage, step, s->S, d); break;
-				default: kernel_hyb(data, n, stage, s->K, s->S, s->lws, d); break;
+				case 0: layer_any(data, n, stage, step, d, threads); break;
+				case 1: kernel_local(data, n, stage, s->K, s->lws, d, threads); break;
+				case 2: kernel_priv(data, n, stage, step, s->S, d, threads); break;
+				default: kernel_hyb(data, n, stage, s->K, s->S, s->lws, d, threads); break;
 			}
 			++launches;
 			if (s->num_steps >= step) break;
@@ -338,6 +350,12 @@ int clo_oracle_abitonic(void* data, size_t numel, const clo_oracle_desc* d,
 	}
 	free(steps);
 	return launches;
+}
+
+int clo_oracle_abitonic(void* data, size_t numel, const clo_oracle_desc* d,
+	size_t lws_max, size_t dev_max_lws,
+	unsigned minps, unsigned maxps, unsigned maxsfs) {
+	return clo_oracle_abitonic_mt(data, numel, d, lws_max, dev_max_lws, minps, maxps, maxsfs, 1);
 }
 
 /* ------------------------------------------------------------------ */

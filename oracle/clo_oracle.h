@@ -113,6 +113,12 @@ int clo_oracle_satradix_mt(void* data, size_t numel, const clo_oracle_desc* d,
 	unsigned radix, size_t lws, int threads);
 int clo_oracle_blelloch_mt(const void* data_in, void* data_out, size_t numel,
 	int elem_size, int sum_size, size_t lws, int threads);
+/* The bitonic networks with the work-items of every launch (disjoint pairs, tiles) spread over
+ * OpenMP threads: same bits as the serial versions. threads <= 0: all host cores. */
+void clo_oracle_sbitonic_mt(void* data, size_t numel, const clo_oracle_desc* d, int threads);
+int clo_oracle_abitonic_mt(void* data, size_t numel, const clo_oracle_desc* d,
+	size_t lws_max, size_t dev_max_lws,
+	unsigned minps, unsigned maxps, unsigned maxsfs, int threads);
 
 #ifdef __cplusplus
 }

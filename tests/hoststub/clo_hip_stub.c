@@ -34,7 +34,14 @@ int clo_hip_get_device_props(int device, clo_hip_device_props* props) {
 int clo_hip_stream_create(void** stream) { *stream = malloc(8); return *stream ? 0 : 2; }
 int clo_hip_stream_create_high_priority(void** stream) { return clo_hip_stream_create(stream); }
 int clo_hip_stream_destroy(void* stream) { free(stream); return 0; }
-int clo_hip_stream_synchronize(void* stream) { (void) stream; return 0; }
+/* A stream is idle at once — unless the test says otherwise: its hook (tests/hoststub/host_paths_test.c: a transport whose
+ * collective is still waiting for a rank) makes clo_hip_stream_query / _synchronize see pending work. */
+int (*clo_hip_stub_stream_hook)(void* stream);
+int clo_hip_stream_query(void* stream) { return clo_hip_stub_stream_hook ? clo_hip_stub_stream_hook(stream) : 0; }
+int clo_hip_stream_synchronize(void* stream) {
+	while (clo_hip_stub_stream_hook && clo_hip_stub_stream_hook(stream) == CLO_HIP_ENOTREADY) { struct timespec ts = { 0, 100000 }; nanosleep(&ts, NULL); }
+	return 0;
+}
 int clo_hip_malloc(void** dptr, size_t bytes) { *dptr = malloc(bytes ? bytes : 1); return *dptr ? 0 : 2; }
 int clo_hip_free(void* dptr) { free(dptr); return 0; }
 int clo_hip_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream) { (void) stream; memcpy(dst, src, bytes); return 0; }
@@ -70,6 +77,7 @@ const char* clo_hip_error_string(int status) {
 		case CLO_HIP_EUNSUPPORTED: return "not supported (host stub)";
 		case CLO_HIP_EWORKSPACE: return "workspace too small";
 		case CLO_HIP_ETIMEOUT: return "a bounded spin gave up";
+		case CLO_HIP_ENOTREADY: return "not ready";
 		default: return "stub error";
 	}
 }
@@ -344,6 +352,7 @@ int clo_hip_rccl_unique_id(void* id_out) { (void) id_out; return CLO_HIP_EUNSUPP
 int clo_hip_rccl_comm_create(void** comm, const void* id_in, int rank, int world) { (void) comm; (void) id_in; (void) rank; (void) world; return CLO_HIP_EUNSUPPORTED; }
 int clo_hip_rccl_comm_destroy(void* comm) { (void) comm; return 0; }
 int clo_hip_rccl_comm_abort(void* comm) { (void) comm; return 0; }
+int clo_hip_rccl_comm_async_error(void* comm) { (void) comm; return 0; }
 int clo_hip_rccl_all_gather_u64(void* comm, const uint64_t* send_dev, uint64_t* recv_dev, size_t count, void* stream) { (void) comm; (void) send_dev; (void) recv_dev; (void) count; (void) stream; return CLO_HIP_EUNSUPPORTED; }
 int clo_hip_rccl_all_to_all_v(void* comm, int rank, int world, const void* send_dev, const size_t* send_bytes, const size_t* send_offset_bytes,
 	void* recv_dev, const size_t* recv_bytes, const size_t* recv_offset_bytes, void* stream) {

@@ -12,11 +12,15 @@
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include "cl_ops.h"
+#include "clo_hip.h"
 #include "clo_shard.h"
 
 static int failures;
@@ -268,6 +272,116 @@ static void test_shard(int world, int es, size_t n_per_rank, const char* options
 	pthread_barrier_destroy(&f.bar);
 }
 
+/* ---- 4. bounded waits (round 5): a peer that never joins, a transport that fails asynchronously, an exchange that never ends ----
+ * The stub executes everything at once, so "a collective still waiting for a rank" is played by the stub's stream hook:
+ * while `hang_busy` is set every stream of the process has pending work. The transport below never blocks (as RCCL's
+ * enqueue does not): a collective that cannot complete just leaves the flag set. */
+extern int (*clo_hip_stub_stream_hook)(void* stream);
+static atomic_int hang_busy, hang_aborts, hang_async;
+static int hang_hook(void* stream) { (void) stream; return atomic_load(&hang_busy) ? CLO_HIP_ENOTREADY : 0; }
+typedef struct { int hang_gather, hang_exchange, world; } hang_user;
+static int hang_all_gather(void* user, const uint64_t* s, uint64_t* r, size_t count, void* stream) {
+	hang_user* u = (hang_user*) user;
+	(void) stream;
+	if (u->hang_gather) { atomic_store(&hang_busy, 1); return 0; }   /* the other rank never arrives */
+	for (int p = 0; p < u->world; ++p) memcpy(r + (size_t) p * count, s, count * sizeof(uint64_t));
+	return 0;
+}
+static int hang_all_to_all_v(void* user, const void* send, const size_t* sb, const size_t* so, void* recv, const size_t* rb, const size_t* ro, void* stream) {
+	hang_user* u = (hang_user*) user;
+	(void) stream; (void) rb;
+	if (u->hang_exchange) { atomic_store(&hang_busy, 1); return 0; }
+	memcpy((char*) recv + ro[0], (const char*) send + so[0], sb[0]);
+	return 0;
+}
+static void hang_abort(void* user) { (void) user; atomic_fetch_add(&hang_aborts, 1); atomic_store(&hang_busy, 0); }   /* (an abort ends the pending operations) */
+static int hang_async_error(void* user) { (void) user; return atomic_load(&hang_async); }
+static void* hang_killer(void* p) { (void) p; struct timespec ts = { 0, 60 * 1000000 }; nanosleep(&ts, NULL); atomic_store(&hang_async, CLO_HIP_ERCCL - 6); return NULL; }
+static double wall_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
+static void test_shard_bounded_waits(void) {
+	GError* err = NULL;
+	clo_hip_stub_stream_hook = hang_hook;
+	CCLContext* ctx = ccl_context_new_from_device_index(0, &err);
+	CCLQueue* q = ccl_queue_new(ctx, NULL, 0, &err);
+	const size_t n = 6000;
+	uint32_t* keys = (uint32_t*) malloc(n * 4);
+	for (size_t i = 0; i < n; ++i) keys[i] = (uint32_t) rnd();
+	CCLBuffer* in = ccl_buffer_new_from_device_ptr(ctx, keys, n * 4, &err);
+	for (int scenario = 0; scenario < 3; ++scenario) {
+		/* 0: rank 1 of 2 never joins the count exchange, timeout_ms bounds the wait; 1: no bound, but the transport reports an
+		 * asynchronous failure after 60 ms; 2: one rank (loopback), the key exchange never completes: clo_shard_sort_finish gives up */
+		hang_user hu = { scenario < 2, scenario == 2, scenario < 2 ? 2 : 1 };
+		CloShardTransport t;
+		memset(&t, 0, sizeof(t));
+		t.user = &hu; t.rank = 0; t.world = hu.world;
+		t.all_gather_u64 = hang_all_gather; t.all_to_all_v = hang_all_to_all_v; t.abort = hang_abort;
+		if (scenario == 1) t.async_error = hang_async_error;
+		atomic_store(&hang_busy, 0); atomic_store(&hang_aborts, 0); atomic_store(&hang_async, 0);
+		CloShardSort* ss = clo_shard_sort_new(ctx, &t, CLO_UINT, scenario == 0 ? "timeout_ms=150" : (scenario == 2 ? "loopback=1,slices=2,slice_min=1" : NULL), &err);
+		CHECK(ss != NULL, "bounded waits %d: clo_shard_sort_new", scenario);
+		report(&err, "clo_shard_sort_new");
+		if (!ss) continue;
+		pthread_t killer;
+		if (scenario == 1) pthread_create(&killer, NULL, hang_killer, NULL);
+		CCLBuffer* out = NULL;
+		size_t m = 0;
+		const double t0 = wall_ms();
+		CCLEvent* e = clo_shard_sort_with_device_data(ss, q, in, n, &out, &m, &err);
+		if (scenario < 2) {
+			const double dt = wall_ms() - t0;
+			CHECK(e == NULL && err != NULL, "bounded waits %d: the call returned although a rank never joined", scenario);
+			CHECK(dt < 5000.0 && (scenario == 1 || dt >= 150.0), "bounded waits %d: gave up after %.0f ms", scenario, dt);
+			if (err) CHECK(scenario == 0 ? strstr(err->message, "timed out") != NULL : strstr(err->message, "timed out") == NULL, "bounded waits %d: '%s'", scenario, err->message);
+			if (err) { clo_gerror_free(err); err = NULL; }
+			CHECK(atomic_load(&hang_aborts) == 1, "bounded waits %d: %d aborts", scenario, atomic_load(&hang_aborts));
+			e = clo_shard_sort_with_device_data(ss, q, in, n, &out, &m, &err);   /* the object is spent */
+			CHECK(e == NULL && err != NULL && strstr(err->message, "destroy it") != NULL, "bounded waits %d: a second call on the aborted object", scenario);
+			if (err) { clo_gerror_free(err); err = NULL; }
+		} else {
+			CHECK(e != NULL, "bounded waits 2: the call itself only enqueues");
+			report(&err, "clo_shard_sort_with_device_data");
+			const cl_bool ok = clo_shard_sort_finish(ss, q, 120, &err);
+			const double dt = wall_ms() - t0;
+			CHECK(!ok && err != NULL && strstr(err->message, "timed out") != NULL, "bounded waits 2: finish returned %d", (int) ok);
+			CHECK(dt >= 120.0 && dt < 5000.0, "bounded waits 2: gave up after %.0f ms", dt);
+			if (err) { clo_gerror_free(err); err = NULL; }
+			CHECK(atomic_load(&hang_aborts) == 1, "bounded waits 2: %d aborts", atomic_load(&hang_aborts));
+		}
+		if (scenario == 1) pthread_join(killer, NULL);
+		clo_shard_sort_destroy(ss);
+	}
+	/* and a healthy sort under the same polling waits: bound set, nothing hangs */
+	{
+		hang_user hu = { 0, 0, 1 };
+		CloShardTransport t;
+		memset(&t, 0, sizeof(t));
+		t.user = &hu; t.rank = 0; t.world = 1;
+		t.all_gather_u64 = hang_all_gather; t.all_to_all_v = hang_all_to_all_v; t.abort = hang_abort; t.async_error = hang_async_error;
+		atomic_store(&hang_busy, 0); atomic_store(&hang_aborts, 0); atomic_store(&hang_async, 0);
+		CloShardSort* ss = clo_shard_sort_new(ctx, &t, CLO_UINT, "loopback=1,timeout_ms=2000", &err);
+		CCLBuffer* out = NULL;
+		size_t m = 0;
+		CCLEvent* e = ss ? clo_shard_sort_with_device_data(ss, q, in, n, &out, &m, &err) : NULL;
+		CHECK(e != NULL && m == n, "bounded waits: the healthy sort");
+		report(&err, "healthy sort");
+		CHECK(ss && clo_shard_sort_finish(ss, q, 0, &err), "bounded waits: finish of the healthy sort");
+		report(&err, "finish");
+		if (e && out) {
+			const uint32_t* g = (const uint32_t*) ccl_buffer_get_device_ptr(out);
+			size_t bad = 0;
+			for (size_t i = 1; i < m; ++i) bad += g[i - 1] > g[i];
+			CHECK(bad == 0 && atomic_load(&hang_aborts) == 0, "bounded waits: the healthy sort's result");
+		}
+		clo_shard_sort_destroy(ss);
+	}
+	ccl_buffer_destroy(in);
+	ccl_queue_destroy(q);
+	ccl_context_destroy(ctx);
+	free(keys);
+	clo_hip_stub_stream_hook = NULL;
+}
+
 /* Random worlds, sizes (empty ranks included), options and key distributions through the whole protocol. */
 static int fuzz_shard(int cases, uint64_t seed) {
 	static const char* const opts[] = { NULL, "slices=1", "slices=2", "slices=4", "slices=8", "radix=256", "radix=256,slices=4", "radix=4", "slices=auto" };
@@ -327,6 +441,7 @@ int main(int argc, char** argv) {
 	test_shard(2, 4, 50, NULL, 0, 0, 2);          /* tiny: one exchange */
 	test_shard(4, 8, n, NULL, 0, 1, 1);           /* a rank with bad arguments: all fail, then all sort */
 	test_shard(2, 4, n, "slices=2", 0, 2, 1);     /* a rank that cannot grow its receive buffer: all fail, then all sort */
+	test_shard_bounded_waits();                   /* a peer that never joins / an asynchronous failure / an exchange that never ends */
 	if (failures) fprintf(stderr, "%d check(s) failed\n", failures);
 	else printf("host paths ok\n");
 	return failures ? 1 : 0;

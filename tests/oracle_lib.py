@@ -62,6 +62,10 @@ def lib():
         L.clo_oracle_bench_rand.restype = None
         L.clo_oracle_scan_bench_rand.argtypes = [C.c_uint32, C.c_int, vp, sz]
         L.clo_oracle_scan_bench_rand.restype = None
+        L.clo_oracle_sbitonic_mt.argtypes = [vp, sz, C.POINTER(Desc), C.c_int]
+        L.clo_oracle_sbitonic_mt.restype = None
+        L.clo_oracle_abitonic_mt.argtypes = [vp, sz, C.POINTER(Desc), sz, sz, C.c_uint, C.c_uint, C.c_uint, C.c_int]
+        L.clo_oracle_abitonic_mt.restype = C.c_int
         L.clo_oracle_satradix_mt.argtypes = [vp, sz, C.POINTER(Desc), C.c_uint, sz, C.c_int]
         L.clo_oracle_satradix_mt.restype = C.c_int
         L.clo_oracle_blelloch_mt.argtypes = [vp, vp, sz, C.c_int, C.c_int, sz, C.c_int]
@@ -79,10 +83,14 @@ def desc_for(arr, key_size=None, key_shift=0, key_kind=KEY_UNSIGNED, descending=
     return Desc(es, key_size or es, key_shift, key_kind, int(descending))
 
 
-def sbitonic(arr, **kw):
+def sbitonic(arr, threads=1, **kw):
+    """threads > 1 (0: all host cores): the pairs of every step spread over OpenMP threads, same bits."""
     out = np.ascontiguousarray(arr).copy()
     d = desc_for(out, **kw)
-    lib().clo_oracle_sbitonic(_p(out), out.size, C.byref(d))
+    if threads == 1:
+        lib().clo_oracle_sbitonic(_p(out), out.size, C.byref(d))
+    else:
+        lib().clo_oracle_sbitonic_mt(_p(out), out.size, C.byref(d), threads)
     return out
 
 
@@ -94,11 +102,15 @@ def gselect(arr, **kw):
     return out
 
 
-def abitonic(arr, lws_max=0, dev_max_lws=256, minps=1, maxps=4, maxsfs=0xFFFFFFFF, **kw):
+def abitonic(arr, lws_max=0, dev_max_lws=256, minps=1, maxps=4, maxsfs=0xFFFFFFFF, threads=1, **kw):
     out = np.ascontiguousarray(arr).copy()
     d = desc_for(out, **kw)
-    launches = lib().clo_oracle_abitonic(_p(out), out.size, C.byref(d), lws_max, dev_max_lws,
-                                         minps, maxps, maxsfs)
+    if threads == 1:
+        launches = lib().clo_oracle_abitonic(_p(out), out.size, C.byref(d), lws_max, dev_max_lws,
+                                             minps, maxps, maxsfs)
+    else:
+        launches = lib().clo_oracle_abitonic_mt(_p(out), out.size, C.byref(d), lws_max, dev_max_lws,
+                                                minps, maxps, maxsfs, threads)
     return out, launches
 
 

@@ -139,6 +139,14 @@ def test_mt_baseline_equals_serial():
     assert np.array_equal(O.satradix(a, dev_max_lws=256, threads=4), O.satradix(a, dev_max_lws=256))
     s = O.scan_bench_rand(7, np.uint32, 1 << 15)
     assert np.array_equal(O.blelloch(s, np.uint32, dev_max_lws=64, threads=4), O.serial_scan(s, np.uint32))
+    # the bitonic networks on several threads (the cpu_baseline of the sbitonic / abitonic legs): the same bits, ties included
+    pairs = (np.random.default_rng(7).integers(0, 50, 1 << 13, dtype=np.uint64) << np.uint64(32)) | np.arange(1 << 13, dtype=np.uint64)
+    for arr, kw in ((a, {}), (pairs, {"key_size": 4, "key_shift": 32})):
+        assert np.array_equal(O.sbitonic(arr, threads=4, **kw), O.sbitonic(arr, **kw))
+        for lws in (64, 256):
+            mt, l_mt = O.abitonic(arr, dev_max_lws=lws, threads=4, **kw)
+            st, l_st = O.abitonic(arr, dev_max_lws=lws, **kw)
+            assert l_mt == l_st and np.array_equal(mt, st)
 
 
 def test_typed_compare_and_descending():
