@@ -28,7 +28,14 @@ class DeviceProps(C.Structure):
 
 
 def _sig(name, restype, *argtypes):
-    f = getattr(lib, name)
+    try:
+        f = getattr(lib, name)
+    except AttributeError:
+        # The shipped library exports everything this file names (tests/test_boundary_cpu.py checks it): a missing symbol is an
+        # error. Only an OLDER build loaded through CLO_HIP_LIBRARY for an A/B run may lack entry points added since.
+        if os.environ.get("CLO_HIP_LIBRARY"):
+            return None
+        raise
     f.restype = restype
     f.argtypes = list(argtypes)
     return f
@@ -84,6 +91,8 @@ _sig("clo_hip_radix_takes_first_digits", ci, sz, ci, ci, ci)
 _sig("clo_hip_radix_sort_fed", ci, vp, vp, vp, sz, ci, ci, ci, ci, ci, vp, vp, sz, vp)
 _sig("clo_hip_radix_seg_workspace_bytes", sz, sz, ci, ci, ci)
 _sig("clo_hip_radix_sort_segmented", ci, vp, vp, vp, sz, C.POINTER(sz), ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(ci), ci,
+     ci, ci, ci, ci, vp, sz, vp, C.POINTER(ci))
+_sig("clo_hip_radix_sort_segmented2", ci, vp, vp, vp, vp, sz, C.POINTER(sz), ci, C.POINTER(sz), C.POINTER(sz), C.POINTER(ci), C.POINTER(ci), ci,
      ci, ci, ci, ci, vp, sz, vp, C.POINTER(ci))
 _sig("clo_hip_msd_histogram", ci, vp, sz, ci, ci, ci, ci, vp, vp)
 _sig("clo_hip_msd_partition", ci, vp, vp, sz, ci, ci, ci, ci, vp, vp, sz, vp)

@@ -135,8 +135,10 @@ typedef struct {
 	 * segments and the optional pieces lie; the result is in b_dev when *result_in_b, else in a_dev; a_dev is overwritten).
 	 * *handled = 0 and nothing enqueued when this sorter cannot (another radix than 16 / 256, element size, key kind) —
 	 * the caller then sorts the range some other way. reserve_segments grows the buffers it needs for that size NOW. */
+	/* (src2_dev / piece_source: pieces that lie in a second device range, clo_hip_radix_sort_segmented2; NULL / NULL: none) */
 	CCLEvent* (*sort_segments)(struct clo_sort* sorter, CCLQueue* cq_exec, void* a_dev, void* b_dev, size_t numel,
 		const size_t* seg_counts, int nseg, const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
+		const void* src2_dev, const int* piece_source,
 		int key_shift, int key_bits, int* result_in_b, int* handled, GError** err);
 	cl_bool (*reserve_segments)(struct clo_sort* sorter, CCLQueue* cq_exec, size_t numel, int nseg, int* handled, GError** err);
 } clo_sort_impl_ext;

@@ -714,13 +714,18 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 		st = clo_hip_event_record(ss->ev_part, stream);
 		if (st == 0) st = clo_hip_stream_wait_event(ss->comm_stream, ss->ev_part);
 		if (st == 0) st = clo_hip_event_record(ss->evx[0], ss->comm_stream);
-		size_t slice_at[SHARD_MAX_SLICES], slice_n[SHARD_MAX_SLICES];
+		size_t slice_at[SHARD_MAX_SLICES], slice_n[SHARD_MAX_SLICES], self_at[SHARD_MAX_SLICES];
 		for (int j = 0; j < use && st == 0; ++j) {
 			clo_shard_plan_slice(M, row, G, Q, use, me, j, sc, so, rc, ro, &slice_at[j], &slice_n[j]);
+			self_at[j] = so[me];   /* where this rank's own share of the slice starts in the partitioned shard */
 			for (int p = 0; p < G; ++p) {
 				sb[p] = sc[p] * (size_t) es; sob[p] = so[p] * (size_t) es; rb[p] = rc[p] * (size_t) es; rob[p] = ro[p] * (size_t) es;
 				if (p != me) { ss->last_out += sb[p]; ss->last_in += rb[p]; }
 			}
+			/* The rank's own share never moves (round 5): the segmented sort's first pass gathers it straight out of `send`
+			 * (its pieces below name the second source), so the transport has nothing to copy for this rank — 1 / G of the
+			 * exchange's bytes at any G, all of them in the one-rank rehearsal (where the "exchange" was a 0.5-1 ms device copy). */
+			sb[me] = rb[me] = 0;
 			st = ss->t->all_to_all_v(ss->t->user, ss->send.ptr, sb, sob, recv_ptr, rb, rob, ss->comm_stream);
 			if (st == 0) st = clo_hip_event_record(ss->ev_arrived[j], ss->comm_stream);
 		}
@@ -736,7 +741,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 			/* slice j: `group` segments (sub-buckets, ascending key ranges), each in G pieces — one per source rank, in
 			 * source order inside the slice — sorted on the bits the partition has not consumed */
 			size_t seg_counts[SHARD_SUBS], pn[SHARD_SUBS], po[SHARD_SUBS];
-			int ps[SHARD_SUBS];
+			int ps[SHARD_SUBS], psrc[SHARD_SUBS];
 			size_t block_at[SHARD_MAX_WORLD + 1];
 			block_at[0] = 0;
 			for (int p = 0; p < G; ++p) {
@@ -751,7 +756,9 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 					size_t before = 0;
 					for (int k2 = 0; k2 < kk; ++k2) before += (size_t) M[(size_t) p * row + (size_t) me * Q + (size_t) j * group + k2];
 					pn[np] = (size_t) M[(size_t) p * row + (size_t) me * Q + (size_t) j * group + kk];
-					po[np] = block_at[p] + before;
+					/* pieces of the other ranks: where they landed in the slice; this rank's own: where the partition left it */
+					po[np] = p == me ? self_at[j] + before : block_at[p] + before;
+					psrc[np] = p == me;
 					ps[np] = kk;
 					seg_counts[kk] += pn[np];
 					++np;
@@ -759,7 +766,7 @@ CCLEvent* clo_shard_sort_with_device_data(CloShardSort* ss, CCLQueue* cq_exec, C
 			}
 			int handled = 0, b = 0;
 			CCLEvent* e = ext->sort_segments(ss->sorter, cq_exec, recv_ptr + slice_at[j] * (size_t) es, result_ptr + slice_at[j] * (size_t) es,
-				slice_n[j], seg_counts, group, G > 1 ? pn : NULL, G > 1 ? po : NULL, G > 1 ? ps : NULL, G > 1 ? np : 0,
+				slice_n[j], seg_counts, group, pn, po, ps, np, ss->send.ptr, psrc,
 				0, 8 * es - SHARD_PART_BITS, &b, &handled, err);
 			if (!e || !handled) {
 				if (!handled && (err == NULL || *err == NULL)) clo_gerror_set(err, CLO_ERROR, CLO_ERROR_LIBRARY, "the sorter stopped taking segmented sorts");

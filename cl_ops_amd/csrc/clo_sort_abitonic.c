@@ -110,16 +110,21 @@ static const char* clo_sort_abitonic_get_kernel_name(CloSort* sorter, cl_uint i,
 	return clo_sort_abitonic_knames[i];
 }
 
-/* ref: clo_sort_abitonic.c:617-704. "any" and "priv" names map to the
- * register-only HIP kernels (no LDS); "local" and "hyb" names map to the LDS
- * tile kernel, whose usage does not depend on lws_max or numel. */
+/* ref: clo_sort_abitonic.c:617-704. The 26 names are upstream's list, kept so that code which walks
+ * clo_sort_get_num_kernels / _get_kernel_name keeps working; the HIP schedule launches kernels of its own (their names
+ * appear on a profiling queue: abit_presort, abit_merge, abit_strided, abit_strided2). "any" and "priv" names stand
+ * for the register-only kernels (no LDS); "local" and "hyb" names for the LDS tile kernels: the static LDS of the one
+ * that `numel` selects (clo_hip_bitonic_lds_bytes: nothing below 32 elements, the run-time-schedule tile kernel up
+ * to one tile, the compile-time-schedule kernels above). lws_max plays no part (include/clo_sort.h). */
 static size_t clo_sort_abitonic_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max,
 	size_t numel, GError** err) {
 	clo_return_val_if_fail(i < CLO_SORT_ABITONIC_NUM_KERNELS, 0);
-	(void) lws_max; (void) numel; (void) err;
+	(void) lws_max; (void) err;
 	const char* name = clo_sort_abitonic_knames[i];
 	if (strcmp(name, "abit_any") == 0 || strstr(name, "priv")) return 0;
-	return clo_hip_kernel_lds_bytes("bitonic_tile", (int) clo_sort_get_element_size(sorter), 0);
+	void* jit = clo_sort_get_jit(sorter);
+	if (jit) return clo_hip_bitonic_jit_lds_bytes(jit, numel, 1);
+	return clo_hip_bitonic_lds_bytes(numel, (int) clo_sort_get_element_size(sorter), 1);
 }
 
 /* ref: clo_sort_abitonic.c:708-717 */

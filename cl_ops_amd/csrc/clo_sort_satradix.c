@@ -550,6 +550,7 @@ static cl_bool clo_sort_satradix_reserve_segments(CloSort* sorter, CCLQueue* cq_
 
 static CCLEvent* clo_sort_satradix_sort_segments(CloSort* sorter, CCLQueue* cq_exec, void* a_dev, void* b_dev, size_t numel,
 	const size_t* seg_counts, int nseg, const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
+	const void* src2_dev, const int* piece_source,
 	int key_shift, int key_bits, int* result_in_b, int* handled, GError** err) {
 	clo_sort_satradix_data* data = (clo_sort_satradix_data*) clo_sort_get_data(sorter);
 	const CloSortKeySpec* ks = clo_sort_get_key_spec(sorter);
@@ -570,7 +571,7 @@ static CCLEvent* clo_sort_satradix_sort_segments(CloSort* sorter, CCLQueue* cq_e
 		if (!evt) return NULL;
 	}
 	if (numel > 0) {
-		const int st = clo_hip_radix_sort_segmented(a_dev, a_dev, b_dev, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
+		const int st = clo_hip_radix_sort_segmented2(a_dev, src2_dev, a_dev, b_dev, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, piece_source, npieces,
 			ks->elem_size, key_shift, key_bits, (int) clo_tzc((int) data->radix), data->seg_ws.ptr, data->seg_ws.bytes,
 			ccl_queue_get_stream(cq_exec), result_in_b);
 		if (clo_hip_failed(st, err, "clo_hip_radix_sort_segmented")) {

@@ -1,7 +1,7 @@
 /*
  * clo_sort_sbitonic.c — host driver of the "sbitonic" sorter over HIP.
  * Mirrors the INTERFACE of src/cl_ops/sort/clo_sort_sbitonic.c:31-233 of the reference: no
- * options, one kernel name ("sbitonic"), no local memory reported, in place. Upstream runs the
+ * options, one kernel name ("sbitonic"), in place. Upstream runs the
  * bitonic network one launch per (stage, step) (:102-118); the network — the sequence of
  * compare-exchanges, and with it the result, ties included — does not depend on how its steps
  * are grouped into launches, so the steps run in the tiled schedule abitonic uses (registers and
@@ -51,11 +51,19 @@ static const char* clo_sort_sbitonic_get_kernel_name(CloSort* sorter, cl_uint i,
 	return CLO_SORT_SBITONIC_KNAME;
 }
 
+/* ref: clo_sort_sbitonic.c:206-222 — upstream's one kernel uses no local memory and says so. Here the steps run in the
+ * tiled schedule (see the head of this file), whose kernels stage their tile in LDS: the answer is the static LDS of
+ * the kernel that `numel` selects (nothing below 32 elements or on the one-launch-per-step schedule, the tile kernel
+ * above: include/clo_hip.h, clo_hip_bitonic_lds_bytes) — what the launches really hold, not upstream's 0. */
 static size_t clo_sort_sbitonic_get_localmem_usage(CloSort* sorter, cl_uint i, size_t lws_max,
 	size_t numel, GError** err) {
 	clo_return_val_if_fail(i == 0, 0);
-	(void) sorter; (void) lws_max; (void) numel; (void) err;
-	return 0;
+	(void) lws_max; (void) err;
+	clo_bitonic_state* state = (clo_bitonic_state*) clo_sort_get_data(sorter);
+	const int tiled = !(state && state->steps);
+	void* jit = clo_sort_get_jit(sorter);
+	if (jit) return clo_hip_bitonic_jit_lds_bytes(jit, numel, tiled);
+	return clo_hip_bitonic_lds_bytes(numel, (int) clo_sort_get_element_size(sorter), tiled);
 }
 
 /* ref: clo_sort_sbitonic.c:224-233 */

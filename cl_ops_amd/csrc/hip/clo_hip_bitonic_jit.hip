@@ -115,22 +115,25 @@ extern "C" __global__ __launch_bounds__(256) void jit_strided4(E* d, unsigned lo
 extern "C" __global__ __launch_bounds__(256) void jit_strided5(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<5>(d, n, s, p); }
 #endif
 
-extern "C" __global__ __launch_bounds__(256)
+// The tile kernels: CLO_JIT_TT = 512 threads on tiles of up to 512 * 2^Q elements (2^14 of up to 4 bytes, 2^13 of 8: 67 KiB
+// of LDS, two work-groups per CU) — the shape of the ahead-of-time kernels; round 4's 256 x 2^Q tiles meant one more
+// stage, and up to one more strided pass per stage, above the tile.
+extern "C" __global__ __launch_bounds__(CLO_JIT_TT)
 void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, int mode) {
 	constexpr int Q = CLO_JIT_Q;
 	constexpr int V = 1 << Q;
-	constexpr int TILE_MAX = 256 * V;
+	constexpr int TILE_MAX = CLO_JIT_TT * V;
 	__shared__ E s[TILE_MAX + TILE_MAX / 32];
 	const unsigned tid = threadIdx.x;
 	const unsigned tile = 1u << kl;
 	const unsigned nthr = tile >> Q;
 	const unsigned long gbase = (unsigned long) blockIdx.x << kl;
 	#define PHYS(i) ((i) + ((i) >> 5))
-	for (unsigned i = tid; i < tile; i += 256) s[PHYS(i)] = data[gbase + i];
+	for (unsigned i = tid; i < tile; i += CLO_JIT_TT) s[PHYS(i)] = data[gbase + i];
 	__syncthreads();
 	E v[V];
 	int cur_b0 = -1;
-	unsigned base = 0;
+	unsigned base = 0, pbase = 0;
 	const unsigned s_first = mode ? 1u : stage;
 	for (unsigned S = s_first; S <= stage; ++S) {
 		unsigned p = mode ? S : p_hi;
@@ -141,14 +144,17 @@ void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, 
 				if (cur_b0 >= 0) {
 					if (tid < nthr) {
 						#pragma unroll
-						for (int j = 0; j < V; ++j) s[PHYS(base + ((unsigned) j << cur_b0))] = v[j];
+						for (int j = 0; j < V; ++j) s[pbase + PHYS((unsigned) j << cur_b0)] = v[j];
 					}
 					__syncthreads();
 				}
+				// (the thread's base and the offsets j << b0 share no bits, so the padded slot of their sum is the sum of their
+				// padded slots: one per-thread value per group plus wave-uniform offsets — it was a shift and two adds per access)
 				base = ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u));
+				pbase = PHYS(base);
 				if (tid < nthr) {
 					#pragma unroll
-					for (int j = 0; j < V; ++j) v[j] = s[PHYS(base + ((unsigned) j << b0))];
+					for (int j = 0; j < V; ++j) v[j] = s[pbase + PHYS((unsigned) j << b0)];
 				}
 				cur_b0 = (int) b0;
 			}
@@ -158,10 +164,63 @@ void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, 
 	}
 	if (cur_b0 >= 0 && tid < nthr) {
 		#pragma unroll
-		for (int j = 0; j < V; ++j) s[PHYS(base + ((unsigned) j << cur_b0))] = v[j];
+		for (int j = 0; j < V; ++j) s[pbase + PHYS((unsigned) j << cur_b0)] = v[j];
 	}
 	__syncthreads();
-	for (unsigned i = tid; i < tile; i += 256) data[gbase + i] = s[PHYS(i)];
+	for (unsigned i = tid; i < tile; i += CLO_JIT_TT) data[gbase + i] = s[PHYS(i)];
+}
+
+// Steps KL .. 1 of a stage above the tile (the merge pass, one per stage: 13 of the 38 launches of a 2^26-key sort) with the
+// schedule fixed at COMPILE time (round 5): the groups of register bits are always [KL - Q, KL), [KL - 2Q, KL - Q), ...,
+// so every LDS access is the thread's padded base plus an immediate offset, and the direction — one bit of the tile's
+// number — is a scalar branch around two straight-line networks. (The run-time schedule above spends more VALU on
+// addresses and per-pair directions than on the user's compare.)
+template <bool DIR>
+__device__ __forceinline__ void cmpxch_u(E& e1, E& e2) {
+	const K a = (K) (CLO_SORT_KEY_GET_X(e1));
+	const K b = (K) (CLO_SORT_KEY_GET_X(e2));
+	const bool cmp = (bool) (CLO_SORT_COMPARE_AB(a, b));
+	if (cmp != DIR) { const E t = e1; e1 = e2; e2 = t; }
+}
+template <int V, int NSTEPS, bool DIR>
+__device__ __forceinline__ void reg_network_u(E (&v)[V]) {
+	#pragma unroll
+	for (int half = V / 2; half >= 1; half /= 2) {
+		if (half < (1 << NSTEPS)) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j)
+				if ((j & half) == 0) cmpxch_u<DIR>(v[j], v[j + half]);
+		}
+	}
+}
+// one group: the values at register bits [B0, B0 + Q) come out of LDS, NSTEPS steps run on them, they go back
+template <int P, bool DIR>
+__device__ __forceinline__ void merge_groups(E* s, unsigned tid) {
+	constexpr int Q = CLO_JIT_Q, V = 1 << Q;
+	constexpr int B0 = P > Q ? P - Q : 0, NSTEPS = P - B0;
+	const unsigned base = ((tid >> B0) << (B0 + Q)) | (tid & ((1u << B0) - 1u));
+	const unsigned pb = PHYS(base);
+	E v[V];
+	#pragma unroll
+	for (int j = 0; j < V; ++j) v[j] = s[pb + PHYS((unsigned) j << B0)];
+	reg_network_u<V, NSTEPS, DIR>(v);
+	#pragma unroll
+	for (int j = 0; j < V; ++j) s[pb + PHYS((unsigned) j << B0)] = v[j];
+	__syncthreads();   // (a thread rewrites exactly the slots it read: one barrier per group)
+	if constexpr (B0 > 0) merge_groups<B0, DIR>(s, tid);
+}
+extern "C" __global__ __launch_bounds__(CLO_JIT_TT, CLO_JIT_MERGE_WPE)
+void jit_merge(E* __restrict__ data, unsigned stage) {
+	constexpr int Q = CLO_JIT_Q, V = 1 << Q, KL = CLO_JIT_TB + Q, TILE = CLO_JIT_TT * V;
+	__shared__ E s[TILE + TILE / 32];
+	const unsigned tid = threadIdx.x;
+	const unsigned long gbase = (unsigned long) blockIdx.x << KL;
+	#pragma unroll
+	for (int k = 0; k < V; ++k) { const unsigned i = (unsigned) k * CLO_JIT_TT + tid; s[PHYS(i)] = data[gbase + i]; }
+	__syncthreads();
+	if ((gbase >> stage) & 1ul) merge_groups<KL, true>(s, tid); else merge_groups<KL, false>(s, tid);
+	#pragma unroll
+	for (int k = 0; k < V; ++k) { const unsigned i = (unsigned) k * CLO_JIT_TT + tid; data[gbase + i] = s[PHYS(i)]; }
 }
 
 // gselect with the user's two macro bodies pasted in, as upstream pastes them
@@ -190,9 +249,10 @@ void jit_gselect(const E* __restrict__ in, E* __restrict__ out, unsigned long n)
 
 struct jit_sorter {
 	hipModule_t module = nullptr;
-	hipFunction_t step = nullptr, step_any = nullptr, tile = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipFunction_t step = nullptr, step_any = nullptr, tile = nullptr, merge = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	int elem_size = 0;
 	int q = 0;
+	int tb = 0;   // thread bits of the tile kernels
 };
 
 const char* ctype_of(int clo_type) {
@@ -213,8 +273,10 @@ void set_log(char** log, const std::string& text) {
 	if (*log) memcpy(*log, text.c_str(), text.size() + 1);
 }
 
-int launch(hipFunction_t f, unsigned blocks, hipStream_t s, void** args) {
-	return (int) hipModuleLaunchKernel(f, blocks, 1, 1, 256, 1, 1, 0, s, args, nullptr);
+constexpr int JIT_TB = 9;   // thread bits of the tile kernels: 512 threads
+
+int launch(hipFunction_t f, unsigned blocks, hipStream_t s, void** args, unsigned threads = 256) {
+	return (int) hipModuleLaunchKernel(f, blocks, 1, 1, threads, 1, 1, 0, s, args, nullptr);
 }
 
 }  // namespace
@@ -238,6 +300,12 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	src += std::string("#define CLO_SORT_COMPARE_AB(a, b) ") + (compare ? compare : "((a) > (b))") + "\n";
 	src += std::string("#define CLO_SORT_KEY_GET_X(x) ") + (get_key ? get_key : "(x)") + "\n";
 	src += "#define CLO_JIT_Q " + std::to_string(q) + "\n";
+	// (experiment switches of round 5, read once per sorter: CLO_JIT_TB = 8 | 9, CLO_JIT_WPE = waves per SIMD the merge kernel is compiled for)
+	const char* env_tb = getenv("CLO_JIT_TB");
+	const char* env_wpe = getenv("CLO_JIT_WPE");
+	const int tb = (env_tb && (atoi(env_tb) == 8 || atoi(env_tb) == 9)) ? atoi(env_tb) : JIT_TB;
+	const int wpe = (env_wpe && atoi(env_wpe) >= 1 && atoi(env_wpe) <= 8) ? atoi(env_wpe) : 1;
+	src += "#define CLO_JIT_TB " + std::to_string(tb) + "\n#define CLO_JIT_TT " + std::to_string(1 << tb) + "\n#define CLO_JIT_MERGE_WPE " + std::to_string(wpe) + "\n";
 	src += k_src;
 
 	hiprtcProgram prog = nullptr;
@@ -267,10 +335,12 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	jit_sorter* js = new jit_sorter();
 	js->elem_size = es;
 	js->q = q;
+	js->tb = tb;
 	hipError_t e = hipModuleLoadData(&js->module, code.data());
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->step, js->module, "jit_step");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->step_any, js->module, "jit_step_any");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->tile, js->module, "jit_tile");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js->merge, js->module, "jit_merge");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->gselect, js->module, "jit_gselect");
 	for (int ns = 1; ns <= q && e == hipSuccess; ++ns) {
 		const std::string name = "jit_strided" + std::to_string(ns);
@@ -304,6 +374,15 @@ int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t
 	return launch(js->gselect, (unsigned) ((numel + 255) / 256), (hipStream_t) stream, args);
 }
 
+// Static LDS per work-group of the kernels clo_hip_bitonic_jit_sort launches for `numel` elements (introspection): only the
+// tiled schedule of a power of two from 2^Q elements on runs the tile kernel, whose array is sized for 512 x 2^Q elements.
+size_t clo_hip_bitonic_jit_lds_bytes(void* handle, size_t numel, int tiled) {
+	const jit_sorter* js = (const jit_sorter*) handle;
+	if (!js || numel <= 1 || !tiled || (numel & (numel - 1)) != 0 || numel < ((size_t) 1 << js->q)) return 0;
+	const size_t tile = (size_t) (1 << js->tb) << js->q;
+	return (tile + tile / 32) * (size_t) js->elem_size;
+}
+
 // In-place sort of data[0..numel). A power of two: tiled = 0: one launch per step; 1: the tile/strided
 // schedule (upstream's network). Any other numel: the flip network, one launch per step.
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream) {
@@ -328,7 +407,7 @@ int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, 
 		if (launches) *launches = count;
 		return st;
 	}
-	const unsigned Q = (unsigned) js->q, KL_MAX = 8 + Q;
+	const unsigned Q = (unsigned) js->q, KL_MAX = (unsigned) js->tb + Q;
 
 	if (!tiled || T < Q) {
 		unsigned long npairs = n / 2;
@@ -346,7 +425,7 @@ int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, 
 		unsigned stage = kl, p_hi = kl;
 		{
 			void* args[] = { &data, &kl, &stage, &p_hi, &mode };
-			st = launch(js->tile, tiles, s, args);
+			st = launch(js->tile, tiles, s, args, 1u << js->tb);
 			++count;
 		}
 		mode = 0;
@@ -361,9 +440,9 @@ int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, 
 				++count;
 				p -= ns;
 			}
-			if (!st) {
-				void* args[] = { &data, &kl, &stage, &p_hi, &mode };
-				st = launch(js->tile, tiles, s, args);
+			if (!st) {   // (stages above the tile only exist on full tiles, kl == KL_MAX: the compile-time schedule)
+				void* args[] = { &data, &stage };
+				st = launch(js->merge, tiles, s, args, 1u << js->tb);
 				++count;
 			}
 		}

@@ -112,14 +112,14 @@ size_t clo_radixw_partial_rows(size_t tiles);
 // comes as one piece per source rank): a tile never straddles pieces, its output goes to the segment's contiguous
 // place, so the first pass gathers the pieces as a by-product. Chunks never straddle segments. ----
 #define CLO_SEG_MAX 256
-struct clo_seg_tile { unsigned in_base, count_seg, out_base, seg_n; };  // the tile's first element in the source; count | segment << 16; where the segment starts in the output; its length
+struct clo_seg_tile { unsigned in_base, count_seg, out_base, seg_n; };  // the tile's first element in the source; count | segment << 16 | (second source) << 31; where the segment starts in the output; its length
 struct clo_seg_chunk { unsigned t0, tend, c_first, seg_last; };        // tiles [t0, tend) of the launch; first chunk of the same segment; segment | (last chunk of it) << 31
 struct clo_seg_pieces {                                                // (a kernel argument: no host buffer has to outlive the call) pieces in segment order
 	unsigned n[CLO_SEG_MAX], in_base[CLO_SEG_MAX];
-	unsigned short seg[CLO_SEG_MAX];
+	unsigned short seg[CLO_SEG_MAX];                                   // (bit 15: the piece lies in the call's second source)
 };
 struct clo_seg_tables { const clo_seg_tile* tiles; const clo_seg_chunk* chunks; unsigned ntiles, nchunks, nseg; };
-int clo_radixw_launch_tilehist_seg(const void* in, const clo_seg_tables& sg, int elem_size, int bits, unsigned shift, unsigned mask,
+int clo_radixw_launch_tilehist_seg(const void* in, const void* in2, const clo_seg_tables& sg, int elem_size, int bits, unsigned shift, unsigned mask,
 	unsigned* thist, unsigned* tinfo, unsigned* partial, bool big, hipStream_t s);
 int clo_radixw_launch_tilehist_bytes_seg(const unsigned char* dig, const clo_seg_tables& sg, int elem_size, int bits, unsigned mask,
 	unsigned* thist, unsigned* tinfo, unsigned* partial, bool big, hipStream_t s);
@@ -127,13 +127,13 @@ int clo_radixw_launch_tilehist_bytes_seg(const unsigned char* dig, const clo_seg
 int clo_radixw_launch_offsets_seg(int bits, const unsigned* thist, const clo_seg_tables& sg, unsigned* partial, unsigned* toff,
 	const unsigned** dbase, hipStream_t s);
 size_t clo_radixw_partial_rows_seg(size_t chunks, size_t nseg);
-// pieces (npieces <= CLO_SEG_MAX, ordered by segment): lengths, first elements, segments
-int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int nseg, size_t tile,
+// pieces (npieces <= CLO_SEG_MAX, ordered by segment): lengths, first elements, segments, source (0 / 1; may be null: all 0)
+int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const int* piece_seg, const int* piece_src, int npieces, int nseg, size_t tile,
 	clo_seg_tile* tiles, clo_seg_chunk* chunks, unsigned* ntiles, unsigned* nchunks, hipStream_t s);
 void clo_radixw_seg_bounds(size_t numel, int npieces, int nseg, size_t tile, size_t* max_tiles, size_t* max_chunks);
 size_t clo_radix4_seg_workspace_bytes(size_t n, int nseg, int elem_size, int digit_bits);
-int clo_radix4_sort_segmented(const void* src, void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
-	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int elem_size, int key_shift,
+int clo_radix4_sort_segmented(const void* src, const void* src2, void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
+	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, const int* piece_src, int npieces, int elem_size, int key_shift,
 	int key_bits, int digit_bits, void* ws, hipStream_t s, int* result_in_b);
 
 typedef unsigned long long clo_u64;

@@ -111,6 +111,13 @@ size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, 
 int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
 	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
 	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream, int* result_in_b) {
+	return clo_hip_radix_sort_segmented2(src, nullptr, a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, nullptr, npieces,
+		elem_size, key_shift, key_bits, digit_bits, workspace, workspace_bytes, stream, result_in_b);
+}
+
+int clo_hip_radix_sort_segmented2(const void* src, const void* src2, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, const int* piece_source, int npieces,
+	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream, int* result_in_b) {
 	if (!result_in_b) return CLO_HIP_EARGS;
 	*result_in_b = 0;
 	if (numel == 0) return 0;
@@ -128,6 +135,7 @@ int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel
 		for (int k = 0; k < nseg; ++k) per[k] = 0;
 		for (int i = 0; i < npieces; ++i) {
 			if (piece_segment[i] < 0 || piece_segment[i] >= nseg || piece_offsets[i] > 0xffffffffull || piece_counts[i] > numel) return CLO_HIP_EARGS;
+			if (piece_source && piece_source[i] != 0 && (piece_source[i] != 1 || !src2 || src2 == b)) return CLO_HIP_EARGS;   // (a piece of the second source needs one; the first pass writes b)
 			per[piece_segment[i]] += piece_counts[i];
 		}
 		for (int k = 0; k < nseg; ++k) if (per[k] != seg_counts[k]) return CLO_HIP_EARGS;
@@ -135,7 +143,7 @@ int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel
 	const size_t need = clo_radix4_seg_workspace_bytes(numel, nseg, elem_size, digit_bits);
 	if (need == 0) return CLO_HIP_EUNSUPPORTED;
 	if (workspace_bytes < need) return CLO_HIP_EWORKSPACE;
-	return clo_radix4_sort_segmented(src, a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces,
+	return clo_radix4_sort_segmented(src, src2, a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, npieces > 0 ? piece_source : nullptr, npieces,
 		elem_size, key_shift, key_bits, digit_bits, workspace, (hipStream_t) stream, result_in_b);
 }
 

@@ -61,7 +61,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	const unsigned* __restrict__ thist, const unsigned* __restrict__ toff, const unsigned* __restrict__ dbase,
 	const unsigned* __restrict__ tinfo, int aligned,
 	clo_keyx kx_in, clo_keyx kx_out, unsigned char* __restrict__ dig_out = nullptr, unsigned next_shift = 0,
-	const clo_seg_tile* __restrict__ tdesc = nullptr) {
+	const clo_seg_tile* __restrict__ tdesc = nullptr, const E* __restrict__ in2 = nullptr) {
 
 	constexpr int THREADS = pair_shape<E, BIG>::THREADS;
 	constexpr int ITEMS = pair_shape<E, BIG>::ITEMS;
@@ -93,7 +93,8 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		n32 = td.seg_n;
 		out += td.out_base;
 		if constexpr (DIG) dig_out += td.out_base;
-		dbase += (size_t) (td.count_seg >> 16) * R2;
+		dbase += (size_t) ((td.count_seg >> 16) & 0x7fffu) * R2;
+		if (td.count_seg >> 31) in = in2;   // (a piece in the call's second source; the same for the whole work-group)
 	} else {
 		if (base >= n) return;
 		count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
@@ -554,8 +555,8 @@ rp_seg_layout rp_make_seg_layout(size_t n, int nseg, int elem_size) {
 }
 
 template <typename E>
-int rp_sort_seg_impl(const E* src, E* a, E* b, size_t n, const size_t* seg_counts, int nseg,
-	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int key_shift, int key_bits, void* ws,
+int rp_sort_seg_impl(const E* src, const E* src2, E* a, E* b, size_t n, const size_t* seg_counts, int nseg,
+	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, const int* piece_src, int npieces, int key_shift, int key_bits, void* ws,
 	hipStream_t s, int* result_in_b) {
 	constexpr int LB = 4, HB = 4, PB = 8;
 	const int passes = (key_bits + PB - 1) / PB;
@@ -578,13 +579,13 @@ int rp_sort_seg_impl(const E* src, E* a, E* b, size_t n, const size_t* seg_count
 	sg.nseg = (unsigned) nseg;
 	{
 		clo_timing_scope timing("radix_seg_tables", s);
-		int st = clo_radixw_seg_build(seg_counts, seg_base, seg_id, nseg, nseg, L.tile, (clo_seg_tile*) sg.tiles, (clo_seg_chunk*) sg.chunks, &sg.ntiles, &sg.nchunks, s);
+		int st = clo_radixw_seg_build(seg_counts, seg_base, seg_id, nullptr, nseg, nseg, L.tile, (clo_seg_tile*) sg.tiles, (clo_seg_chunk*) sg.chunks, &sg.ntiles, &sg.nchunks, s);
 		if (st != 0) return st;
 		sg0 = sg;
 		if (npieces > 0) {
 			sg0.tiles = (const clo_seg_tile*) ((char*) ws + L.tdesc + up(L.max_tiles * sizeof(clo_seg_tile)));
 			sg0.chunks = (const clo_seg_chunk*) ((char*) ws + L.cdesc + up(L.max_chunks * sizeof(clo_seg_chunk)));
-			st = clo_radixw_seg_build(piece_n, piece_base, piece_seg, npieces, nseg, L.tile, (clo_seg_tile*) sg0.tiles, (clo_seg_chunk*) sg0.chunks, &sg0.ntiles, &sg0.nchunks, s);
+			st = clo_radixw_seg_build(piece_n, piece_base, piece_seg, piece_src, npieces, nseg, L.tile, (clo_seg_tile*) sg0.tiles, (clo_seg_chunk*) sg0.chunks, &sg0.ntiles, &sg0.nchunks, s);
 			if (st != 0) return st;
 		}
 	}
@@ -608,7 +609,7 @@ int rp_sort_seg_impl(const E* src, E* a, E* b, size_t n, const size_t* seg_count
 			clo_timing_scope timing("radix_hist", s);
 			const int st = (dig && p > 0)
 				? clo_radixw_launch_tilehist_bytes_seg(dig, sgp, (int) sizeof(E), PB, (mask_hi << LB) | mask_lo, thist, tinfo, partial, L.big, s)
-				: clo_radixw_launch_tilehist_seg(cur_in, sgp, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo, thist, tinfo, partial, L.big, s);
+				: clo_radixw_launch_tilehist_seg(cur_in, p == 0 ? src2 : nullptr, sgp, (int) sizeof(E), PB, shift, (mask_hi << LB) | mask_lo, thist, tinfo, partial, L.big, s);
 			if (st != 0) return st;
 		}
 		const unsigned* dbase = nullptr;
@@ -624,15 +625,15 @@ int rp_sort_seg_impl(const E* src, E* a, E* b, size_t n, const size_t* seg_count
 				if (dig && p + 1 < passes)
 					hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, true, true>), dim3(grid), dim3(pair_shape<E, true>::THREADS), 0, s,
 						(const E*) cur_in, cur_out, (size_t) sgp.ntiles, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, 0,
-						kx_none, kx_none, dig, next_shift, sgp.tiles);
+						kx_none, kx_none, dig, next_shift, sgp.tiles, p == 0 ? src2 : (const E*) nullptr);
 				else
 					hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, true, false, true>), dim3(grid), dim3(pair_shape<E, true>::THREADS), 0, s,
 						(const E*) cur_in, cur_out, (size_t) sgp.ntiles, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, 0,
-						kx_none, kx_none, nullptr, 0u, sgp.tiles);
+						kx_none, kx_none, nullptr, 0u, sgp.tiles, p == 0 ? src2 : (const E*) nullptr);
 			} else {
 				hipLaunchKernelGGL((clo_radix4_pair_kernel<E, LB, HB, false, false, true>), dim3(grid), dim3(pair_shape<E, false>::THREADS), 0, s,
 					(const E*) cur_in, cur_out, (size_t) sgp.ntiles, shift, mask_lo, mask_hi, (const unsigned*) thist, (const unsigned*) toff, dbase, (const unsigned*) tinfo, 0,
-					kx_none, kx_none, nullptr, 0u, sgp.tiles);
+					kx_none, kx_none, nullptr, 0u, sgp.tiles, p == 0 ? src2 : (const E*) nullptr);
 			}
 		}
 		cur_in = cur_out;
@@ -680,12 +681,12 @@ size_t clo_radix4_seg_workspace_bytes(size_t n, int nseg, int elem_size, int dig
 	return rp_make_seg_layout(n, nseg, elem_size).total;
 }
 
-int clo_radix4_sort_segmented(const void* src, void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
-	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int elem_size, int key_shift,
+int clo_radix4_sort_segmented(const void* src, const void* src2, void* a, void* b, size_t n, const size_t* seg_counts, int nseg,
+	const size_t* piece_n, const size_t* piece_base, const int* piece_seg, const int* piece_src, int npieces, int elem_size, int key_shift,
 	int key_bits, int digit_bits, void* ws, hipStream_t s, int* result_in_b) {
 	if (digit_bits != 4 && digit_bits != 8) return CLO_HIP_EUNSUPPORTED;
-	if (elem_size == 4) return rp_sort_seg_impl<uint32_t>((const uint32_t*) src, (uint32_t*) a, (uint32_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
-	if (elem_size == 8) return rp_sort_seg_impl<uint64_t>((const uint64_t*) src, (uint64_t*) a, (uint64_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, npieces, key_shift, key_bits, ws, s, result_in_b);
+	if (elem_size == 4) return rp_sort_seg_impl<uint32_t>((const uint32_t*) src, (const uint32_t*) src2, (uint32_t*) a, (uint32_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, piece_src, npieces, key_shift, key_bits, ws, s, result_in_b);
+	if (elem_size == 8) return rp_sort_seg_impl<uint64_t>((const uint64_t*) src, (const uint64_t*) src2, (uint64_t*) a, (uint64_t*) b, n, seg_counts, nseg, piece_n, piece_base, piece_seg, piece_src, npieces, key_shift, key_bits, ws, s, result_in_b);
 	return CLO_HIP_EUNSUPPORTED;
 }
 

@@ -385,7 +385,10 @@ template <typename E, bool BIG> struct pair_shape {
 // (8-byte elements gain from 32 MiB on — their digit stream is an eighth of the
 // array; 2^22 uint64 0.254 -> 0.234 ms, pairs 0.127 -> 0.119, profiles/r03_big_tile_threshold.txt —
 // 4-byte ones from 256 MiB: measured, docs/lab_notebook.md)
-inline size_t clo_big_tile_bytes(int elem_size) { return (size_t) (elem_size == 8 ? 32 : 256) << 20; }
+#ifndef CLO_BIG_TILE_MIB4
+#define CLO_BIG_TILE_MIB4 256   /* (experiment builds: EXTRA=-DCLO_BIG_TILE_MIB4=128) */
+#endif
+inline size_t clo_big_tile_bytes(int elem_size) { return (size_t) (elem_size == 8 ? 32 : CLO_BIG_TILE_MIB4) << 20; }
 inline bool clo_radix_big_tiles(size_t n, int elem_size) { return elem_size >= 4 && n * (size_t) elem_size >= clo_big_tile_bytes(elem_size); }
 // The digit stream (one byte per element between two passes) goes with the
 // big tiles: on 8 192-element tiles (arrays that sit in the last-level cache) its extra

@@ -21,12 +21,18 @@
 
 namespace {
 
-constexpr int RW_CHUNK = 128;   // tiles per chunk of the counter scan
+#ifndef CLO_RW_CHUNK
+#define CLO_RW_CHUNK 128
+#endif
+constexpr int RW_CHUNK = CLO_RW_CHUNK;   // tiles per chunk of the counter scan
 
 // the pair kernel's tile (clo_hip_radix_rank.h), one thread per 16 elements (8 of 8 bytes)
+#ifndef CLO_HIST_THREADS_DIV
+#define CLO_HIST_THREADS_DIV 1   /* (experiment builds: 2 = half the threads on the same tile, twice the loads in flight per thread) */
+#endif
 template <typename E, bool BIG> struct rw_shape {
 	static constexpr int TILE = pair_shape<E, BIG>::TILE;
-	static constexpr int THREADS = pair_shape<E, BIG>::THREADS;
+	static constexpr int THREADS = pair_shape<E, BIG>::THREADS / ((BIG && sizeof(E) == 4) ? CLO_HIST_THREADS_DIV : 1);
 	static constexpr int ITEMS = TILE / THREADS;
 };
 
@@ -52,11 +58,13 @@ __device__ __forceinline__ void rw_tile_info(unsigned h, unsigned count, unsigne
 }
 
 // Where a tile of a segmented launch lies (clo_hip_internal.h): one 16-byte load, the same for the whole work-group.
-__device__ __forceinline__ void rw_seg_tile(const clo_seg_tile* __restrict__ tdesc, size_t& base, unsigned& count, unsigned tile_elems) {
+// (bit 31 of count_seg: the tile lies in the launch's SECOND source — a piece that never travelled, clo_hip_radix_sort_segmented2)
+__device__ __forceinline__ bool rw_seg_tile(const clo_seg_tile* __restrict__ tdesc, size_t& base, unsigned& count, unsigned tile_elems) {
 	const clo_seg_tile td = tdesc[blockIdx.x];
 	base = (size_t) td.in_base;
 	count = td.count_seg & 0xffffu;
 	(void) tile_elems;
+	return (td.count_seg >> 31) != 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -68,7 +76,7 @@ template <typename E, int BITS, bool BIG, bool SEG = false>
 __global__ __launch_bounds__((rw_shape<E, BIG>::THREADS))
 void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
 	unsigned* __restrict__ thist, unsigned* __restrict__ tinfo, int aligned, clo_keyx kx,
-	unsigned* __restrict__ clear, unsigned clear_words, const clo_seg_tile* __restrict__ tdesc = nullptr) {
+	unsigned* __restrict__ clear, unsigned clear_words, const clo_seg_tile* __restrict__ tdesc = nullptr, const E* __restrict__ in2 = nullptr) {
 	constexpr int R = 1 << BITS;
 	constexpr int ITEMS = rw_shape<E, BIG>::ITEMS;
 	constexpr int TILE = rw_shape<E, BIG>::TILE;
@@ -85,7 +93,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	const unsigned tid = threadIdx.x, lane = tid & 63u;
 	size_t base = (size_t) blockIdx.x * TILE;
 	unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
-	if constexpr (SEG) rw_seg_tile(tdesc, base, count, (unsigned) TILE);
+	if constexpr (SEG) { if (rw_seg_tile(tdesc, base, count, (unsigned) TILE)) in = in2; }   // (the same for the whole work-group)
 	{   // (16-byte stores: a quarter of the LDS instructions of a dword loop)
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
 		const vec4u z = { 0u, 0u, 0u, 0u };
@@ -238,21 +246,28 @@ void clo_radixw_tilehist_bytes_kernel(const unsigned char* __restrict__ dig, siz
 //   partial: rows 0 .. chunks-1 the sums, row `chunks` word 0 the ticket, row chunks+1 dbase
 // ---------------------------------------------------------------------------
 constexpr int RW_CS_THREADS = 1024;
-template <int R> struct rw_cs {
-	static constexpr int G = (RW_CS_THREADS / R) < RW_CHUNK ? (RW_CS_THREADS / R) : RW_CHUNK;   // thread groups per chunk
-	static constexpr int SUB = RW_CHUNK / G;                                                      // rows per group
-	static_assert(G * SUB == RW_CHUNK && G * R <= RW_CS_THREADS, "the groups tile the chunk");
+// Arrays of up to RW_SMALL_TILES tiles scan their counters in chunks of RW_CHUNK_SMALL tiles: with 128-tile chunks a 2^24-key
+// sort (2 048 tiles) runs this latency-bound kernel on 16 work-groups of a 256-CU chip (round 5, profiles/r05_ab_mid_sizes.txt:
+// 2^22 keys 0.101 -> 0.093 ms per sort, 2^24 0.208 -> 0.204; from 4 096 tiles on the larger chunk is the faster one, at 16 384
+// tiles by a factor of two — the last chunk adds up the published rows of all earlier ones).
+constexpr int RW_CHUNK_SMALL = 32;
+constexpr unsigned RW_SMALL_TILES = 2048;
+constexpr int rw_chunk_for(unsigned tiles) { return tiles <= RW_SMALL_TILES ? RW_CHUNK_SMALL : RW_CHUNK; }
+template <int R, int CHUNK = RW_CHUNK> struct rw_cs {
+	static constexpr int G = (RW_CS_THREADS / R) < CHUNK ? (RW_CS_THREADS / R) : CHUNK;   // thread groups per chunk
+	static constexpr int SUB = CHUNK / G;                                                  // rows per group
+	static_assert(G * SUB == CHUNK && G * R <= RW_CS_THREADS, "the groups tile the chunk");
 };
 
 constexpr unsigned RW_WRITTEN = 0x80000000u;
 // SEG: the chunks of a segmented launch (cdesc): a chunk's tiles belong to ONE segment, it adds up the published sums of
 // the earlier chunks of ITS segment only (they hold earlier tickets, as before), and the last chunk of every segment
 // leaves that segment's digit bases in row chunks + 1 + segment.
-template <int R, bool SEG = false>
+template <int R, bool SEG = false, int CHUNK = RW_CHUNK>
 __global__ __launch_bounds__(RW_CS_THREADS)
 void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned tiles, unsigned chunks,
 	unsigned* __restrict__ partial, unsigned* __restrict__ toff, const clo_seg_chunk* __restrict__ cdesc = nullptr) {
-	constexpr int G = rw_cs<R>::G, SUB = rw_cs<R>::SUB;
+	constexpr int G = rw_cs<R, CHUNK>::G, SUB = rw_cs<R, CHUNK>::SUB;
 	constexpr int GA = RW_CS_THREADS / R;   // thread groups of the look-back (all threads)
 	constexpr int LB = 8;                   // published rows a thread asks for at once (16: the same times; 32: twice as long — registers)
 	__shared__ unsigned s_p[G * R], s_lb[GA * R], s_w[4], s_c;
@@ -263,8 +278,8 @@ void clo_radixw_offsets_lb_kernel(const unsigned* __restrict__ thist, unsigned t
 	// start in the order of their numbers often enough.)
 	__syncthreads();
 	const unsigned c = s_c;
-	unsigned t0 = c * RW_CHUNK;
-	unsigned tend = t0 + RW_CHUNK < tiles ? t0 + RW_CHUNK : tiles;
+	unsigned t0 = c * CHUNK;
+	unsigned tend = t0 + CHUNK < tiles ? t0 + CHUNK : tiles;
 	unsigned c_first = 0u, dbase_row = chunks + 1u;
 	bool last = c + 1u == chunks;
 	if constexpr (SEG) {
@@ -404,8 +419,8 @@ void clo_radix_seg_build_kernel(clo_seg_pieces pc, unsigned npieces, unsigned ti
 	if (tid < npieces) {
 		pn = pc.n[tid];
 		ptl = (pn + tile - 1u) / tile;
-		atomicAdd(&s_sn[pc.seg[tid]], pn);
-		atomicAdd(&s_stl[pc.seg[tid]], ptl);
+		atomicAdd(&s_sn[pc.seg[tid] & 0x7fffu], pn);   // (bit 15: the piece lies in the second source)
+		atomicAdd(&s_stl[pc.seg[tid] & 0x7fffu], ptl);
 	}
 	__syncthreads();
 	if (tid < (unsigned) CLO_SEG_MAX) {
@@ -427,10 +442,10 @@ void clo_radix_seg_build_kernel(clo_seg_pieces pc, unsigned npieces, unsigned ti
 	if (i < ntiles) {   // the piece p with s_pt[p] <= i < s_pt[p + 1] (empty pieces have empty ranges)
 		unsigned lo = 0, hi = CLO_SEG_MAX;
 		while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (s_pt[mid] <= i) lo = mid; else hi = mid; }
-		const unsigned off = (i - s_pt[lo]) * tile, left = pc.n[lo] - off, sg = pc.seg[lo];
+		const unsigned off = (i - s_pt[lo]) * tile, left = pc.n[lo] - off, sg = pc.seg[lo] & 0x7fffu, from2 = pc.seg[lo] >> 15;
 		clo_seg_tile td;
 		td.in_base = pc.in_base[lo] + off;
-		td.count_seg = (left < tile ? left : tile) | (sg << 16);
+		td.count_seg = (left < tile ? left : tile) | (sg << 16) | (from2 << 31);
 		td.out_base = s_ob[sg];
 		td.seg_n = s_sn[sg];
 		tdesc[i] = td;
@@ -456,7 +471,7 @@ void clo_radixw_seg_bounds(size_t numel, int npieces, int nseg, size_t tile, siz
 	*max_chunks = *max_tiles / RW_CHUNK + (size_t) nseg;
 }
 
-int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const int* piece_seg, int npieces, int nseg, size_t tile,
+int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const int* piece_seg, const int* piece_src, int npieces, int nseg, size_t tile,
 	clo_seg_tile* tiles, clo_seg_chunk* chunks, unsigned* ntiles, unsigned* nchunks, hipStream_t s) {
 	if (nseg < 1 || nseg > CLO_SEG_MAX || npieces < 1 || npieces > CLO_SEG_MAX) return CLO_HIP_EARGS;
 	clo_seg_pieces c;
@@ -471,7 +486,7 @@ int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const 
 		prev = sg;
 		c.n[i] = (unsigned) n;
 		c.in_base[i] = i < npieces ? (unsigned) piece_base[i] : 0u;
-		c.seg[i] = (unsigned short) sg;
+		c.seg[i] = (unsigned short) (sg | ((i < npieces && piece_src && piece_src[i]) ? 0x8000 : 0));
 		const size_t t = (n + tile - 1) / tile;
 		seg_tiles[sg] += t;
 		nt += t;
@@ -490,23 +505,23 @@ int clo_radixw_seg_build(const size_t* piece_n, const size_t* piece_base, const 
 size_t clo_radixw_partial_rows_seg(size_t chunks, size_t nseg) { return chunks + 1 + nseg; }
 
 template <typename E>
-static int rw_launch_tilehist_seg(const void* in, const clo_seg_tables& sg, int bits, unsigned shift, unsigned mask, unsigned* thist,
+static int rw_launch_tilehist_seg(const void* in, const void* in2, const clo_seg_tables& sg, int bits, unsigned shift, unsigned mask, unsigned* thist,
 	unsigned* tinfo, unsigned* partial, bool big, hipStream_t s) {
 	const unsigned clear_words = (sg.nchunks + 1u) << bits;
 	const clo_keyx kx_none = { 0, 0, 0 };
 	if (bits != 8) return CLO_HIP_EUNSUPPORTED;   // (the segmented sorts run the radix-16 / 256 schedule only)
 	if (big) hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, 8, true, true>), dim3(sg.ntiles), dim3(rw_shape<E, true>::THREADS), 0, s,
-		(const E*) in, (size_t) 0, shift, mask, thist, tinfo, 0, kx_none, partial, clear_words, sg.tiles);
+		(const E*) in, (size_t) 0, shift, mask, thist, tinfo, 0, kx_none, partial, clear_words, sg.tiles, (const E*) in2);
 	else hipLaunchKernelGGL((clo_radixw_tilehist_kernel<E, 8, false, true>), dim3(sg.ntiles), dim3(rw_shape<E, false>::THREADS), 0, s,
-		(const E*) in, (size_t) 0, shift, mask, thist, tinfo, 0, kx_none, partial, clear_words, sg.tiles);
+		(const E*) in, (size_t) 0, shift, mask, thist, tinfo, 0, kx_none, partial, clear_words, sg.tiles, (const E*) in2);
 	return (int) hipGetLastError();
 }
 
-int clo_radixw_launch_tilehist_seg(const void* in, const clo_seg_tables& sg, int elem_size, int bits, unsigned shift, unsigned mask,
+int clo_radixw_launch_tilehist_seg(const void* in, const void* in2, const clo_seg_tables& sg, int elem_size, int bits, unsigned shift, unsigned mask,
 	unsigned* thist, unsigned* tinfo, unsigned* partial, bool big, hipStream_t s) {
 	switch (elem_size) {
-		case 4: return rw_launch_tilehist_seg<uint32_t>(in, sg, bits, shift, mask, thist, tinfo, partial, big, s);
-		case 8: return rw_launch_tilehist_seg<uint64_t>(in, sg, bits, shift, mask, thist, tinfo, partial, big, s);
+		case 4: return rw_launch_tilehist_seg<uint32_t>(in, in2, sg, bits, shift, mask, thist, tinfo, partial, big, s);
+		case 8: return rw_launch_tilehist_seg<uint64_t>(in, in2, sg, bits, shift, mask, thist, tinfo, partial, big, s);
 		default: return CLO_HIP_EUNSUPPORTED;
 	}
 }
@@ -590,16 +605,17 @@ int clo_radixw_launch_tilehist_bytes(const unsigned char* dig, size_t n, int ele
 
 // Words of `partial` the histogram launch zeroes for the scan: the chunk sums and the ticket's row (0: one tile, nothing to hand over).
 unsigned clo_radixw_clear_words(int bits, unsigned tiles) {
-	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
+	const unsigned chunk = (unsigned) rw_chunk_for(tiles), chunks = (tiles + chunk - 1) / chunk;
 	return tiles > 1 ? ((chunks + 1u) << bits) : 0u;   // (chunks + 1 <= tiles: every word has a thread of the launch)
 }
 // Rows of (1 << bits) words `partial` needs.
-size_t clo_radixw_partial_rows(size_t tiles) { return (tiles + RW_CHUNK - 1) / RW_CHUNK + 2; }
+size_t clo_radixw_partial_rows(size_t tiles) { const size_t chunk = (size_t) rw_chunk_for((unsigned) (tiles > 0xffffffffull ? 0xffffffffull : tiles)); return (tiles + chunk - 1) / chunk + 2; }
 
 // *dbase: null — toff holds the final offsets (one tile) —, or the row of digit bases the consumer adds to toff[tile][digit].
 int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, unsigned* partial, unsigned* toff,
 	const unsigned** dbase, hipStream_t s) {
-	const unsigned chunks = (tiles + RW_CHUNK - 1) / RW_CHUNK;
+	const unsigned chunk = (unsigned) rw_chunk_for(tiles);
+	const unsigned chunks = (tiles + chunk - 1) / chunk;
 	*dbase = nullptr;
 	#define CLO_RW_OFF1(B) case B: hipLaunchKernelGGL((clo_radixw_offsets1_kernel<(1 << B)>), dim3(1), dim3(256), 0, s, thist, tiles, toff); break
 	if (tiles == 1) {
@@ -611,7 +627,9 @@ int clo_radixw_launch_offsets(int bits, const unsigned* thist, unsigned tiles, u
 	}
 	#undef CLO_RW_OFF1
 	#define CLO_RW_LB(B) case B: \
-		hipLaunchKernelGGL((clo_radixw_offsets_lb_kernel<(1 << B)>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, chunks, partial, toff); break
+		if (chunk == (unsigned) RW_CHUNK) hipLaunchKernelGGL((clo_radixw_offsets_lb_kernel<(1 << B), false, RW_CHUNK>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, chunks, partial, toff); \
+		else hipLaunchKernelGGL((clo_radixw_offsets_lb_kernel<(1 << B), false, RW_CHUNK_SMALL>), dim3(chunks), dim3(RW_CS_THREADS), 0, s, thist, tiles, chunks, partial, toff); \
+		break
 	switch (bits) {
 		CLO_RW_LB(1); CLO_RW_LB(2); CLO_RW_LB(3); CLO_RW_LB(4); CLO_RW_LB(5); CLO_RW_LB(6); CLO_RW_LB(7); CLO_RW_LB(8);
 		default: return CLO_HIP_EUNSUPPORTED;

@@ -199,8 +199,11 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 	// workspace left in the header (its last work-group to leave wrote it, below;
 	// clo_hip_scan_workspace_init wrote 0). Every work-group of the launch reads it
 	// before that happens again: the header only changes when all have left.
+	// (requested here, waited for only where the first tile's loads have been issued: the ticket below and this load are two
+	// round trips to memory that would otherwise stand one behind the other in front of every work-group's first load)
+	const unsigned epoch_raw = __hip_atomic_load(&hdr[CLO_WS_EPOCH_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	scan_ctl ctl;
-	ctl.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) __hip_atomic_load(&hdr[CLO_WS_EPOCH_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+	ctl.epoch = 0;
 	ctl.max_spins = max_spins;
 	ctl.status = &hdr[0];
 	const unsigned tiles = last_tile + 1u;
@@ -225,6 +228,7 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 		if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_DONE_WORD], 1u);
 		__syncthreads();
 		if (s_tile != gridDim.x - 1u) return;
+		ctl.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) epoch_raw) + 1u;
 		const bool wrap = ctl.epoch >= CLO_LB_EPOCH_MAX;
 		if (wrap) {
 			clo_u64* g = reinterpret_cast<clo_u64*>(reinterpret_cast<char*>(hdr) + CLO_WS_HEADER_BYTES);
@@ -262,6 +266,8 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 			}
 		}
 	}
+
+	ctl.epoch = (unsigned) __builtin_amdgcn_readfirstlane((int) epoch_raw) + 1u;   // (wave-uniform: scalar from here on)
 
 	// ---- in-lane inclusive prefix, wave scan of lane totals per row ----
 	TSum lane_excl[ROWS];

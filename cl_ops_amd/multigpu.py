@@ -455,6 +455,12 @@ class CShardedSorter:
     def collect_phase_times(self):
         return dict(self.phase_times or {})
 
+    def finish(self, timeout_ms=0):
+        """Bounded wait (clo_shard_sort_finish) for what the last sort left running on the current stream's queue: raises
+        CloError when `timeout_ms` (0: the `timeout_ms` option; that being 0 too: no bound) have passed or the transport has
+        failed — a peer that died must not hang this rank. The object is then only good for close()."""
+        self.ss.finish(self.queue, timeout_ms)
+
     def check(self):
         """ccl_queue_finish on the queues this object has sorted on: synchronises and raises CloError(CLO_ERROR_LIBRARY)
         if a kernel of a local sort gave up a bounded look-back spin (a caller that only synchronises through torch

@@ -221,6 +221,15 @@ int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel
 	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
 	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream,
 	int* result_in_b);
+/* The same with the pieces in TWO sources: piece i lies in `src2` when piece_source[i] is 1 (piece_source NULL: all in
+ * `src`), its offset counted from that source's start. What it is for: the piece of a sub-bucket that a rank of the
+ * sharded sort keeps for itself never needs to move — it is gathered straight out of the partitioned shard, and the
+ * rank's own share of every exchange (1 / G of the bytes; all of them on one rank) is not copied at all. `src2` is
+ * only read, by the first pass; it must not be `b`. */
+int clo_hip_radix_sort_segmented2(const void* src, const void* src2, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, const int* piece_source, int npieces,
+	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream,
+	int* result_in_b);
 
 /* MSD bucket partition used by the multi-GPU exchange (new
  * functionality): stable split of src into 1<<bucket_bits buckets by the top
@@ -314,6 +323,8 @@ void clo_hip_bitonic_jit_destroy(void* handle);
  * src -> dst (distinct), ties by index. */
 int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t numel, void* stream);
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream);
+/* Static LDS bytes per work-group of the kernels that call would launch (0: one launch per step, registers only). */
+size_t clo_hip_bitonic_jit_lds_bytes(void* handle, size_t numel, int tiled);
 
 /* ---- satradix specialised at run time (hiprtc) for a get_key expression
  *      outside the ahead-of-time family: the key is materialised as

@@ -100,6 +100,12 @@ extern const CloSortImplDef clo_sort_satradix_def;  /* clo_sort_satradix.in.h:55
 #define CLO_SORT_SATRADIX_KNAME_LOCALSORT "satradix_localsort"
 #define CLO_SORT_SATRADIX_KNAME_HISTOGRAM "satradix_histogram"
 #define CLO_SORT_SATRADIX_KNAME_SCATTER "satradix_scatter"
+/* The 26 abitonic names (abit_any, abit_local_s2 .. s11, abit_priv_*, abit_hyb_*) are UPSTREAM's kernel list
+ * (clo_sort_abitonic.in.h:64-106), reported for API compatibility: the HIP schedule launches four kernels of its own
+ * (a tile presort, a tile merge and two strided kernels). clo_sort_get_localmem_usage answers for the
+ * kernel that `numel` selects: 0 for the names that stand for register-only kernels ("any", "priv"), the tile kernels'
+ * static LDS for the others; sbitonic's one name answers for the tiled schedule it runs (0 only below 32 elements or
+ * with CLO_SBITONIC_STEPS=1). */
 #define CLO_SORT_ABITONIC_NUM_KERNELS 26
 
 /* Not upstream — parsed form of (elem_type, key_type, compare, get_key) shared

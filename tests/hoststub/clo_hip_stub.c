@@ -88,6 +88,7 @@ int clo_hip_timing_enabled(void) { return 0; }
 int clo_hip_timing_reset(void) { return 0; }
 int clo_hip_timing_read(const char* label, unsigned* count, float* total_ms) { (void) label; if (count) *count = 0; if (total_ms) *total_ms = 0; return 0; }
 size_t clo_hip_kernel_lds_bytes(const char* family, int elem_size, int param) { (void) family; (void) elem_size; (void) param; return 0; }
+size_t clo_hip_bitonic_lds_bytes(size_t numel, int elem_size, int tiled) { (void) numel; (void) elem_size; (void) tiled; return 0; }
 
 /* ---- keys ---- */
 static uint64_t load_elem(const void* p, int es) {
@@ -170,6 +171,12 @@ size_t clo_hip_radix_seg_workspace_bytes(size_t numel, int nseg, int elem_size, 
 int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
 	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, int npieces,
 	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream, int* result_in_b) {
+	return clo_hip_radix_sort_segmented2(src, NULL, a, b, numel, seg_counts, nseg, piece_counts, piece_offsets, piece_segment, NULL, npieces,
+		elem_size, key_shift, key_bits, digit_bits, workspace, workspace_bytes, stream, result_in_b);
+}
+int clo_hip_radix_sort_segmented2(const void* src, const void* src2, void* a, void* b, size_t numel, const size_t* seg_counts, int nseg,
+	const size_t* piece_counts, const size_t* piece_offsets, const int* piece_segment, const int* piece_source, int npieces,
+	int elem_size, int key_shift, int key_bits, int digit_bits, void* workspace, size_t workspace_bytes, void* stream, int* result_in_b) {
 	(void) stream;
 	if (!result_in_b) return CLO_HIP_EARGS;
 	*result_in_b = 0;
@@ -194,7 +201,9 @@ int clo_hip_radix_sort_segmented(const void* src, void* a, void* b, size_t numel
 			if (piece_segment[i] < prev || piece_segment[i] >= nseg) { free(gathered); return CLO_HIP_EARGS; }
 			prev = piece_segment[i];
 			per[piece_segment[i]] += piece_counts[i];
-			memcpy(gathered + at * es, (const char*) src + piece_offsets[i] * es, piece_counts[i] * es);   /* (a piece outside the source: ASan says so) */
+			const int from2 = piece_source && piece_source[i];
+			if (from2 && (piece_source[i] != 1 || !src2 || src2 == (const void*) b)) { free(gathered); return CLO_HIP_EARGS; }
+			memcpy(gathered + at * es, (const char*) (from2 ? src2 : src) + piece_offsets[i] * es, piece_counts[i] * es);   /* (a piece outside its source: ASan says so) */
 			at += piece_counts[i];
 		}
 		for (int k = 0; k < nseg; ++k) if (per[k] != seg_counts[k]) { free(gathered); return CLO_HIP_EARGS; }
@@ -337,6 +346,7 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 void clo_hip_bitonic_jit_destroy(void* handle) { (void) handle; }
 int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t numel, void* stream) { (void) handle; (void) src; (void) dst; (void) numel; (void) stream; return CLO_HIP_EUNSUPPORTED; }
 int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, int* launches, void* stream) { (void) handle; (void) data; (void) numel; (void) tiled; (void) launches; (void) stream; return CLO_HIP_EUNSUPPORTED; }
+size_t clo_hip_bitonic_jit_lds_bytes(void* handle, size_t numel, int tiled) { (void) handle; (void) numel; (void) tiled; return 0; }
 int clo_hip_radix_jit_create(int elem_type, int key_type, const char* get_key, const char* compiler_opts, void** handle, char** log) {
 	(void) elem_type; (void) key_type; (void) get_key; (void) compiler_opts;
 	if (handle) *handle = NULL;

@@ -2,9 +2,9 @@
 # Runs ON THE GPU BOX (through gpurun): bench lines, rocprofv3 kernel stats, the two PMC passes for the HBM traffic of
 # every workload, the harness sweeps and the probes. Raw output goes to gpurun_out/$TAG/; tools/summarize_profiles.py
 # turns it into the files under profiles/. One part per gpurun call (a call is limited to 20 minutes):
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r04 bench'     (parts: bench trace pmc harness probes sq shard)
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r05 bench'     (parts: bench trace pmc harness probes sq shard)
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-bench}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -62,6 +62,8 @@ probes)
 	python3 "$ROOT/tools/mid_probe.py" uint 22 28 > "$OUT/mid_probe.txt" 2>&1 || exit 1
 	python3 "$ROOT/tools/skew_probe.py" 28 u32 > "$OUT/skew_probe.txt" 2>&1 || exit 1
 	python3 "$ROOT/tools/hostsort_pipe_probe.py" 24 26 28 > "$OUT/hostsort_pipeline.txt" 2>&1 || exit 1
+	python3 "$ROOT/tools/jit_probe.py" > "$OUT/jit_probe.txt" 2>&1 || exit 1
+	python3 "$ROOT/tools/scan_sizes_probe.py" > "$OUT/scan_sizes_probe.txt" 2>&1 || exit 1
 	echo "probes done" ;;
 shard)
 	python3 "$ROOT/tools/shard_alone_probe.py" 28 both > "$OUT/shard_alone_probe.txt" 2>&1 || exit 1

@@ -152,7 +152,7 @@ for workload in ("satradix_pairs", "satradix_u64"):
 
 # ---- SQ counters of the kernels that ship (tools/pmc_busy.sh) and the other probes of the collection ----
 for extra in ("sq_counters_satradix_u32.txt", "sq_counters_satradix_u64.txt", "skew_probe.txt", "skew_probe_u64.txt",
-              "hostsort_pipeline.txt", "size_sweep.txt", "sweep_sizes_big.txt", "mid_probe.txt", "shard_alone_probe.txt", "seg_probe.txt",
+              "hostsort_pipeline.txt", "size_sweep.txt", "sweep_sizes_big.txt", "mid_probe.txt", "shard_alone_probe.txt", "seg_probe.txt", "jit_probe.txt", "scan_sizes_probe.txt",
               "bench_headline_with_configs.json"):
     f = os.path.join(src, extra)
     if os.path.exists(f):
@@ -231,3 +231,124 @@ for workload in ("satradix_u32", "satradix_pairs", "satradix_u64", "scan", "abit
                 if k["name"] in d["families"]:
                     d["families"][k["name"]]["sweep_launches_per_step"] = k["launches_per_step"]
     json.dump(d, open(tj, "w"), indent=1)
+
+# ---- round 5: ONE file per workload in which the roofline can be recomputed ----
+# For every workload the trace part ran:  rocprofv3 --kernel-trace --stats -- python3 bench.py --workload W ...
+# That one process produced BOTH the rocprofv3 per-kernel durations (kernel_stats.csv) and bench.py's own line
+# (trace_W.json: HIP-event means over its extra instrumented steps, the step time under the profiler). Joined here with
+# the PMC bytes per launch (separate --pmc passes, above) and the unprofiled bench line of the same collection.
+def _line(path):
+    try:
+        return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        return None
+
+
+def _rocprof_families(workload):
+    best, best_calls = None, -1
+    for f in glob.glob(os.path.join(src, "trace_" + workload, "*", "*kernel_stats.csv")):
+        rows = list(csv.DictReader(open(f)))
+        calls = sum(int(r["Calls"]) for r in rows)
+        if calls > best_calls:
+            best, best_calls = rows, calls
+    fams = {}
+    for r in best or []:
+        name = short(r["Name"])
+        fam = next((lab for needle, lab in FAMILY_OF if needle in name), None)
+        if fam is None:
+            continue
+        d = fams.setdefault(fam, {"calls": 0, "total_ns": 0.0, "kernels": []})
+        d["calls"] += int(r["Calls"])
+        d["total_ns"] += float(r["TotalDurationNs"])
+        d["kernels"].append({"name": name[:120], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 3)})
+    return fams
+
+
+def _rocprof_trace(workload, steps):
+    """Per family, from the dispatch records of the same process (kernel_trace.csv, in dispatch order): the mean duration
+    over the launches of the TIMED steps (kernels back to back) and over those of the INSTRUMENTED steps (the last `steps`
+    steps: the very launches bench.py's event pairs bracket), and the timed steps' length first start -> last end."""
+    best = None
+    for f in glob.glob(os.path.join(src, "trace_" + workload, "*", "*kernel_trace.csv")):
+        rows = list(csv.DictReader(open(f)))
+        if best is None or len(rows) > len(best):
+            best = rows
+    if not best:
+        return {}, None
+    best.sort(key=lambda r: int(r["Start_Timestamp"]))
+    per = {}
+    for r in best:
+        fam = next((lab for needle, lab in FAMILY_OF if needle in r["Kernel_Name"]), None)
+        if fam:
+            per.setdefault(fam, []).append(r)
+    out = dict(per)
+    return out, best
+
+
+for w in ("satradix_u32", "satradix_pairs", "satradix_u64", "scan", "abitonic"):
+    prof_line = _line(os.path.join(src, "trace_%s.json" % w))
+    rp = _rocprof_families(w)
+    if not prof_line or not rp:
+        continue
+    plain = _line(os.path.join(src, "bench_%s.json" % w))
+    try:
+        traffic = json.load(open(os.path.join(dst, "traffic_%s.json" % w))).get("families", {})
+    except Exception:
+        traffic = {}
+    steps_profiled = prof_line["steps"]
+    ev = {k["name"]: k for k in prof_line["roofline"].get("kernels", [])}
+    tr, all_rows = _rocprof_trace(w, steps_profiled)
+    fams = []
+    timed_window = None
+    for fam, d in sorted(rp.items(), key=lambda kv: -kv[1]["total_ns"]):
+        e = ev.get(fam)
+        b = (traffic.get(fam) or {}).get("hbm_bytes_per_launch") or (e or {}).get("bytes_per_launch")
+        rp_ms = d["total_ns"] / d["calls"] / 1e6
+        row = {"family": fam, "rocprof_calls": d["calls"], "rocprof_mean_ms": round(rp_ms, 5),
+               "events_mean_ms_same_run": (e or {}).get("avg_launch_ms"),
+               "pmc_bytes_per_launch": b,
+               "frac_rocprof_all_launches": round(b / (rp_ms * 1e-3) / 8e12, 4) if b else None,
+               "frac_events_same_run": round(b / (e["avg_launch_ms"] * 1e-3) / 8e12, 4) if b and e and e.get("avg_launch_ms") else None}
+        rows = tr.get(fam)
+        lps = int(round(e["launches_per_step"])) if e and e.get("launches_per_step") else None
+        if rows and lps and len(rows) >= 2 * steps_profiled * lps:
+            k = steps_profiled * lps
+            dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            instr, timed = rows[-k:], rows[-2 * k:-k]
+            row["rocprof_mean_ms_instrumented_launches"] = round(sum(map(dur, instr)) / k, 5)   # the launches the events bracket
+            row["rocprof_mean_ms_timed_launches"] = round(sum(map(dur, timed)) / k, 5)          # the launches of the timed region
+            row["rocprof_over_events_same_launches"] = round(row["rocprof_mean_ms_instrumented_launches"] / e["avg_launch_ms"], 4)
+            if b:
+                row["frac_rocprof_instrumented_launches"] = round(b / (row["rocprof_mean_ms_instrumented_launches"] * 1e-3) / 8e12, 4)
+                row["frac_rocprof_timed_launches"] = round(b / (row["rocprof_mean_ms_timed_launches"] * 1e-3) / 8e12, 4)
+            w0, w1 = int(timed[0]["Start_Timestamp"]), int(timed[-1]["End_Timestamp"])
+            timed_window = (min(w0, timed_window[0]), max(w1, timed_window[1])) if timed_window else (w0, w1)
+        row["kernels"] = d["kernels"]
+        fams.append(row)
+    dom = prof_line["roofline"].get("kernel")
+    out = {"workload": w,
+           "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps %d --warmup %d --no-cpu-baseline --no-configs"
+                      % (w, prof_line["steps"], prof_line["warmup"]),
+           "how_to_read": "ONE process produced every duration here. rocprof_mean_ms: its kernel_stats.csv (all launches: warm-up, timed and "
+                          "instrumented steps). bench.py first times `steps` steps with the kernels back to back (no events in between), then runs "
+                          "`steps` more with a HIP-event pair around every launch: events_mean_ms_same_run. rocprof_mean_ms_instrumented_launches / "
+                          "_timed_launches: rocprofv3's own dispatch records (kernel_trace.csv) of exactly those two groups of launches — the first is "
+                          "the same launches the events bracket (rocprof_over_events_same_launches is their ratio), the second is what the kernels "
+                          "take inside the timed region, where a kernel starts while its predecessor's stores are still draining. "
+                          "pmc_bytes_per_launch: FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes (profiles/traffic_%s.json). "
+                          "frac = bytes / duration / 8 TB/s." % w,
+           "dominant_kernel": dom,
+           "line_frac_events_same_run": prof_line["roofline"].get("frac"),
+           "frac_from_rocprof_same_launches": next((r.get("frac_rocprof_instrumented_launches") for r in fams if r["family"] == dom), None),
+           "frac_from_rocprof_timed_launches": next((r.get("frac_rocprof_timed_launches") for r in fams if r["family"] == dom), None),
+           "frac_from_rocprof_all_launches": next((r["frac_rocprof_all_launches"] for r in fams if r["family"] == dom), None),
+           "ms_per_step_under_rocprofv3": prof_line.get("ms_per_step"),
+           "ms_per_step_from_rocprof_dispatch_records_of_the_timed_steps": round((timed_window[1] - timed_window[0]) / 1e6 / steps_profiled, 5) if timed_window else None,
+           "ms_per_step_unprofiled_same_box_collection": plain.get("ms_per_step") if plain else None,
+           "line_frac_unprofiled": plain["roofline"].get("frac") if plain else None,
+           "step_frac_unprofiled": plain["roofline"].get("step_frac") if plain else None,
+           "steps_in_profiled_run": steps_profiled,
+           "families": fams}
+    json.dump(out, open(os.path.join(dst, "%s_roofline_%s.json" % (tag, w)), "w"), indent=1)
+    print("roofline file:", w, "dominant", dom, "frac: events", out["line_frac_events_same_run"], "rocprof same launches", out["frac_from_rocprof_same_launches"],
+          "rocprof timed launches", out["frac_from_rocprof_timed_launches"], "step ms bench/rocprof", out["ms_per_step_under_rocprofv3"], out["ms_per_step_from_rocprof_dispatch_records_of_the_timed_steps"])
