@@ -115,9 +115,7 @@ extern "C" __global__ __launch_bounds__(256) void jit_strided4(E* d, unsigned lo
 extern "C" __global__ __launch_bounds__(256) void jit_strided5(E* d, unsigned long n, unsigned s, unsigned p) { strided_body<5>(d, n, s, p); }
 #endif
 
-// The tile kernels: CLO_JIT_TT = 512 threads on tiles of up to 512 * 2^Q elements (2^14 of up to 4 bytes, 2^13 of 8: 67 KiB
-// of LDS, two work-groups per CU) — the shape of the ahead-of-time kernels; round 4's 256 x 2^Q tiles meant one more
-// stage, and up to one more strided pass per stage, above the tile.
+// The tile kernels: CLO_JIT_TT threads on tiles of up to CLO_JIT_TT * 2^Q elements (see JIT_TB on the host side).
 extern "C" __global__ __launch_bounds__(CLO_JIT_TT)
 void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, int mode) {
 	constexpr int Q = CLO_JIT_Q;
@@ -172,30 +170,30 @@ void jit_tile(E* __restrict__ data, unsigned kl, unsigned stage, unsigned p_hi, 
 
 // Steps KL .. 1 of a stage above the tile (the merge pass, one per stage: 13 of the 38 launches of a 2^26-key sort) with the
 // schedule fixed at COMPILE time (round 5): the groups of register bits are always [KL - Q, KL), [KL - 2Q, KL - Q), ...,
-// so every LDS access is the thread's padded base plus an immediate offset, and the direction — one bit of the tile's
-// number — is a scalar branch around two straight-line networks. (The run-time schedule above spends more VALU on
-// addresses and per-pair directions than on the user's compare.)
-template <bool DIR>
-__device__ __forceinline__ void cmpxch_u(E& e1, E& e2) {
+// so every LDS access is the thread's padded base plus an immediate offset, and the direction is one bit of the tile's
+// number. (The run-time schedule above spends more VALU on addresses and per-pair directions than on the user's compare.)
+// (`dir` is the same for the whole work-group: the compare's lane mask is flipped by a scalar instruction. Two straight-line
+// networks under a scalar branch, one per direction, doubled the time hiprtc takes for these kernels and bought nothing.)
+__device__ __forceinline__ void cmpxch_u(E& e1, E& e2, bool dir) {
 	const K a = (K) (CLO_SORT_KEY_GET_X(e1));
 	const K b = (K) (CLO_SORT_KEY_GET_X(e2));
 	const bool cmp = (bool) (CLO_SORT_COMPARE_AB(a, b));
-	if (cmp != DIR) { const E t = e1; e1 = e2; e2 = t; }
+	if (cmp != dir) { const E t = e1; e1 = e2; e2 = t; }
 }
-template <int V, int NSTEPS, bool DIR>
-__device__ __forceinline__ void reg_network_u(E (&v)[V]) {
+template <int V, int NSTEPS>
+__device__ __forceinline__ void reg_network_u(E (&v)[V], bool dir) {
 	#pragma unroll
 	for (int half = V / 2; half >= 1; half /= 2) {
 		if (half < (1 << NSTEPS)) {
 			#pragma unroll
 			for (int j = 0; j < V; ++j)
-				if ((j & half) == 0) cmpxch_u<DIR>(v[j], v[j + half]);
+				if ((j & half) == 0) cmpxch_u(v[j], v[j + half], dir);
 		}
 	}
 }
 // one group: the values at register bits [B0, B0 + Q) come out of LDS, NSTEPS steps run on them, they go back
-template <int P, bool DIR>
-__device__ __forceinline__ void merge_groups(E* s, unsigned tid) {
+template <int P>
+__device__ __forceinline__ void merge_groups(E* s, unsigned tid, bool dir) {
 	constexpr int Q = CLO_JIT_Q, V = 1 << Q;
 	constexpr int B0 = P > Q ? P - Q : 0, NSTEPS = P - B0;
 	const unsigned base = ((tid >> B0) << (B0 + Q)) | (tid & ((1u << B0) - 1u));
@@ -203,13 +201,15 @@ __device__ __forceinline__ void merge_groups(E* s, unsigned tid) {
 	E v[V];
 	#pragma unroll
 	for (int j = 0; j < V; ++j) v[j] = s[pb + PHYS((unsigned) j << B0)];
-	reg_network_u<V, NSTEPS, DIR>(v);
+	reg_network_u<V, NSTEPS>(v, dir);
 	#pragma unroll
 	for (int j = 0; j < V; ++j) s[pb + PHYS((unsigned) j << B0)] = v[j];
 	__syncthreads();   // (a thread rewrites exactly the slots it read: one barrier per group)
-	if constexpr (B0 > 0) merge_groups<B0, DIR>(s, tid);
+	if constexpr (B0 > 0) merge_groups<B0>(s, tid, dir);
 }
-extern "C" __global__ __launch_bounds__(CLO_JIT_TT, CLO_JIT_MERGE_WPE)
+// (The presort — all of stages 1 .. KL of a tile, 91 steps — keeps the run-time schedule of jit_tile: unrolled at compile time
+// it took 0.70 instead of 1.0 ms of a 2^26-key sort, and 2.5 s more of hiprtc per sorter: 3.1 s instead of 0.64.)
+extern "C" __global__ __launch_bounds__(CLO_JIT_TT)
 void jit_merge(E* __restrict__ data, unsigned stage) {
 	constexpr int Q = CLO_JIT_Q, V = 1 << Q, KL = CLO_JIT_TB + Q, TILE = CLO_JIT_TT * V;
 	__shared__ E s[TILE + TILE / 32];
@@ -218,9 +218,65 @@ void jit_merge(E* __restrict__ data, unsigned stage) {
 	#pragma unroll
 	for (int k = 0; k < V; ++k) { const unsigned i = (unsigned) k * CLO_JIT_TT + tid; s[PHYS(i)] = data[gbase + i]; }
 	__syncthreads();
-	if ((gbase >> stage) & 1ul) merge_groups<KL, true>(s, tid); else merge_groups<KL, false>(s, tid);
+	merge_groups<KL>(s, tid, ((gbase >> stage) & 1ul) != 0ul);   // (the direction: one bit of the tile's number)
 	#pragma unroll
 	for (int k = 0; k < V; ++k) { const unsigned i = (unsigned) k * CLO_JIT_TT + tid; data[gbase + i] = s[PHYS(i)]; }
+}
+
+// Two-level strided pass (round 5; the ahead-of-time clo_bitonic_strided2_kernel with the user's compare): steps p .. p-ns+1
+// (Q < ns <= 2Q) of a stage in ONE pass. A work-group owns 2^ns rows (index bits [p-ns, p)) of 2^(KL-ns) contiguous elements
+// as a tile of 2^KL elements in LDS order row * 2^(KL-ns) + column: the top Q row bits in registers (Q steps), one LDS
+// exchange, then tile bits [KL-2Q, KL-Q), whose top ns-Q bits are the remaining row bits (ns-Q steps). The direction is a
+// bit of the group's own part of the index: a scalar branch.
+template <int V>
+__device__ __forceinline__ void reg_network_um(E (&v)[V], int min_half, bool dir) {
+	#pragma unroll
+	for (int half = V / 2; half >= 1; half /= 2) {
+		if (half >= min_half) {   // (the same for the whole launch)
+			#pragma unroll
+			for (int j = 0; j < V; ++j)
+				if ((j & half) == 0) cmpxch_u(v[j], v[j + half], dir);
+		}
+	}
+}
+__device__ __forceinline__ void strided2_body(E* __restrict__ data, E* s, unsigned p, unsigned ns, unsigned long wbase, bool dir) {
+	constexpr int Q = CLO_JIT_Q, V = 1 << Q, KL = CLO_JIT_TB + Q, B1 = KL - Q, B2 = KL - 2 * Q;
+	static_assert(B2 >= 0, "two register groups inside the tile");
+	const unsigned tid = threadIdx.x;
+	const unsigned C = (unsigned) KL - ns, cmask = (1u << C) - 1u;
+	const unsigned t1 = ((tid >> B1) << (B1 + Q)) | (tid & ((1u << B1) - 1u));
+	const unsigned t2 = ((tid >> B2) << (B2 + Q)) | (tid & ((1u << B2) - 1u));
+	E v[V];
+	{
+		const E* src = data + wbase + ((unsigned long) (t1 >> C) << (p - ns)) + (t1 & cmask);   // register bits = the top Q row bits = index bits [p-Q, p)
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = src[(unsigned long) j << (p - Q)];
+	}
+	reg_network_um<V>(v, 1, dir);
+	{
+		const unsigned pf = PHYS(t1), pt = PHYS(t2);
+		#pragma unroll
+		for (int j = 0; j < V; ++j) s[pf + PHYS((unsigned) j << B1)] = v[j];
+		__syncthreads();
+		#pragma unroll
+		for (int j = 0; j < V; ++j) v[j] = s[pt + PHYS((unsigned) j << B2)];
+	}
+	reg_network_um<V>(v, V >> (ns - Q), dir);
+	#pragma unroll
+	for (int j = 0; j < V; ++j) {
+		const unsigned t = t2 | ((unsigned) j << B2);
+		data[wbase + ((unsigned long) (t >> C) << (p - ns)) + (t & cmask)] = v[j];
+	}
+}
+extern "C" __global__ __launch_bounds__(CLO_JIT_TT)
+void jit_strided2l(E* __restrict__ data, unsigned stage, unsigned p, unsigned ns) {
+	constexpr int Q = CLO_JIT_Q, V = 1 << Q, KL = CLO_JIT_TB + Q, TILE = CLO_JIT_TT * V;
+	__shared__ E s[TILE + TILE / 32];
+	const unsigned C = (unsigned) KL - ns;
+	const unsigned midbits = p - ns - C;          // index bits between the columns and the rows
+	const unsigned long w = blockIdx.x;
+	const unsigned long wbase = ((w >> midbits) << p) | ((w & ((1ul << midbits) - 1ul)) << C);
+	strided2_body(data, s, p, ns, wbase, ((wbase >> stage) & 1ul) != 0ul);
 }
 
 // gselect with the user's two macro bodies pasted in, as upstream pastes them
@@ -249,7 +305,7 @@ void jit_gselect(const E* __restrict__ in, E* __restrict__ out, unsigned long n)
 
 struct jit_sorter {
 	hipModule_t module = nullptr;
-	hipFunction_t step = nullptr, step_any = nullptr, tile = nullptr, merge = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipFunction_t step = nullptr, step_any = nullptr, tile = nullptr, merge = nullptr, strided2 = nullptr, gselect = nullptr, strided[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	int elem_size = 0;
 	int q = 0;
 	int tb = 0;   // thread bits of the tile kernels
@@ -273,7 +329,10 @@ void set_log(char** log, const std::string& text) {
 	if (*log) memcpy(*log, text.c_str(), text.size() + 1);
 }
 
-constexpr int JIT_TB = 9;   // thread bits of the tile kernels: 512 threads
+// Thread bits of the tile kernels: 256 threads on tiles of 256 * 2^Q elements. (512 threads on the ahead-of-time kernels' 2^14-
+// element tiles measured the same, 3.58 against 3.59 ms per 2^26-key sort, once the merge kernel no longer carried one
+// network per direction — with those it needed 164 VGPRs, one work-group per CU: 4.33 against 4.02 ms; profiles/r05_jit_variants.txt.)
+constexpr int JIT_TB = 8;
 
 int launch(hipFunction_t f, unsigned blocks, hipStream_t s, void** args, unsigned threads = 256) {
 	return (int) hipModuleLaunchKernel(f, blocks, 1, 1, threads, 1, 1, 0, s, args, nullptr);
@@ -300,12 +359,8 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	src += std::string("#define CLO_SORT_COMPARE_AB(a, b) ") + (compare ? compare : "((a) > (b))") + "\n";
 	src += std::string("#define CLO_SORT_KEY_GET_X(x) ") + (get_key ? get_key : "(x)") + "\n";
 	src += "#define CLO_JIT_Q " + std::to_string(q) + "\n";
-	// (experiment switches of round 5, read once per sorter: CLO_JIT_TB = 8 | 9, CLO_JIT_WPE = waves per SIMD the merge kernel is compiled for)
-	const char* env_tb = getenv("CLO_JIT_TB");
-	const char* env_wpe = getenv("CLO_JIT_WPE");
-	const int tb = (env_tb && (atoi(env_tb) == 8 || atoi(env_tb) == 9)) ? atoi(env_tb) : JIT_TB;
-	const int wpe = (env_wpe && atoi(env_wpe) >= 1 && atoi(env_wpe) <= 8) ? atoi(env_wpe) : 1;
-	src += "#define CLO_JIT_TB " + std::to_string(tb) + "\n#define CLO_JIT_TT " + std::to_string(1 << tb) + "\n#define CLO_JIT_MERGE_WPE " + std::to_string(wpe) + "\n";
+	const int tb = JIT_TB;
+	src += "#define CLO_JIT_TB " + std::to_string(tb) + "\n#define CLO_JIT_TT " + std::to_string(1 << tb) + "\n";
 	src += k_src;
 
 	hiprtcProgram prog = nullptr;
@@ -341,6 +396,7 @@ int clo_hip_bitonic_jit_create(int elem_type, int key_type, const char* compare,
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->step_any, js->module, "jit_step_any");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->tile, js->module, "jit_tile");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->merge, js->module, "jit_merge");
+	if (e == hipSuccess) e = hipModuleGetFunction(&js->strided2, js->module, "jit_strided2l");
 	if (e == hipSuccess) e = hipModuleGetFunction(&js->gselect, js->module, "jit_gselect");
 	for (int ns = 1; ns <= q && e == hipSuccess; ++ns) {
 		const std::string name = "jit_strided" + std::to_string(ns);
@@ -375,7 +431,7 @@ int clo_hip_bitonic_jit_gselect(void* handle, const void* src, void* dst, size_t
 }
 
 // Static LDS per work-group of the kernels clo_hip_bitonic_jit_sort launches for `numel` elements (introspection): only the
-// tiled schedule of a power of two from 2^Q elements on runs the tile kernel, whose array is sized for 512 x 2^Q elements.
+// tiled schedule of a power of two from 2^Q elements on runs the tile kernel, whose array is sized for 2^JIT_TB x 2^Q elements.
 size_t clo_hip_bitonic_jit_lds_bytes(void* handle, size_t numel, int tiled) {
 	const jit_sorter* js = (const jit_sorter*) handle;
 	if (!js || numel <= 1 || !tiled || (numel & (numel - 1)) != 0 || numel < ((size_t) 1 << js->q)) return 0;
@@ -431,8 +487,21 @@ int clo_hip_bitonic_jit_sort(void* handle, void* data, size_t numel, int tiled, 
 		mode = 0;
 		for (stage = kl + 1; stage <= T && !st; ++stage) {
 			unsigned p = stage;
+			// The steps above the tile: plain strided passes of up to Q steps first, then — from Q + 1 steps on — ONE two-level
+			// pass of up to NS2 steps right above the tile (rows of at least 128 bytes): 13 steps = 5 + 8, where round 4 made
+			// 5 + 5 + 3 (2^26 keys: 18 strided launches instead of 24).
+			const unsigned NS2 = (unsigned) js->tb < 2u * Q ? (unsigned) js->tb : 2u * Q;   // rows of 2^(KL - ns) elements: 32 four-byte / 16 eight-byte ones (128 bytes) at ns = NS2
 			while (p > kl && !st) {
-				unsigned ns = p - kl;
+				const unsigned h = p - kl;
+				if (h > Q && h <= NS2 && kl == KL_MAX) {
+					unsigned ns = h;
+					void* args[] = { &data, &stage, &p, &ns };
+					st = launch(js->strided2, tiles, s, args, 1u << js->tb);
+					++count;
+					p -= ns;
+					continue;
+				}
+				unsigned ns = h > NS2 ? h - NS2 : h;
 				if (ns > Q) ns = Q;
 				const unsigned long threads = n >> ns;
 				void* args[] = { &data, &n, &stage, &p };

@@ -104,6 +104,11 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 	const unsigned tbase = tid * ITEMS;
 	const unsigned mask2 = (mask_hi << LB) | mask_lo;
 
+	// A wave that is about to request its tile goes first on its SIMD (until the requests are out): the other work-group of
+	// the CU is in its splits then, and every cycle its VALU work delays these loads is a cycle of HBM time lost. 8-byte
+	// elements: uint64 2^28 8.04-8.14 -> 7.90-7.94 ms, pairs 4.15-4.21 -> 4.10-4.12; 4-byte ones: no difference
+	// (profiles/r05_ab_wave_priority.txt). The same priority for the scatter's stores too: no further gain.
+	__builtin_amdgcn_s_setprio(3);
 	// the tile's counters (upstream's counters / counters_sum), requested before the keys
 	unsigned h2 = 0, goff = 0;
 	if (tid < (unsigned) R2) {
@@ -119,6 +124,7 @@ void clo_radix4_pair_kernel(const E* __restrict__ in, E* __restrict__ out, size_
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) key[i] = (tbase + i < count) ? in[base + tbase + i] : (E) 0;
 	}
+	__builtin_amdgcn_s_setprio(0);
 	if (kx_in.kind) {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i) key[i] = clo_keyx_fwd<E>(key[i], kx_in);
