@@ -41,10 +41,7 @@ __device__ __forceinline__ unsigned dpp_add(unsigned x) {
 	return x + (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROW_MASK, 0xF, true);
 }
 
-#ifndef CLO_PC_BATCH
-#define CLO_PC_BATCH 4
-#endif
-constexpr int PC_BATCH = CLO_PC_BATCH;        // lookups of ends requested together in a full tile
+constexpr int PC_BATCH = 4;        // lookups of ends requested together in a full tile
 constexpr int PC_END_STRIDE = 8;   // dwords per thread in the table of ends: 16 digits x 16 bits (digit-major, see pc_local_split)
 
 template <int BITS> struct pc_words { static constexpr int H = (1 << BITS) >= 2 ? (1 << BITS) / 2 : 1; };
@@ -256,6 +253,7 @@ __device__ __forceinline__ void pc_local_split_impl(const E (&key)[ITEMS], unsig
 		// (wave-uniform values) gives the digit starts. One barrier later every
 		// thread has its bases.
 		static_assert(WAVES <= 16, "one row of 16 lanes spans the waves");
+
 		constexpr int ROUNDS = (H + 3) / 4;
 		const unsigned wv = lane & 15u, q = lane >> 4;
 		unsigned excl[ROUNDS], tot[ROUNDS];
@@ -385,10 +383,7 @@ template <typename E, bool BIG> struct pair_shape {
 // (8-byte elements gain from 32 MiB on — their digit stream is an eighth of the
 // array; 2^22 uint64 0.254 -> 0.234 ms, pairs 0.127 -> 0.119, profiles/r03_big_tile_threshold.txt —
 // 4-byte ones from 256 MiB: measured, docs/lab_notebook.md)
-#ifndef CLO_BIG_TILE_MIB4
-#define CLO_BIG_TILE_MIB4 256   /* (experiment builds: EXTRA=-DCLO_BIG_TILE_MIB4=128) */
-#endif
-inline size_t clo_big_tile_bytes(int elem_size) { return (size_t) (elem_size == 8 ? 32 : CLO_BIG_TILE_MIB4) << 20; }
+inline size_t clo_big_tile_bytes(int elem_size) { return (size_t) (elem_size == 8 ? 32 : 256) << 20; }
 inline bool clo_radix_big_tiles(size_t n, int elem_size) { return elem_size >= 4 && n * (size_t) elem_size >= clo_big_tile_bytes(elem_size); }
 // The digit stream (one byte per element between two passes) goes with the
 // big tiles: on 8 192-element tiles (arrays that sit in the last-level cache) its extra

@@ -21,18 +21,13 @@
 
 namespace {
 
-#ifndef CLO_RW_CHUNK
-#define CLO_RW_CHUNK 128
-#endif
-constexpr int RW_CHUNK = CLO_RW_CHUNK;   // tiles per chunk of the counter scan
+constexpr int RW_CHUNK = 128;   // tiles per chunk of the counter scan (arrays of up to RW_SMALL_TILES tiles: RW_CHUNK_SMALL, below)
 
 // the pair kernel's tile (clo_hip_radix_rank.h), one thread per 16 elements (8 of 8 bytes)
-#ifndef CLO_HIST_THREADS_DIV
-#define CLO_HIST_THREADS_DIV 1   /* (experiment builds: 2 = half the threads on the same tile, twice the loads in flight per thread) */
-#endif
+// (Half the threads on the same tile — twice the loads in flight per thread — measured the same: profiles/r05_ab_mid_sizes.txt, lib_h.)
 template <typename E, bool BIG> struct rw_shape {
 	static constexpr int TILE = pair_shape<E, BIG>::TILE;
-	static constexpr int THREADS = pair_shape<E, BIG>::THREADS / ((BIG && sizeof(E) == 4) ? CLO_HIST_THREADS_DIV : 1);
+	static constexpr int THREADS = pair_shape<E, BIG>::THREADS;
 	static constexpr int ITEMS = TILE / THREADS;
 };
 
