@@ -217,12 +217,35 @@ def load_traffic(workload):
                   "source_head": d.get("source_head")}
 
 
+def host_cores():
+    """(threads to use, cores of the affinity mask, cgroup CPU quota or None). A GPU box hands a job a share of its cores
+    through the cgroup's CPU quota while the affinity mask still shows every core of the machine (256 on the MI355X boxes,
+    16 of them ours): threads beyond the quota only get throttled — 256 OpenMP threads on a 16-core quota ran the radix
+    port at 36 Mkeys/s where 16 threads reach 165. All the cores we may use = min(affinity, quota)."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    cores = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return cores, affinity, quota
+
+
 def cpu_baseline(workload, host_input, radix, sample_log2n):
     """Times the CPU oracle (port of the reference decomposition) on a bounded
     sample of the same input, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = len(os.sched_getaffinity(0))   # every core this process may run on (SURVEY §8d: "all host cores, core count printed")
+    cores, affinity, quota = host_cores()   # every core this process may USE (SURVEY §8d: "all host cores, core count printed")
     m = min(host_input.size, 1 << sample_log2n)
     sample = host_input[:m]
     t0 = time.perf_counter()
@@ -245,8 +268,10 @@ def cpu_baseline(workload, host_input, radix, sample_log2n):
     dt = time.perf_counter() - t0
     unit = "MValues/s" if workload == "scan" else "Mkeys/s"
     return {"value": round(m / dt / 1e6, 3), "unit": unit, "cores": cores, "kind": "port",
+            "affinity_cores": affinity, "cgroup_cpu_quota": quota,
             "sample": "first 2^%d elements of the same input, oracle/clo_oracle.c %s, %.1f s%s"
-                      % (int(np.log2(m)), ("OpenMP on all %d cores of the affinity mask" % cores) if cores > 1 else "serial", dt, "" if ok else " (CHECK FAILED)")}
+                      % (int(np.log2(m)), ("OpenMP on all %d usable cores (affinity mask %d, cgroup quota %s)" % (cores, affinity, "none" if quota is None else "%.1f" % quota))
+                         if cores > 1 else "serial", dt, "" if ok else " (CHECK FAILED)")}
 
 
 # ----------------------------------------------------------------------------
