@@ -177,6 +177,15 @@ __device__ __forceinline__ unsigned clo_mbcnt(clo_u64 mask) {
 		__builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
 }
 
+// Work-group barrier that orders LDS traffic only: global loads and stores requested before it stay in flight across it
+// (a __syncthreads() makes every wave wait for ALL its outstanding memory operations first). For barriers that hand over
+// nothing but LDS contents: the radix splits, the scan kernel's tile loop.
+__device__ __forceinline__ void clo_lds_barrier() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Wave64 prefix sums of INTEGER values (32 or 64 bits) on the DPP network — four shifts inside the rows of 16 lanes,
 // two row broadcasts — with no LDS traffic and nothing to wait for. (Rounds 1-4 went through __shfl_up, i.e. one
 // ds_bpermute_b32 per step and `s_waitcnt lgkmcnt(0)` behind each: six dependent LDS round trips per scan, 48 of them per

@@ -13,14 +13,7 @@
 
 namespace {
 
-// Work-group barrier that orders LDS traffic only: global loads requested before
-// it stay in flight across it (a __syncthreads() makes every wave wait for ALL its
-// outstanding memory operations first; the splits below exchange nothing but LDS).
-__device__ __forceinline__ void clo_lds_barrier() {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-	__builtin_amdgcn_s_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+// (clo_lds_barrier — the work-group barrier that orders LDS traffic only — lives in clo_hip_internal.h)
 
 // ---------------------------------------------------------------------------
 // Ranking with thread-private packed counters.

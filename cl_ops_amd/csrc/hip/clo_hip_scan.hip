@@ -210,7 +210,11 @@ void clo_scan_kernel(const TIn* __restrict__ in, TOut* __restrict__ out, size_t 
 
 	// value carried into this call (a chunk of a longer array): added to every output
 	const TSum carry = carry_in ? (TSum) *carry_in : (TSum) 0;
-	// a work-group draws tiles until none is left (it holds one ticket at a time)
+	// A work-group draws tiles until none is left (it holds one ticket at a time). Measured and NOT done (round 5,
+	// profiles/r05_ab_scan_barriers.txt): drawing the next tile's ticket early — before the look-back: tickets run ahead of the
+	// tiles' starts and the groups behind wait for tiles nobody has begun, 2^28 0.36 -> 0.54 ms; right behind the look-back,
+	// with barriers that order LDS only so that no wave waits for its stores' acknowledgements: still 0.366 -> 0.381 (2^26
+	// 0.1027 -> 0.1056). The full barriers stay.
 	for (;;) {
 	if (tid == 0) s_tile = atomicAdd(&hdr[CLO_WS_TICKET_WORD], 1u);
 	__syncthreads();
