@@ -244,9 +244,17 @@ def _line(path):
         return None
 
 
+def _latest(files):
+    """The files of the LATEST collection only (gpurun_out/<tag>/ keeps what earlier calls of the same tag merged back)."""
+    if not files:
+        return []
+    newest = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if newest - os.path.getmtime(f) < 300]
+
+
 def _rocprof_families(workload):
     best, best_calls = None, -1
-    for f in glob.glob(os.path.join(src, "trace_" + workload, "*", "*kernel_stats.csv")):
+    for f in _latest(glob.glob(os.path.join(src, "trace_" + workload, "*", "*kernel_stats.csv"))):
         rows = list(csv.DictReader(open(f)))
         calls = sum(int(r["Calls"]) for r in rows)
         if calls > best_calls:
@@ -269,7 +277,7 @@ def _rocprof_trace(workload, steps):
     over the launches of the TIMED steps (kernels back to back) and over those of the INSTRUMENTED steps (the last `steps`
     steps: the very launches bench.py's event pairs bracket), and the timed steps' length first start -> last end."""
     best = None
-    for f in glob.glob(os.path.join(src, "trace_" + workload, "*", "*kernel_trace.csv")):
+    for f in _latest(glob.glob(os.path.join(src, "trace_" + workload, "*", "*kernel_trace.csv"))):
         rows = list(csv.DictReader(open(f)))
         if best is None or len(rows) > len(best):
             best = rows
