@@ -67,15 +67,22 @@ __device__ __forceinline__ bool rw_seg_tile(const clo_seg_tile* __restrict__ tde
 // ---------------------------------------------------------------------------
 // SEG: a segmented launch — `tdesc` says where the tile lies (n is unused); a segment starts at any element, so the
 // vector loads are only element-aligned.
-template <typename E, int BITS, bool BIG, bool SEG = false>
+// TPW tiles per work-group (not for segmented launches), one per THREADS / TPW consecutive threads with counters of their own:
+// twice the key bytes in flight per thread, half the work-groups. Launched with TPW = 1: with two tiles the histogram over the
+// KEYS takes the same time (2^28 uint32: 0.222 ms either way — it reads at the 4.9 TB/s a read-only stream gets on this part;
+// profiles/r05_ab_hist_keys_two_tiles.txt), unlike the one over the digit bytes below.
+template <typename E, int BITS, bool BIG, bool SEG = false, int TPW = 1>
 __global__ __launch_bounds__((rw_shape<E, BIG>::THREADS))
 void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shift, unsigned mask,
 	unsigned* __restrict__ thist, unsigned* __restrict__ tinfo, int aligned, clo_keyx kx,
 	unsigned* __restrict__ clear, unsigned clear_words, const clo_seg_tile* __restrict__ tdesc = nullptr, const E* __restrict__ in2 = nullptr) {
+	static_assert(!SEG || TPW == 1, "segmented launches: one tile per work-group");
 	constexpr int R = 1 << BITS;
-	constexpr int ITEMS = rw_shape<E, BIG>::ITEMS;
 	constexpr int TILE = rw_shape<E, BIG>::TILE;
 	constexpr int RW_THREADS = rw_shape<E, BIG>::THREADS;
+	constexpr int PART = RW_THREADS / TPW;   // threads of one tile
+	constexpr int ITEMS = TILE / PART;
+	static_assert(PART % 64 == 0 && PART * TPW == RW_THREADS, "whole waves per tile");
 	constexpr int VB = ITEMS * (int) sizeof(E) >= 16 ? 16 : ITEMS * (int) sizeof(E);   // bytes per vector load
 	constexpr int VECS = ITEMS * (int) sizeof(E) / VB;
 	constexpr int PER = VB / (int) sizeof(E);
@@ -84,13 +91,15 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	// LDS add holds its bank for many cycles; one copy per wave, lanes colliding on
 	// banks, made the adds a co-bottleneck of this otherwise streaming kernel).
 	constexpr int COPIES = 32;
-	__shared__ __attribute__((aligned(16))) unsigned s_cnt[R * COPIES];
+	__shared__ __attribute__((aligned(16))) unsigned s_cnt[TPW * R * COPIES];
 	const unsigned tid = threadIdx.x, lane = tid & 63u;
-	size_t base = (size_t) blockIdx.x * TILE;
-	unsigned count = (n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE;
+	const unsigned part = tid / PART, ptid = tid % PART;
+	const unsigned tile = blockIdx.x * TPW + part;   // this thread's tile (the same for its whole wave)
+	size_t base = (size_t) tile * TILE;
+	unsigned count = base >= n ? 0u : ((n - base) < (size_t) TILE ? (unsigned) (n - base) : (unsigned) TILE);
 	if constexpr (SEG) { if (rw_seg_tile(tdesc, base, count, (unsigned) TILE)) in = in2; }   // (the same for the whole work-group)
-	const unsigned tbase = tid * ITEMS;
-	const unsigned cp = lane & (COPIES - 1);
+	const unsigned tbase = ptid * ITEMS;
+	unsigned* const cnt = s_cnt + part * (R * COPIES) + (lane & (COPIES - 1));
 	typedef E vecA __attribute__((ext_vector_type(PER)));   // (`aligned`: the source is 16-byte aligned)
 	typedef E vecU __attribute__((ext_vector_type(PER), aligned(sizeof(E))));
 	typedef typename std::conditional<SEG, vecU, vecA>::type vecE;
@@ -107,7 +116,7 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 	{   // (16-byte stores: a quarter of the LDS instructions of a dword loop)
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
 		const vec4u z = { 0u, 0u, 0u, 0u };
-		for (unsigned i = tid; i < (unsigned) (R * COPIES / 4); i += RW_THREADS) reinterpret_cast<vec4u*>(s_cnt)[i] = z;
+		for (unsigned i = tid; i < (unsigned) (TPW * R * COPIES / 4); i += RW_THREADS) reinterpret_cast<vec4u*>(s_cnt)[i] = z;
 	}
 	clo_lds_barrier();
 	if (whole) {
@@ -115,28 +124,35 @@ void clo_radixw_tilehist_kernel(const E* __restrict__ in, size_t n, unsigned shi
 		for (int k = 0; k < VECS; ++k) {
 			#pragma unroll
 			for (int q = 0; q < PER; ++q)
-				atomicAdd(&s_cnt[(((unsigned) (clo_keyx_fwd<E>(v[k][q], kx) >> shift) & mask) << 5) + cp], 1u);
+				atomicAdd(&cnt[((unsigned) (clo_keyx_fwd<E>(v[k][q], kx) >> shift) & mask) << 5], 1u);
 		}
 	} else {
 		#pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
 			if (tbase + i < count)
-				atomicAdd(&s_cnt[(((unsigned) (clo_keyx_fwd<E>(in[base + tbase + i], kx) >> shift) & mask) << 5) + cp], 1u);
+				atomicAdd(&cnt[((unsigned) (clo_keyx_fwd<E>(in[base + tbase + i], kx) >> shift) & mask) << 5], 1u);
 	}
 	__syncthreads();
-	for (unsigned d = tid; d < (unsigned) R; d += RW_THREADS) {
+	for (unsigned i = tid; i < (unsigned) (TPW * R); i += RW_THREADS) {
 		typedef unsigned vec4u __attribute__((ext_vector_type(4)));
-		const vec4u* row = reinterpret_cast<const vec4u*>(&s_cnt[d * COPIES]);
+		const unsigned row_part = i / R, d = i % R, rt = blockIdx.x * TPW + row_part;   // (the row's tile, which may be another part's)
+		unsigned rcount = count;
+		if constexpr (TPW > 1) {
+			const size_t rb = (size_t) rt * TILE;
+			if (rb >= n) break;
+			rcount = (n - rb) < (size_t) TILE ? (unsigned) (n - rb) : (unsigned) TILE;
+		}
+		const vec4u* row = reinterpret_cast<const vec4u*>(&s_cnt[row_part * (R * COPIES) + d * COPIES]);
 		unsigned h = 0;
 		#pragma unroll
 		for (int k = 0; k < COPIES / 4; ++k) {   // (rotated: the lanes' rows are 128 bytes apart)
 			const vec4u x = row[(k + d) & (COPIES / 4 - 1)];
 			h += x[0] + x[1] + x[2] + x[3];
 		}
-		thist[(size_t) blockIdx.x * R + d] = h;
-		rw_tile_info(h, count, tinfo, blockIdx.x);
-		rw_clear(clear, clear_words, blockIdx.x * R + d);
-		if constexpr (SEG) rw_clear(clear, clear_words, (gridDim.x + blockIdx.x) * R + d);   // (up to one chunk per tile, and the ticket's row)
+		thist[(size_t) rt * R + d] = h;
+		rw_tile_info(h, rcount, tinfo, rt);
+		rw_clear(clear, clear_words, rt * R + d);
+		if constexpr (SEG) rw_clear(clear, clear_words, (gridDim.x + rt) * R + d);   // (up to one chunk per tile, and the ticket's row)
 	}
 }
 
