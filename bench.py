@@ -525,9 +525,9 @@ def _run_sharded_leg(be, etype, n_local, steps, warmup, seed, rank, world, local
     return {"value": round(n_local * world * steps / t_max / 1e6, 1), "unit": "Mkeys/s",
             "exchange_stats": {
                 "bytes_out_per_gpu": x_bytes_max, "slices": x_slices, "device_ms": round(x_s_max * 1e3, 4),
-                "key_exchange_GBps": round(x_rate, 4),
+                "key_exchange_GBps": float("%.6g" % x_rate),
                 "xgmi_peak_GBps": round((world - 1) * XGMI_LINK_GBPS, 1),
-                "xgmi_frac": round(x_rate / ((world - 1) * XGMI_LINK_GBPS), 7) if world > 1 else None,
+                "xgmi_frac": float("%.6g" % (x_rate / ((world - 1) * XGMI_LINK_GBPS))) if world > 1 else None,
                 "note": "bytes a rank sends to the other ranks per step (its own bucket stays on the GPU) / device time from the "
                         "first all-to-all(v) to the end of the last; peak = (N - 1) links x %.0f GB/s" % XGMI_LINK_GBPS},
             "local_sort_roofline": {
