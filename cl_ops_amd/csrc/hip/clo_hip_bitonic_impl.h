@@ -499,6 +499,101 @@ void clo_bitonic_tile_merge_kernel(E* __restrict__ data, unsigned stage, key_des
 	}
 }
 
+// ---- steps KL+1 .. 1 of one stage > KL on PAIRS of full tiles: a merge pass that takes the lowest strided step along ----
+// A work-group owns two neighbouring tiles (2^(KL+1) contiguous elements): a thread loads its V values of the first
+// tile and the V at the same places of the second (step KL+1 pairs exactly those: V compare-exchanges in registers), then
+// runs the merge pass above on the first tile and, through the same LDS array, on the second, whose values wait in
+// registers meanwhile. Where it pays: the stages whose strided part thereby loses a whole pass (stage KL+1: no strided pass
+// at all; the stage whose strided steps otherwise need one pass more) — twice the registers, half the waves per CU.
+template <typename E, int Q, int TB, int MODE>
+// (One group per CU: 130-138 VGPRs. Capped at 128 for two groups the compiler spills 8-16 registers, and a sort with
+// scratch-using launches in it measured SLOWER than without the two-tile merge: 2.52 against 2.48 ms, 2^26 uint32.)
+__global__ __launch_bounds__(1 << TB)
+void clo_bitonic_tile_merge2_kernel(E* __restrict__ data, unsigned stage, key_desc kd) {
+	constexpr int V = 1 << Q;
+	constexpr int KL = TB + Q;
+	constexpr int TILE = V << TB;
+	__shared__ E s[TILE + TILE / 32];
+	typedef E vec16 __attribute__((ext_vector_type(16 / sizeof(E)), aligned(sizeof(E))));
+	constexpr int PER = 16 / (int) sizeof(E);
+	static_assert(V % PER == 0, "a thread's consecutive run is whole 16-byte vectors");
+
+	const unsigned tid = threadIdx.x;
+	auto tbase = [&](int b0) __attribute__((always_inline)) { return ((tid >> b0) << (b0 + Q)) | (tid & ((1u << b0) - 1u)); };
+	auto phys = [](unsigned i) __attribute__((always_inline)) { return i + (i >> 5); };
+	const size_t gbase = (size_t) blockIdx.x << (KL + 1);
+	const unsigned dir = (unsigned) ((gbase >> stage) & 1);   // stage > KL: a bit of the pair's number
+	E a[V], b[V];
+	{
+		// first group of the merge: register bits [KL-Q, KL), lanes read adjacent elements — of both tiles
+		const E* src = data + gbase + tbase(KL - Q);
+		#pragma unroll
+		for (int j = 0; j < V; ++j) a[j] = bt_in<E, MODE>(src[(unsigned) j << (KL - Q)]);
+		#pragma unroll
+		for (int j = 0; j < V; ++j) b[j] = bt_in<E, MODE>(src[(size_t) TILE + ((unsigned) j << (KL - Q))]);
+	}
+	// step KL+1: element i of the first tile against element i of the second (the direction is the pair's: a scalar
+	// branch around bare min / max — selects would keep both results of all V pairs alive)
+	if (MODE == 0) {
+		#pragma unroll
+		for (int j = 0; j < V; ++j) cmpxch<E, 0>(a[j], b[j], dir, kd);
+	} else {
+		typedef typename std::make_signed<E>::type S;
+		if ((dir ^ kd.descending) == 0) {
+			#pragma unroll
+			for (int j = 0; j < V; ++j) {
+				const bool lt = MODE != 2 ? (a[j] < b[j]) : ((S) a[j] < (S) b[j]);
+				const E lo = lt ? a[j] : b[j], hi = lt ? b[j] : a[j];
+				a[j] = lo; b[j] = hi;
+			}
+		} else {
+			#pragma unroll
+			for (int j = 0; j < V; ++j) {
+				const bool lt = MODE != 2 ? (a[j] < b[j]) : ((S) a[j] < (S) b[j]);
+				const E lo = lt ? a[j] : b[j], hi = lt ? b[j] : a[j];
+				a[j] = hi; b[j] = lo;
+			}
+		}
+	}
+	auto merge_one = [&](E (&v)[V], size_t tile_base, bool again) __attribute__((always_inline)) {
+		auto exchange = [&](int from, int to) __attribute__((always_inline)) {
+			const unsigned pf = phys(tbase(from)), pt = phys(tbase(to));
+			#pragma unroll
+			for (int j = 0; j < V; ++j) s[pf + phys((unsigned) j << from)] = v[j];
+			__syncthreads();
+			#pragma unroll
+			for (int j = 0; j < V; ++j) v[j] = s[pt + phys((unsigned) j << to)];
+		};
+		static_for<0, (KL + Q - 1) / Q>([&](auto gc) __attribute__((always_inline)) {
+			constexpr int g = decltype(gc)::value;
+			constexpr int p = KL - g * Q;
+			constexpr int b0 = p > Q ? p - Q : 0;
+			if (g > 0) exchange(p, b0);
+			reg_network_uniform<E, V, MODE>(v, p - b0, dir, kd);
+		});
+		{
+			const unsigned pf = phys(tbase(0));
+			#pragma unroll
+			for (int j = 0; j < V; ++j) s[pf + (unsigned) j] = v[j];
+			__syncthreads();
+			vec16* dst = reinterpret_cast<vec16*>(data + tile_base) + tid;
+			#pragma unroll
+			for (int k = 0; k < V / PER; ++k) {
+				const unsigned pe = phys(((unsigned) k << TB) * PER + tid * PER);   // PER consecutive slots: no multiple of 32 inside
+				vec16 t;
+				#pragma unroll
+				for (int q = 0; q < PER; ++q) t[q] = bt_out<E, MODE>(s[pe + q]);
+				dst[(unsigned) k << TB] = t;
+			}
+		}
+		if (again) __syncthreads();   // (the array is read out: the second tile may go in)
+	};
+	__builtin_amdgcn_sched_barrier(0);
+	merge_one(a, gbase, true);
+	__builtin_amdgcn_sched_barrier(0);
+	merge_one(b, gbase + (size_t) TILE, false);
+}
+
 // ---- two-level strided pass: steps p .. p-ns+1 (Q < ns <= 2Q) of a stage in ONE pass ----
 // A work-group owns 2^ns rows (the index bits [p-ns, p)) of 2^(KL-ns) contiguous
 // elements each, as a tile of 2^KL elements in LDS order t = row * 2^(KL-ns) +
@@ -680,6 +775,9 @@ void launch_strided(E* data, size_t n, unsigned stage, unsigned p, const key_des
 		data, n, stage, p, kd);
 }
 
+#ifndef CLO_MERGE2_EXTRA
+#define CLO_MERGE2_EXTRA 20u
+#endif
 template <typename E, int MODE, int TBF = 9>
 int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_size, int key_kind, int descending,
 	int* launches, hipStream_t s) {
@@ -712,28 +810,38 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 			hipLaunchKernelGGL((clo_bitonic_tile_kernel<E, Q, MODE>), dim3(tiles), dim3(256), 0, s, data, kl, kl, kl, 1, kd);
 	}
 	++count;
+	// Cost of the strided passes for h steps above the tile (us per 2^26 uint32, see below), and where the two-tile merge
+	// (which takes the lowest of them along) saves a whole pass.
+	const int merge2_mode = clo_hip_env()->bitonic_merge2;   // 0: never, 2: at every stage (tests, A/B runs); 1: where it saves a pass
+	// register bits of a strided pass: 64 values per thread for identity keys,
+	// one wave per SIMD — these passes only stream (76 us per 2^26 uint32). The
+	// general compare needs more temporaries: 32 (16 of 8 bytes). 128 values
+	// were measured too: 100-117 us per pass (412 VGPRs and up, spills), which
+	// costs more over a sort than the one pass it saves.
+	constexpr int QS = MODE == 0 ? Q + 1 : 6;
+	// The passes' measured times (2^26 uint32, us per pass: plain 72 + k for k <= 5 steps, 81 for 6; two-level 77 / 78 / 82
+	// for 7 / 8 / 9 steps and 124 for 10, whose rows are 64 bytes, half a cache line: profiles/r04_abitonic_strided_by_position.txt)
+	auto plain_cost = [&](unsigned k) { unsigned c = 0; while (k > 0) { const unsigned t = k > (unsigned) QS ? (k % QS ? k % QS : QS) : k; c += t >= 6 ? 81u : 72u + t; k -= t; } return c; };
+	// (a two-level pass of b2 steps reads rows of 2^(KLF - b2) elements: 77 us and 2 more per halving down to one
+	// cache line, 124 for half a line)
+	auto s2_cost = [&](unsigned b2) { const size_t row = ((size_t) 1 << (KLF - b2)) * sizeof(E); return row >= 128 ? 75u + 2u * (b2 - (unsigned) Q) : (row >= 64 ? 124u : 250u); };
+	// cheapest cut of h strided steps: plain passes first (the top steps), then at most ONE two-level pass of Q + 2 .. 2Q steps
+	auto strided_cost = [&](unsigned h) { unsigned best = plain_cost(h); for (unsigned b2 = Q + 2; b2 <= 2u * Q && b2 <= h; ++b2) { const unsigned c = plain_cost(h - b2) + s2_cost(b2); if (c < best) best = c; } return best; };
 	for (unsigned stage = kl + 1; stage <= T; ++stage) {
 		unsigned p = stage;
-		while (p > kl) {
-			// register bits of a strided pass: 64 values per thread for identity keys,
-			// one wave per SIMD — these passes only stream (76 us per 2^26 uint32). The
-			// general compare needs more temporaries: 32 (16 of 8 bytes). 128 values
-			// were measured too: 100-117 us per pass (412 VGPRs and up, spills), which
-			// costs more over a sort than the one pass it saves.
-			constexpr int QS = MODE == 0 ? Q + 1 : 6;
-			unsigned ns = p - kl;
-			// How the h = p - kl steps above the tile are cut into passes: plain passes of up to QS steps first (the top
-			// steps), then ONE two-level pass of Q + 2 .. 2Q steps on the steps right above the tile — whichever cut costs
-			// least by the passes' measured times (2^26 uint32, us per pass: plain 72 + k for k <= 5 steps, 81 for 6;
-			// two-level 77 / 78 / 82 for 7 / 8 / 9 steps and 124 for 10, whose rows are 64 bytes, half a cache line:
-			// profiles/r04_abitonic_strided_by_position.txt). Round 3 took the two-level pass first and as long as it
+		// The two-tile merge where it saves more than it costs (CLO_MERGE2_EXTRA us over a merge pass: 0.099 against 0.082 ms):
+		// 2^26 uint32 — stages 15, 24, 25 — 2.48 -> 2.39 ms, 2^24 0.556 -> 0.535; at every stage: 2.55 (profiles/r05_abitonic_merge2.txt).
+		// From 64 tiles on (fewer: its groups, one per CU, are too few — 2^16 elements 0.040 -> 0.042 ms).
+		const bool use_m2 = MODE != 0 && merge2_mode != 0 && kl == KLF && tiles >= (merge2_mode == 2 ? 2u : 64u) && (merge2_mode == 2 || strided_cost(stage - kl) > strided_cost(stage - kl - 1u) + CLO_MERGE2_EXTRA);
+		const unsigned stop = use_m2 ? kl + 1u : kl;   // the strided passes end above this step
+		while (p > stop) {
+			unsigned ns = p - stop;
+			// How the h = p - stop steps above the tile (above the two-tile merge's step) are cut into passes: plain passes of up
+			// to QS steps first (the top steps), then ONE two-level pass of Q + 2 .. 2Q steps on the steps right above the tile —
+			// whichever cut costs least by the passes' measured times. Round 3 took the two-level pass first and as long as it
 			// could be: 11 steps = 10 + 1, 12 = 6 + 6; now 11 = 4 + 7, 12 = 5 + 7.
 			{
 				const unsigned h = ns;
-				auto plain_cost = [&](unsigned k) { unsigned c = 0; while (k > 0) { const unsigned t = k > (unsigned) QS ? (k % QS ? k % QS : QS) : k; c += t >= 6 ? 81u : 72u + t; k -= t; } return c; };
-				// (a two-level pass of b2 steps reads rows of 2^(KLF - b2) elements: 77 us and 2 more per halving down to one
-				// cache line, 124 for half a line)
-				auto s2_cost = [&](unsigned b2) { const size_t row = ((size_t) 1 << (KLF - b2)) * sizeof(E); return row >= 128 ? 75u + 2u * (b2 - (unsigned) Q) : (row >= 64 ? 124u : 250u); };
 				unsigned best = plain_cost(h), best_b = 0;
 				for (unsigned b2 = Q + 2; b2 <= 2u * Q && b2 <= h; ++b2) {
 					const unsigned c = plain_cost(h - b2) + s2_cost(b2);
@@ -767,7 +875,10 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 		{
 			clo_timing_scope timing("bitonic_tile", s);
 			// stage > kl only happens with full tiles (kl == KLF)
-			hipLaunchKernelGGL((clo_bitonic_tile_merge_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, kd);
+			if constexpr (MODE != 0) {   // (general keys: 256 registers and spills — their merge passes stay one tile wide)
+				if (use_m2) hipLaunchKernelGGL((clo_bitonic_tile_merge2_kernel<E, Q, TBF, MODE>), dim3(tiles / 2u), dim3(1 << TBF), 0, s, data, stage, kd);
+			}
+			if (!use_m2) hipLaunchKernelGGL((clo_bitonic_tile_merge_kernel<E, Q, TBF, MODE>), dim3(tiles), dim3(1 << TBF), 0, s, data, stage, kd);
 		}
 		++count;
 	}

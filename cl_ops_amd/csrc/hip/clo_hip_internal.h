@@ -23,7 +23,8 @@
 //   CLO_RADIX_SWEEP      0: never take the single-sweep radix passes, 1: whenever possible; unset: the library's choice
 //   CLO_R1_POOLS         8: the single-sweep passes draw tiles from one ticket pool per XCD (256-CU devices only)
 //   CLO_RADIX_NO_DIGITS  set: no digit stream between the chain-free passes (tests compare both)
-struct clo_hip_env_t { unsigned max_spins; int radix_sweep; int r1_pools; int no_digits; };
+//   CLO_BITONIC_MERGE2   0: no two-tile merge passes in the tiled bitonic schedule, 2: at every stage; unset / 1: where they save a pass
+struct clo_hip_env_t { unsigned max_spins; int radix_sweep; int r1_pools; int no_digits; int bitonic_merge2; };
 const clo_hip_env_t* clo_hip_env();
 int clo_radixw_preload();   // clo_hip_radixw.hip
 

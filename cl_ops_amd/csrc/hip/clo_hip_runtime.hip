@@ -171,20 +171,22 @@ int clo_hip_event_record(void* event, void* stream) {
 	return (int) hipEventRecord((hipEvent_t) event, (hipStream_t) stream);
 }
 // ---- environment switches: one reader (clo_hip_internal.h has the list) ----
-static clo_hip_env_t g_env = { CLO_MAX_SPINS, 2, 0, 0 };
+static clo_hip_env_t g_env = { CLO_MAX_SPINS, 2, 0, 0, 1 };
 static int g_env_read = 0;
 void clo_hip_env_refresh(void) {
-	clo_hip_env_t e = { CLO_MAX_SPINS, 2, 0, 0 };
+	clo_hip_env_t e = { CLO_MAX_SPINS, 2, 0, 0, 1 };
 	if (const char* m = getenv("CLO_MAX_SPINS")) e.max_spins = (unsigned) strtoul(m, nullptr, 10);
 	if (const char* m = getenv("CLO_RADIX_SWEEP")) e.radix_sweep = atoi(m) != 0 ? 1 : 0;
 	if (const char* m = getenv("CLO_R1_POOLS")) e.r1_pools = atoi(m);
 	e.no_digits = getenv("CLO_RADIX_NO_DIGITS") != nullptr;
+	if (const char* m = getenv("CLO_BITONIC_MERGE2")) e.bitonic_merge2 = atoi(m);
 	// (objects may be created on several threads while others sort: field by field, never a torn struct — the values
 	// only differ from the ones already there when the environment changed between two object creations)
 	__atomic_store_n(&g_env.max_spins, e.max_spins, __ATOMIC_RELAXED);
 	__atomic_store_n(&g_env.radix_sweep, e.radix_sweep, __ATOMIC_RELAXED);
 	__atomic_store_n(&g_env.r1_pools, e.r1_pools, __ATOMIC_RELAXED);
 	__atomic_store_n(&g_env.no_digits, e.no_digits, __ATOMIC_RELAXED);
+	__atomic_store_n(&g_env.bitonic_merge2, e.bitonic_merge2, __ATOMIC_RELAXED);
 	__atomic_store_n(&g_env_read, 1, __ATOMIC_RELEASE);
 }
 int clo_hip_event_synchronize(void* event) { return (int) hipEventSynchronize((hipEvent_t) event); }

@@ -153,3 +153,45 @@ def test_radix_tiles_that_end_at_the_64k_boundary(gpu, etype, dt, keys):
     s.close()
     q.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("etype,dt,log2n", [("uint", np.uint32, 20), ("int", np.int32, 21), ("float", np.float32, 20),
+                                            ("ulong", np.uint64, 19), ("long", np.int64, 20), ("uint", np.uint32, 24)])
+def test_abitonic_two_tile_merge_modes(gpu, etype, dt, log2n):
+    """The tiled bitonic schedule with no two-tile merge pass (CLO_BITONIC_MERGE2=0), with one where it saves a strided
+    pass (the default) and with one at EVERY stage above the tile (2): the same network cut into launches three ways —
+    the same result, ascending and descending, also for a size that is no power of two."""
+    import os
+    import cl_ops_amd as clo
+    from cl_ops_amd._hip import lib
+    rng = np.random.default_rng(log2n)
+    n = (1 << log2n) - (12345 if log2n == 21 else 0)
+    if np.issubdtype(dt, np.floating):
+        a = rng.standard_normal(n).astype(dt)
+    else:
+        a = rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, n, dtype=dt, endpoint=True)
+    ctx = clo.Context(0)
+    q = clo.Queue(ctx)
+    old = os.environ.get("CLO_BITONIC_MERGE2")
+    try:
+        for mode in ("0", "1", "2"):
+            os.environ["CLO_BITONIC_MERGE2"] = mode
+            lib.clo_hip_env_refresh()
+            for opts, exp in ((None, np.sort(a)), ("desc", np.sort(a)[::-1])):
+                s = clo.Sorter("abitonic", ctx, etype, compare="((a) < (b))" if opts else None)   # (upstream's compare says when to SWAP: "<" sorts descending)
+                src, dst = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, a.nbytes)
+                src.write(q, a)
+                s.with_device_data(q, src, dst, n)
+                got = dst.read(q, dt, n)
+                assert np.array_equal(got, exp), (mode, opts)
+                for b in (src, dst):
+                    b.close()
+                s.close()
+    finally:
+        if old is None:
+            os.environ.pop("CLO_BITONIC_MERGE2", None)
+        else:
+            os.environ["CLO_BITONIC_MERGE2"] = old
+        lib.clo_hip_env_refresh()
+        q.close()
+        ctx.close()
