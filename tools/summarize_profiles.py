@@ -57,7 +57,8 @@ def families(rows, launches_of):
         fam = next((lab for needle, lab in FAMILY_OF if needle in name), None)
         if fam is None:
             continue
-        base = name.split("<")[0].replace("_bytes", "")   # (the two histogram kernels are alternatives: first pass / later passes)
+        # (the two histogram kernels are alternatives: first pass / later passes; so are the one- and the two-tile merge pass)
+        base = name.split("<")[0].replace("_bytes", "").replace("merge2", "merge")
         d = acc.setdefault(fam, {}).setdefault(base, {"kernels": [], "bytes_total": 0, "launches": 0})
         d["kernels"].append(name)
         d["bytes_total"] += b * n
