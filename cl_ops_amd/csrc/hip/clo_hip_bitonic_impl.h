@@ -831,8 +831,9 @@ int tiled_run(void* vdata, size_t numel, int key_shift, int key_bits, int key_si
 		unsigned p = stage;
 		// The two-tile merge where it saves more than it costs (CLO_MERGE2_EXTRA us over a merge pass: 0.099 against 0.082 ms):
 		// 2^26 uint32 — stages 15, 24, 25 — 2.48 -> 2.39 ms, 2^24 0.556 -> 0.535; at every stage: 2.55 (profiles/r05_abitonic_merge2.txt).
-		// From 64 tiles on (fewer: its groups, one per CU, are too few — 2^16 elements 0.040 -> 0.042 ms).
-		const bool use_m2 = MODE != 0 && merge2_mode != 0 && kl == KLF && tiles >= (merge2_mode == 2 ? 2u : 64u) && (merge2_mode == 2 || strided_cost(stage - kl) > strided_cost(stage - kl - 1u) + CLO_MERGE2_EXTRA);
+		// From 64 tiles on (fewer: its groups, one per CU, are too few — 2^16 elements 0.040 -> 0.042 ms). 4-byte elements only: on
+		// 8-byte ones the two-tile pass costs 0.167 ms against 0.108 (2^25 ulong 3.19 -> 3.21 ms with it); 1- and 2-byte: not measured.
+		const bool use_m2 = MODE != 0 && merge2_mode != 0 && kl == KLF && tiles >= (merge2_mode == 2 ? 2u : 64u) && (merge2_mode == 2 || (sizeof(E) == 4 && strided_cost(stage - kl) > strided_cost(stage - kl - 1u) + CLO_MERGE2_EXTRA));
 		const unsigned stop = use_m2 ? kl + 1u : kl;   // the strided passes end above this step
 		while (p > stop) {
 			unsigned ns = p - stop;

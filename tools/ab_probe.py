@@ -2,7 +2,7 @@
   python tools/ab_probe.py --libs lib,lib_old --jobs sort:uint:28,scan:uint:26 [--rounds 2] [--steps 20]
 Every (library, round) is a child process with CLO_HIP_LIBRARY set; inside it every job is timed the way bench.py
 times a step: K back-to-back calls between one pair of events (plus the per-kernel-family event times of K more calls).
-Jobs: sort:<uint|ulong|pairs>:<log2 n>[:radix]   scan:<uint|ulong>:<log2 n>   abitonic:<log2 n>   sbitonic:<log2 n>"""
+Jobs: sort:<uint|ulong|pairs>:<log2 n>[:radix]   scan:<uint|ulong>:<log2 n>   abitonic:<log2 n>[:uint|ulong|float]   sbitonic:<log2 n>"""
 import argparse
 import os
 import subprocess
@@ -84,12 +84,14 @@ def child(jobs, steps):
             src.close(); dst.close(); sc.close()
         elif f[0] in ("abitonic", "sbitonic"):
             n = 1 << int(f[1])
-            a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
-            s = clo.Sorter(f[0], ctx, "uint")
+            et = f[2] if len(f) > 2 else "uint"   # abitonic:<log2 n>[:uint|ulong|float]
+            bdt = {"uint": np.uint32, "ulong": np.uint64, "float": np.float32}[et]
+            a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(bdt) if et != "ulong" else rng.integers(0, 2**63, n, dtype=np.uint64)
+            s = clo.Sorter(f[0], ctx, et)
             src, dst = clo.Buffer(ctx, a.nbytes), clo.Buffer(ctx, a.nbytes)
             src.write(q, a)
             ms, k = run(lambda: s.with_device_data(q, src, dst, n), ["bitonic_presort", "bitonic_tile", "bitonic_strided", "bitonic_strided2", "bitonic_step"])
-            got = dst.read(q, np.uint32, n)
+            got = dst.read(q, bdt, n)
             print("RESULT %s ms=%.4f Mkeys/s=%.0f ok=%s | %s" % (job, ms, n / ms / 1e3, bool(np.all(got[:-1] <= got[1:])), k), flush=True)
             src.close(); dst.close(); s.close()
     q.close()
